@@ -1,0 +1,170 @@
+/* TEST INFRASTRUCTURE — not part of the product.
+ *
+ * Scalar fp32 helpers for the CPU oracle: GLSL-like vector types with a fixed,
+ * documented evaluation order, and the deterministic transcendental functions
+ * ("vkr math") whose polynomial form is mirrored by the HIP kernels so that
+ * CPU and GPU results can be compared bit for bit.  The oracle can also be
+ * switched to libm (math_mode 0) to show that nothing hides behind the
+ * polynomials.
+ *
+ * GLSL leaves the precision of atan/acos/sin/cos/inversesqrt to the driver
+ * (reference: src/shaders/polygon_sampling.glsl:79-82 quotes "at most 2 ulps" for
+ * native atan on Turing).  Both modes here are within 2-3 ulp of the exact value
+ * (tests/test_oracle_math.py).
+ *
+ * Everything must be compiled with -ffp-contract=off; fused operations appear
+ * only where the GLSL says fma(). */
+#ifndef ORACLE_MATH_H
+#define ORACLE_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define O_PI 3.1415926535897932384626433832795f
+#define O_INV_PI 0.31830988618379067153776752674503f
+#define O_HALF_PI 1.5707963267948966192313216916398f
+
+typedef struct { float x, y; } v2;
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+/* column-major like GLSL: c[i] is column i */
+typedef struct { v3 c[3]; } m3;
+typedef struct { v3 c[4]; } m43;
+typedef struct { v2 c[2]; } m2;
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline v2 mk2(float x, float y) { v2 r = {x, y}; return r; }
+static inline v3 mk3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v2 add2(v2 a, v2 b) { return mk2(a.x + b.x, a.y + b.y); }
+static inline v2 sub2(v2 a, v2 b) { return mk2(a.x - b.x, a.y - b.y); }
+static inline v2 scale2(v2 a, float s) { return mk2(a.x * s, a.y * s); }
+static inline v2 neg2(v2 a) { return mk2(-a.x, -a.y); }
+static inline v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 scale3(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+static inline v3 mul3(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 neg3(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+/* dot products accumulate left to right, no fusing */
+static inline float dot2(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b) {
+	return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* fma(vec3(s), a, b) */
+static inline v3 fma3s(float s, v3 a, v3 b) { return mk3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
+static inline v2 fma2s(float s, v2 a, v2 b) { return mk2(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y)); }
+static inline float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
+static inline v3 normalize3(v3 a) { return scale3(a, rsqrt_f(dot3(a, a))); }
+static inline v2 normalize2(v2 a) { return scale2(a, rsqrt_f(dot2(a, a))); }
+static inline float clamp_f(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static inline v2 rot90(v2 a) { return mk2(-a.y, a.x); }
+/* M * v = c0*v.x + c1*v.y + c2*v.z, accumulated left to right */
+static inline v3 m3_mul(const m3* m, v3 v) {
+	return mk3(
+		(m->c[0].x * v.x + m->c[1].x * v.y) + m->c[2].x * v.z,
+		(m->c[0].y * v.x + m->c[1].y * v.y) + m->c[2].y * v.z,
+		(m->c[0].z * v.x + m->c[1].z * v.y) + m->c[2].z * v.z);
+}
+/* mat4x3 * vec4(p, w) */
+static inline v3 m43_mul(const m43* m, v3 p, float w) {
+	return mk3(
+		((m->c[0].x * p.x + m->c[1].x * p.y) + m->c[2].x * p.z) + m->c[3].x * w,
+		((m->c[0].y * p.x + m->c[1].y * p.y) + m->c[2].y * p.z) + m->c[3].y * w,
+		((m->c[0].z * p.x + m->c[1].z * p.y) + m->c[2].z * p.z) + m->c[3].z * w);
+}
+/* (transpose(mat4x3) * d).xyz */
+static inline v3 m43_mul_transposed(const m43* m, v3 d) {
+	return mk3(dot3(m->c[0], d), dot3(m->c[1], d), dot3(m->c[2], d));
+}
+
+/* ---- deterministic transcendental functions (mirrored in the HIP kernels) -- */
+
+/* 0 = libm, 1 = polynomial "vkr math" */
+extern int g_oracle_math_mode;
+
+static inline float poly_atan_core(float z) {
+	/* atan(z) for z in [0,1]: z + z*s*P(s); coefficients from oracle/tools/fit_math.py */
+	float s = z * z;
+	float p = -2.508576494e-03f;
+	p = fmaf(p, s, 1.399648376e-02f);
+	p = fmaf(p, s, -3.667028621e-02f);
+	p = fmaf(p, s, 6.318219751e-02f);
+	p = fmaf(p, s, -8.689044416e-02f);
+	p = fmaf(p, s, 1.104203537e-01f);
+	p = fmaf(p, s, -1.427961588e-01f);
+	p = fmaf(p, s, 1.999979019e-01f);
+	p = fmaf(p, s, -3.333333135e-01f);
+	return fmaf(z * s, p, z);
+}
+
+static inline float vkr_atanf(float t) {
+	float a = fabsf(t);
+	int big = a > 1.0f;
+	float z = big ? (1.0f / a) : a;
+	float r = poly_atan_core(z);
+	r = big ? (O_HALF_PI - r) : r;
+	return copysignf(r, t);
+}
+
+static inline float poly_asin_tail(float z, float s) {
+	/* asin(z) - z = z*s*R(s), s = z*z <= 0.25 */
+	float r = 3.392100707e-02f;
+	r = fmaf(r, s, 1.700583287e-02f);
+	r = fmaf(r, s, 3.113191016e-02f);
+	r = fmaf(r, s, 4.459662735e-02f);
+	r = fmaf(r, s, 7.500103116e-02f);
+	r = fmaf(r, s, 1.666666567e-01f);
+	return (z * s) * r;
+}
+
+/* acos for arguments in [0,1] (the shaders always clamp first) */
+static inline float vkr_acosf_unit(float x) {
+	if (x <= 0.5f) {
+		float s = x * x;
+		return (O_HALF_PI - x) - poly_asin_tail(x, s);
+	}
+	else {
+		float s = (1.0f - x) * 0.5f;
+		float z = sqrtf(s);
+		return 2.0f * (z + poly_asin_tail(z, s));
+	}
+}
+
+static inline void vkr_sincosf(float x, float* out_sin, float* out_cos) {
+	const float two_over_pi = 0.63661977236758134308f;
+	const float pio2_hi = 1.57079637050628662109375f;
+	const float pio2_lo = -4.37113882867379e-8f;
+	float k = rintf(x * two_over_pi);
+	float r = fmaf(-k, pio2_hi, x);
+	r = fmaf(-k, pio2_lo, r);
+	float s = r * r;
+	float ps = 2.724694696e-06f;
+	ps = fmaf(ps, s, -1.984006376e-04f);
+	ps = fmaf(ps, s, 8.333331905e-03f);
+	ps = fmaf(ps, s, -1.666666716e-01f);
+	float sn = fmaf(r * s, ps, r);
+	float pc = -2.729846358e-07f;
+	pc = fmaf(pc, s, 2.480058174e-05f);
+	pc = fmaf(pc, s, -1.388888806e-03f);
+	pc = fmaf(pc, s, 4.166666791e-02f);
+	float cs = fmaf(s * s, pc, fmaf(-0.5f, s, 1.0f));
+	int q = ((int) k) & 3;
+	float s_out = (q & 1) ? cs : sn;
+	float c_out = (q & 1) ? sn : cs;
+	s_out = (q & 2) ? -s_out : s_out;
+	c_out = ((q + 1) & 2) ? -c_out : c_out;
+	*out_sin = s_out;
+	*out_cos = c_out;
+}
+
+static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : atanf(t); }
+static inline float o_acos_unit(float x) { return g_oracle_math_mode ? vkr_acosf_unit(x) : acosf(x); }
+static inline void o_sincos(float x, float* s, float* c) {
+	if (g_oracle_math_mode) vkr_sincosf(x, s, c);
+	else { *s = sinf(x); *c = cosf(x); }
+}
+
+#endif
