@@ -1,0 +1,72 @@
+/* Scene loader: reference src/scene.h:47-184.  Vulkan buffers become device
+ * pointers; the driver-built acceleration structure becomes an LBVH built by HIP
+ * kernels; material textures are reduced to one constant texel per texture
+ * (texture filtering is out of scope). */
+#ifndef VKR_SCENE_H
+#define VKR_SCENE_H
+#include "vkr_device.h"
+
+/*! reference scene.h:47-116 */
+typedef struct mesh_s {
+	uint64_t triangle_count;
+	float dequantization_factor[3], dequantization_summand[3];
+	/*! 2 uint32_t per vertex, 3 vertices per triangle (bit layout: scene.h:56-61) */
+	uint32_t* host_positions;
+	/*! 4 uint16_t per vertex: octahedral normal xy, texture coordinate xy */
+	uint16_t* host_normals_and_tex_coords;
+	/*! one uint8_t per triangle */
+	uint8_t* host_material_indices;
+	void* positions;
+	void* normals_and_tex_coords;
+	void* material_indices;
+} mesh_t;
+
+/*! reference scene.h:119-137 */
+typedef enum material_texture_type_e {
+	material_texture_type_base_color,
+	material_texture_type_specular,
+	material_texture_type_normal,
+	material_texture_count
+} material_texture_type_t;
+
+/*! reference scene.h:143-156, with textures collapsed to constants */
+typedef struct materials_s {
+	uint64_t material_count;
+	char** material_names;
+	/*! 8 floats per material: base_color.rgb, specular.rgb (occlusion, linear
+		roughness, metalicity), normal.xy (0.5, 0.5 is the geometric normal) */
+	float* host_constants;
+	void* constants;
+} materials_t;
+
+/*! Replaces reference scene.h:161-175: a binary LBVH over the de-quantised
+	triangle soup (same de-quantisation as scene.c:176-187). */
+typedef struct acceleration_structure_s {
+	/*! float4 per vertex, 3 per triangle, in LBVH leaf order */
+	void* triangle_vertices;
+	/*! original triangle index per leaf slot */
+	void* triangle_indices;
+	/*! (2 * triangle_count - 1) nodes, see vulkan_renderer_amd/csrc/lbvh.h */
+	void* nodes;
+	uint32_t node_count;
+	uint32_t root;
+} acceleration_structure_t;
+
+/*! reference scene.h:161-166 */
+typedef struct scene_s {
+	mesh_t mesh;
+	materials_t materials;
+	acceleration_structure_t acceleration_structure;
+} scene_t;
+
+/*! reference scene.h:171 */
+VKR_API const char* get_material_texture_suffix(material_texture_type_t type);
+/*! reference scene.h:181 / scene.c:409-559.  texture_path/<material>_<suffix>.vkt
+	files are read when present (uncompressed float / half formats only; the
+	smallest mip level supplies the constant), otherwise defaults apply: base
+	colour 0.8, specular (1, 0.5, 0), flat normal. */
+VKR_API int load_scene(scene_t* scene, const device_t* device, const char* file_path, const char* texture_path, VkBool32 request_acceleration_structure);
+/*! reference scene.h:184 */
+VKR_API void destroy_scene(scene_t* scene, const device_t* device);
+
+#endif

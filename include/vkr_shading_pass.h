@@ -1,0 +1,238 @@
+/* The shading pass behind the reference's own entry points.
+ *
+ * Reference call path (src/main.c): create_shading_pass (:598) selects the shader
+ * variant from render_settings_t + scene_specification_t, write_constants (:2114)
+ * fills the uniform buffer every frame, record_render_frame_commands (:1428-1434)
+ * runs the pass with vkCmdDraw(3) over the viewport, implement_screenshot (:1719)
+ * reads the result back.  The functions below keep those names and argument
+ * meanings; application_t is reduced to the members that path touches. */
+#ifndef VKR_SHADING_PASS_H
+#define VKR_SHADING_PASS_H
+#include "vkr_device.h"
+#include "vkr_camera.h"
+#include "vkr_polygonal_light.h"
+#include "vkr_ltc_table.h"
+#include "vkr_noise_table.h"
+#include "vkr_scene.h"
+
+/*! reference main.h:28-42 */
+typedef struct scene_specification_s {
+	char* file_path;
+	char* texture_path;
+	char* quick_save_path;
+	first_person_camera_t camera;
+	uint32_t polygonal_light_count;
+	polygonal_light_t* polygonal_lights;
+} scene_specification_t;
+
+/*! reference main.h:45-67 */
+typedef enum sampling_strategies_e {
+	sampling_strategies_diffuse_only,
+	sampling_strategies_diffuse_ggx_mis,
+	sampling_strategies_diffuse_specular_separately,
+	sampling_strategies_diffuse_specular_mis,
+	sampling_strategies_diffuse_specular_random,
+	sampling_strategies_count
+} sampling_strategies_t;
+
+/*! reference main.h:71-89 */
+typedef enum mis_heuristic_e {
+	mis_heuristic_balance,
+	mis_heuristic_power,
+	mis_heuristic_weighted,
+	mis_heuristic_optimal_clamped,
+	mis_heuristic_optimal,
+	mis_heuristic_count
+} mis_heuristic_t;
+
+/*! reference main.h:93-118.  Only error_display_none is implemented in the
+	kernels; the sampler's error functions are exposed for tests instead. */
+typedef enum error_display_e {
+	error_display_none,
+	error_display_diffuse_backward,
+	error_display_diffuse_backward_scaled,
+	error_display_diffuse_forward,
+	error_display_specular_backward,
+	error_display_specular_backward_scaled,
+	error_display_specular_forward,
+	error_display_count
+} error_display_t;
+
+/*! reference main.h:128-159, same member order */
+typedef struct render_settings_s {
+	float exposure_factor, roughness_factor;
+	uint32_t sample_count;
+	sampling_strategies_t sampling_strategies;
+	mis_heuristic_t mis_heuristic;
+	float mis_visibility_estimate;
+	sample_polygon_technique_t polygon_sampling_technique;
+	error_display_t error_display;
+	float error_min_exponent;
+	noise_type_t noise_type;
+	VkBool32 animate_noise;
+	VkBool32 trace_shadow_rays;
+	VkBool32 show_polygonal_lights;
+	VkBool32 show_gui;
+	VkBool32 v_sync;
+} render_settings_t;
+
+/*! reference main.h:488-505; byte image of the uniform block
+	shared_constants.glsl:20-66 (std140, row_major) */
+typedef struct per_frame_constants_s {
+	float mesh_dequantization_factor[3], padding_0, mesh_dequantization_summand[3];
+	float error_factor;
+	float world_to_projection_space[4][4];
+	float pixel_to_ray_direction_world_space[3][4];
+	float camera_position_world_space[3];
+	float mis_visibility_estimate;
+	VkExtent2D viewport_size;
+	int32_t cursor_position[2];
+	float exposure_factor;
+	float roughness_factor;
+	uint32_t noise_resolution_mask[2];
+	uint32_t noise_texture_index_mask;
+	uint32_t frame_bits;
+	uint32_t padding_3[2];
+	uint32_t noise_random_numbers[4];
+	ltc_constants_t ltc_constants;
+} per_frame_constants_t;
+
+/*! Only the extent of the reference swapchain_t matters to the pass */
+typedef struct swapchain_s {
+	VkExtent2D extent;
+} swapchain_t;
+
+/*! Replaces render_targets_t (reference main.h:233-247) plus the swapchain
+	image the pass writes: linear device buffers, row-major. */
+typedef struct render_targets_s {
+	/*! R32_UINT primitive index per pixel, 0xFFFFFFFF = nothing visible
+		(reference main.c:282-298, cleared at main.c:1409) */
+	void* visibility_buffer;
+	/*! RGBA32F, vec4(final_color * exposure, 1): the value the reference
+		computes at shading_pass.frag.glsl:866 before any output encoding */
+	void* radiance;
+	/*! RGBA8 after the reference's output encoding (sRGB or half-bit split,
+		shading_pass.frag.glsl:871-892); filled by encode_output() */
+	void* encoded;
+	VkExtent2D extent;
+} render_targets_t;
+
+/*! frame_bits of reference screenshot_t (main.h:405-428): 0 = LDR frame, 1 / 2 =
+	low / high byte of the half-float HDR screenshot */
+typedef struct screenshot_s {
+	uint32_t frame_bits;
+} screenshot_t;
+
+/*! How pixels are distributed over GPUs: the image is cut into square tiles,
+	tile t (row-major) belongs to rank t % rank_count, and a rank stores its tiles
+	densely one after the other ("slab").  rank_count == 1 renders in place. */
+typedef struct tile_schedule_s {
+	uint32_t tile_size;
+	uint32_t rank, rank_count;
+} tile_schedule_t;
+
+/*! Replaces shading_pass_t (reference main.h:278-285).  The "pipeline" is a
+	pre-compiled kernel variant chosen on the same axes as the reference's
+	preprocessor defines (main.c:752-792). */
+typedef struct shading_pass_s {
+	VkBool32 use_ray_tracing;
+	/*! index into the kernel variant table, negative if none */
+	int32_t variant;
+	/*! MAX_POLYGON_VERTEX_COUNT of the selected variant (main.c:194-216) */
+	uint32_t max_polygon_vertex_count;
+	/*! device + pinned host staging copy of the constant buffer */
+	void* constants_device;
+	void* constants_host;
+	size_t constants_size;
+	/*! arithmetic mode: 0 = exact (IEEE division/sqrt, no contraction; bit-comparable
+		with the CPU oracle), 1 = fast (approximate reciprocals, contraction) */
+	int32_t fast_math;
+	/*! timing of the last dispatch in milliseconds (HIP events on device->stream) */
+	float last_dispatch_ms;
+	void* timing_events[2];
+} shading_pass_t;
+
+/*! The slice of reference application_t (main.h:440-476) that the pass uses */
+typedef struct application_s {
+	device_t device;
+	swapchain_t swapchain;
+	scene_specification_t scene_specification;
+	render_settings_t render_settings;
+	scene_t scene;
+	noise_table_t noise_table;
+	ltc_table_t ltc_table;
+	render_targets_t render_targets;
+	screenshot_t screenshot;
+	shading_pass_t shading_pass;
+	tile_schedule_t tile_schedule;
+} application_t;
+
+/*! reference main.c:232-249 */
+VKR_API void specify_default_render_settings(render_settings_t* settings);
+/*! reference main.c:173-216 */
+VKR_API uint32_t get_min_polygonal_light_vertex_count(const scene_specification_t* scene_specification);
+VKR_API uint32_t get_max_polygonal_light_vertex_count(const scene_specification_t* scene_specification);
+VKR_API uint32_t get_max_polygon_vertex_count(const scene_specification_t* scene_specification, const render_settings_t* render_settings);
+/*! reference main.c:219-229 */
+VKR_API void destroy_scene_specification(scene_specification_t* scene);
+/*! reference main.c:49-80 / :82-130.  `updates` of the reference is reduced to an
+	optional flag that is set when light count or vertex counts changed. */
+VKR_API void quick_save(scene_specification_t* scene);
+VKR_API void quick_load(scene_specification_t* scene, VkBool32* light_count_changed);
+
+/*! reference create_render_targets main.c:259-327 / destroy main.c:253-257 */
+VKR_API int create_render_targets(render_targets_t* targets, const device_t* device, const swapchain_t* swapchain);
+VKR_API void destroy_render_targets(render_targets_t* targets, const device_t* device);
+
+/*! Size in bytes of what write_constants() writes: sizeof(per_frame_constants_t)
+	plus the packed light array (reference create_constant_buffers main.c:330-360) */
+VKR_API size_t get_constant_buffer_size(const application_t* app);
+/*! reference main.c:2114-2188: byte-identical output (the cursor position, which
+	the reference reads from GLFW, is written as 0,0) */
+VKR_API void write_constants(void* data, application_t* app);
+
+/*! reference main.c:598-913: validates the settings the way the GUI does
+	(user_interface.cpp:90-180), picks the kernel variant and allocates the constant
+	buffer.  Returns 0 on success, 1 on failure (message printed, pass destroyed). */
+VKR_API int create_shading_pass(shading_pass_t* pass, application_t* app);
+/*! reference main.c:588-595 */
+VKR_API void destroy_shading_pass(shading_pass_t* pass, const device_t* device);
+
+/*! Replaces the visibility sub-pass (reference main.c:1421-1427,
+	visibility_pass.*.glsl): closest hit through pixel centres with back-face
+	culling against the LBVH.  Requires an acceleration structure. */
+VKR_API int render_visibility_pass(application_t* app);
+/*! Replaces sub-pass 1 of record_render_frame_commands (reference main.c:1428-1434):
+	write_constants -> upload -> one launch over the tiles of app->tile_schedule.
+	`out_radiance` NULL writes app->render_targets.radiance (full frame layout when
+	rank_count == 1, slab layout otherwise). */
+VKR_API int render_shading_pass(application_t* app, void* out_radiance);
+/*! Number of pixels / floats of one rank's slab for the current schedule */
+VKR_API uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank);
+/*! Scatters the all-gathered slabs (rank-major, each padded to
+	get_slab_pixel_count(app, 0) pixels) back into a row-major frame */
+VKR_API int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance);
+/*! Output encoding of shading_pass.frag.glsl:871-892 into render_targets.encoded */
+VKR_API int encode_output(application_t* app, VkBool32 output_linear_rgb);
+/*! Synchronous copies to host memory (implement_screenshot, main.c:1601-1631) */
+VKR_API int read_back_radiance(application_t* app, float* host_rgba);
+VKR_API int read_back_encoded(application_t* app, uint8_t* host_rgba8);
+VKR_API int read_back_visibility(application_t* app, uint32_t* host_primitives);
+/*! Upload a visibility buffer produced elsewhere (tests, external rasteriser) */
+VKR_API int upload_visibility(application_t* app, const uint32_t* host_primitives);
+/*! GPU time of the last render_shading_pass launch in milliseconds, measured with
+	HIP events on the device's stream (blocks until the launch has finished) */
+VKR_API float get_last_dispatch_milliseconds(application_t* app);
+/*! Number of shadow rays the last render_shading_pass traced (0 when the variant
+	was built without counters) */
+VKR_API uint64_t get_last_ray_count(const application_t* app);
+
+/*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,
+	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,
+	materials_t, acceleration_structure_t, scene_t, scene_specification_t,
+	render_settings_t, per_frame_constants_t, swapchain_t, render_targets_t,
+	screenshot_t, tile_schedule_t, shading_pass_t, application_t) so that bindings can
+	check their mirrors.  Returns the number of structs. */
+VKR_API uint32_t get_abi_struct_sizes(uint64_t* sizes, uint32_t capacity);
+
+#endif

@@ -64,6 +64,7 @@ def lib():
         L.oracle_bvh_build.argtypes = [C.c_void_p, C.c_uint64, fp, fp]
         L.oracle_bvh_destroy.argtypes = [C.c_void_p]
         L.oracle_bvh_any_hit.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, C.c_int]
+        L.oracle_primary_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.oracle_clip_polygon.restype = C.c_uint32
         L.oracle_clip_polygon.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, fp]
         L.oracle_psa_prepare.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
@@ -232,4 +233,11 @@ def encode_half_bits(rgba, frame_bits, output_linear_rgb=False):
     a = _f32(rgba)
     out = np.zeros(a.shape[:-1] + (4,), np.uint8)
     lib().oracle_encode_half_bits(a.ctypes.data, out.ctypes.data, a.size // 4, frame_bits, int(output_linear_rgb))
+    return out
+
+
+def primary_visibility(constants, bvh, width, height, near, far):
+    c = np.ascontiguousarray(constants, dtype=np.uint8)
+    out = np.zeros((height, width), np.uint32)
+    lib().oracle_primary_visibility(c.ctypes.data, bvh.handle, width, height, near, far, out.ctypes.data)
     return out

@@ -81,6 +81,9 @@ void oracle_encode_half_bits(const float* rgba, uint8_t* out_rgba8, uint64_t pix
  * for de-quantisation, shading_pass.frag.glsl:120-138 for the ray query) */
 void* oracle_bvh_build(const uint32_t* quantized_positions, uint64_t triangle_count, const float dequantization_factor[3], const float dequantization_summand[3]);
 void oracle_bvh_destroy(void* bvh);
+uint32_t oracle_bvh_closest_front_hit(const void* bvh, const float origin[3], const float dir[3], float t_min, float t_max);
+/* visibility buffer through pixel centres: closest front-facing hit with view depth in [near, far] */
+void oracle_primary_visibility(const uint8_t* constants, const void* bvh, uint32_t width, uint32_t height, float near, float far, uint32_t* out_primitives);
 int oracle_bvh_any_hit(const void* bvh, const float origin[3], const float dir[3], float t_min, float t_max, int brute_force);
 
 /* ---- entry points for unit / property tests ---------------------------- */

@@ -174,3 +174,55 @@ int oracle_bvh_any_hit(const void* handle, const float o[3], const float d[3], f
 	}
 	return 0;
 }
+
+/* Closest hit among front-facing triangles (det > 0, i.e. the normal
+ * (v1-v0)x(v2-v0) faces the ray origin), t in [t_min, t_max]; ties go to the
+ * smaller primitive index.  Checker for the product's primary-visibility kernel,
+ * which stands in for the rasterised visibility pass of the reference
+ * (src/shaders/visibility_pass.vert.glsl:27-33, back-face culling and depth test
+ * at src/main.c:501-507,537-542). */
+static int ray_triangle_front(const float* t, const float o[3], const float d[3], float t_min, float t_max, float* out_dist) {
+	float e1[3] = {t[3] - t[0], t[4] - t[1], t[5] - t[2]};
+	float e2[3] = {t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+	float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+	float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
+	if (!(det > 0.0f)) return 0;
+	float inv = 1.0f / det;
+	float s[3] = {o[0] - t[0], o[1] - t[1], o[2] - t[2]};
+	float u = ((s[0] * p[0] + s[1] * p[1]) + s[2] * p[2]) * inv;
+	if (!(u >= 0.0f && u <= 1.0f)) return 0;
+	float q[3] = {s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0]};
+	float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv;
+	if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
+	float dist = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv;
+	*out_dist = dist;
+	return dist >= t_min && dist <= t_max;
+}
+
+uint32_t oracle_bvh_closest_front_hit(const void* handle, const float o[3], const float d[3], float t_min, float t_max) {
+	const bvh_t* b = (const bvh_t*) handle;
+	uint32_t best = 0xFFFFFFFFu;
+	if (!b) return best;
+	float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+	uint32_t stack[128];
+	int top = 0;
+	stack[top++] = 0;
+	while (top) {
+		const bvh_node_t* n = &b->nodes[stack[--top]];
+		if (!ray_box(n, o, inv, t_min, t_max)) continue;
+		if (n->count) {
+			for (uint32_t i = n->first; i != n->first + n->count; ++i) {
+				uint32_t primitive = b->order[i];
+				float dist;
+				if (ray_triangle_front(b->vertices + 9 * (size_t) primitive, o, d, t_min, t_max, &dist)) {
+					if (dist < t_max || primitive < best) { t_max = dist; best = primitive; }
+				}
+			}
+		}
+		else if (top + 2 <= 128) {
+			stack[top++] = n->first;
+			stack[top++] = n->first + 1;
+		}
+	}
+	return best;
+}

@@ -1236,6 +1236,21 @@ void oracle_shade_rows(const oracle_frame_t* frame, float* out_rgba, uint32_t y0
 	g_ray_count = rays;
 }
 
+void oracle_primary_visibility(const uint8_t* constants, const void* bvh, uint32_t width, uint32_t height, float near, float far, uint32_t* out) {
+	frame_constants_t k = read_frame_constants(constants);
+#pragma omp parallel for schedule(dynamic, 4)
+	for (int64_t y = 0; y < (int64_t) height; ++y)
+		for (uint32_t x = 0; x != width; ++x) {
+			float fx = (float) x, fy = (float) y;
+			float d[3] = {
+				(k.pixel_to_ray[0][0] * fx + k.pixel_to_ray[0][1] * fy) + k.pixel_to_ray[0][2],
+				(k.pixel_to_ray[1][0] * fx + k.pixel_to_ray[1][1] * fy) + k.pixel_to_ray[1][2],
+				(k.pixel_to_ray[2][0] * fx + k.pixel_to_ray[2][1] * fy) + k.pixel_to_ray[2][2]};
+			float o[3] = {k.camera_position.x, k.camera_position.y, k.camera_position.z};
+			out[(size_t) y * width + x] = oracle_bvh_closest_front_hit(bvh, o, d, near, far);
+		}
+}
+
 /* ---- output encodings, shading_pass.frag.glsl:871-892, srgb_utility.glsl --- */
 
 static float linear_to_srgb(float c) {

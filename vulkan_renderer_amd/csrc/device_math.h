@@ -1,0 +1,182 @@
+// Device-side arithmetic for the shading kernels (gfx950).
+//
+// Two arithmetic modes, selected at compile time per translation unit:
+//   VKR_FAST_MATH == 0  "exact": IEEE division and square roots, no contraction
+//                       (-ffp-contract=off), polynomial atan/acos/sincos with
+//                       explicit FMAs.  Every operation is correctly rounded, so the
+//                       result is reproducible on any IEEE machine.
+//   VKR_FAST_MATH == 1  "fast": v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and
+//                       -ffp-contract=fast; same algorithms.
+// The reference leaves these precisions to the GLSL driver
+// (src/shaders/polygon_sampling.glsl:79-82).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef VKR_FAST_MATH
+#define VKR_FAST_MATH 0
+#endif
+
+#define VKR_DEV __device__ __forceinline__
+
+namespace vkr {
+
+constexpr float kPi = 3.1415926535897932384626433832795f;
+constexpr float kInvPi = 0.31830988618379067153776752674503f;
+constexpr float kHalfPi = 1.5707963267948966192313216916398f;
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+VKR_DEV f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+VKR_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+VKR_DEV f2 operator+(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+VKR_DEV f2 operator-(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
+VKR_DEV f2 operator*(f2 a, float s) { return mk2(a.x * s, a.y * s); }
+VKR_DEV f2 operator-(f2 a) { return mk2(-a.x, -a.y); }
+VKR_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+VKR_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VKR_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+VKR_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+VKR_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+// dot products accumulate left to right
+VKR_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+VKR_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+VKR_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+VKR_DEV f3 fma3(float s, f3 a, f3 b) { return mk3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
+VKR_DEV f2 fma2(float s, f2 a, f2 b) { return mk2(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y)); }
+VKR_DEV f2 rot90(f2 a) { return mk2(-a.y, a.x); }
+
+// GLSL min/max/clamp as the specification words them
+VKR_DEV float gmax(float x, float y) { return (x < y) ? y : x; }
+VKR_DEV float gmin(float x, float y) { return (y < x) ? y : x; }
+VKR_DEV float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+VKR_DEV float positive_part(float x) { return (x > 0.0f) ? x : 0.0f; }
+
+VKR_DEV float rcp(float x) {
+#if VKR_FAST_MATH
+	return __builtin_amdgcn_rcpf(x);
+#else
+	return 1.0f / x;
+#endif
+}
+VKR_DEV float divide(float a, float b) {
+#if VKR_FAST_MATH
+	return a * __builtin_amdgcn_rcpf(b);
+#else
+	return a / b;
+#endif
+}
+VKR_DEV float square_root(float x) {
+#if VKR_FAST_MATH
+	return __builtin_amdgcn_sqrtf(x);
+#else
+	return sqrtf(x);
+#endif
+}
+VKR_DEV float rsqrt(float x) {
+#if VKR_FAST_MATH
+	return __builtin_amdgcn_rsqf(x);
+#else
+	return 1.0f / sqrtf(x);
+#endif
+}
+VKR_DEV f3 normalize(f3 a) { return a * rsqrt(dot(a, a)); }
+VKR_DEV f2 normalize(f2 a) { return a * rsqrt(dot(a, a)); }
+
+// 3x3 and 4x3 matrices, column major like GLSL
+struct m3 { f3 c[3]; };
+struct m43 { f3 c[4]; };
+VKR_DEV f3 mul(const m3& m, f3 v) {
+	return mk3(
+		(m.c[0].x * v.x + m.c[1].x * v.y) + m.c[2].x * v.z,
+		(m.c[0].y * v.x + m.c[1].y * v.y) + m.c[2].y * v.z,
+		(m.c[0].z * v.x + m.c[1].z * v.y) + m.c[2].z * v.z);
+}
+VKR_DEV f3 mul_point(const m43& m, f3 p) {
+	return mk3(
+		((m.c[0].x * p.x + m.c[1].x * p.y) + m.c[2].x * p.z) + m.c[3].x * 1.0f,
+		((m.c[0].y * p.x + m.c[1].y * p.y) + m.c[2].y * p.z) + m.c[3].y * 1.0f,
+		((m.c[0].z * p.x + m.c[1].z * p.y) + m.c[2].z * p.z) + m.c[3].z * 1.0f);
+}
+VKR_DEV f3 mul_direction(const m43& m, f3 p) {
+	return mk3(
+		((m.c[0].x * p.x + m.c[1].x * p.y) + m.c[2].x * p.z) + m.c[3].x * 0.0f,
+		((m.c[0].y * p.x + m.c[1].y * p.y) + m.c[2].y * p.z) + m.c[3].y * 0.0f,
+		((m.c[0].z * p.x + m.c[1].z * p.y) + m.c[2].z * p.z) + m.c[3].z * 0.0f);
+}
+VKR_DEV f3 mul_transposed(const m43& m, f3 d) { return mk3(dot(m.c[0], d), dot(m.c[1], d), dot(m.c[2], d)); }
+
+// ---- polynomial transcendentals (coefficients: oracle/tools/fit_math.py) -------
+
+VKR_DEV float atan_unit(float z) {
+	float s = z * z;
+	float p = -2.508576494e-03f;
+	p = fmaf(p, s, 1.399648376e-02f);
+	p = fmaf(p, s, -3.667028621e-02f);
+	p = fmaf(p, s, 6.318219751e-02f);
+	p = fmaf(p, s, -8.689044416e-02f);
+	p = fmaf(p, s, 1.104203537e-01f);
+	p = fmaf(p, s, -1.427961588e-01f);
+	p = fmaf(p, s, 1.999979019e-01f);
+	p = fmaf(p, s, -3.333333135e-01f);
+	return fmaf(z * s, p, z);
+}
+
+VKR_DEV float arctan(float t) {
+	float a = fabsf(t);
+	bool big = a > 1.0f;
+	float z = big ? rcp(a) : a;
+	float r = atan_unit(z);
+	r = big ? (kHalfPi - r) : r;
+	return copysignf(r, t);
+}
+
+VKR_DEV float asin_tail(float z, float s) {
+	float r = 3.392100707e-02f;
+	r = fmaf(r, s, 1.700583287e-02f);
+	r = fmaf(r, s, 3.113191016e-02f);
+	r = fmaf(r, s, 4.459662735e-02f);
+	r = fmaf(r, s, 7.500103116e-02f);
+	r = fmaf(r, s, 1.666666567e-01f);
+	return (z * s) * r;
+}
+
+// acos for arguments already clamped to [0, 1]
+VKR_DEV float arccos_unit(float x) {
+	if (x <= 0.5f) {
+		float s = x * x;
+		return (kHalfPi - x) - asin_tail(x, s);
+	}
+	float s = (1.0f - x) * 0.5f;
+	float z = square_root(s);
+	return 2.0f * (z + asin_tail(z, s));
+}
+
+VKR_DEV void sincos_poly(float x, float& out_sin, float& out_cos) {
+	const float two_over_pi = 0.63661977236758134308f;
+	const float pio2_hi = 1.57079637050628662109375f;
+	const float pio2_lo = -4.37113882867379e-8f;
+	float k = rintf(x * two_over_pi);
+	float r = fmaf(-k, pio2_hi, x);
+	r = fmaf(-k, pio2_lo, r);
+	float s = r * r;
+	float ps = 2.724694696e-06f;
+	ps = fmaf(ps, s, -1.984006376e-04f);
+	ps = fmaf(ps, s, 8.333331905e-03f);
+	ps = fmaf(ps, s, -1.666666716e-01f);
+	float sn = fmaf(r * s, ps, r);
+	float pc = -2.729846358e-07f;
+	pc = fmaf(pc, s, 2.480058174e-05f);
+	pc = fmaf(pc, s, -1.388888806e-03f);
+	pc = fmaf(pc, s, 4.166666791e-02f);
+	float cs = fmaf(s * s, pc, fmaf(-0.5f, s, 1.0f));
+	int q = ((int) k) & 3;
+	float s_out = (q & 1) ? cs : sn;
+	float c_out = (q & 1) ? sn : cs;
+	out_sin = (q & 2) ? -s_out : s_out;
+	out_cos = ((q + 1) & 2) ? -c_out : c_out;
+}
+
+}  // namespace vkr

@@ -1,0 +1,87 @@
+/* HIP context and memory helpers behind device_t.  Plain C on top of the HIP
+ * runtime's C API. */
+#include "vkr_internal.h"
+#include <hip/hip_runtime_api.h>
+
+static int check(hipError_t error, const char* what) {
+	if (error == hipSuccess) return 0;
+	printf("HIP error while %s: %s\n", what, hipGetErrorString(error));
+	return 1;
+}
+
+int create_hip_device(device_t* device, int32_t hip_device, void* existing_stream) {
+	memset(device, 0, sizeof(*device));
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		printf("No HIP device is available. The shading pass needs an MI355X (gfx950).\n");
+		return 1;
+	}
+	if (hip_device < 0 || hip_device >= count) {
+		printf("HIP device %d was requested but only %d devices exist.\n", hip_device, count);
+		return 1;
+	}
+	if (check(hipSetDevice(hip_device), "selecting the device")) return 1;
+	hipDeviceProp_t properties;
+	if (check(hipGetDeviceProperties(&properties, hip_device), "querying device properties")) return 1;
+	device->hip_device = hip_device;
+	device->stream = existing_stream;
+	device->ray_tracing_supported = VK_TRUE;
+	device->compute_unit_count = properties.multiProcessorCount;
+	strncpy(device->architecture, properties.gcnArchName, sizeof(device->architecture) - 1);
+	if (strncmp(device->architecture, "gfx950", 6) != 0)
+		printf("Warning: the kernels are built for gfx950 but device %d is %s.\n", hip_device, device->architecture);
+	return 0;
+}
+
+void destroy_hip_device(device_t* device) {
+	memset(device, 0, sizeof(*device));
+}
+
+int wait_for_device(const device_t* device) {
+	return check(hipStreamSynchronize((hipStream_t) device->stream), "waiting for the stream");
+}
+
+int vkr_device_alloc(void** out, const device_t* device, size_t size, const char* what) {
+	*out = NULL;
+	if (!device) return 0;
+	if (hipMalloc(out, size ? size : 1) != hipSuccess) {
+		printf("Failed to allocate %llu bytes of device memory for %s.\n", (unsigned long long) size, what);
+		*out = NULL;
+		return 1;
+	}
+	return 0;
+}
+
+void vkr_device_free(void* pointer, const device_t* device) {
+	(void) device;
+	if (pointer) hipFree(pointer);
+}
+
+int vkr_device_upload(void** out, const device_t* device, const void* host, size_t size, const char* what) {
+	if (vkr_device_alloc(out, device, size, what)) return 1;
+	if (!device) return 0;
+	if (check(hipMemcpy(*out, host, size, hipMemcpyHostToDevice), what)) {
+		hipFree(*out);
+		*out = NULL;
+		return 1;
+	}
+	return 0;
+}
+
+int vkr_host_alloc_pinned(void** out, size_t size) {
+	if (hipHostMalloc(out, size, hipHostMallocDefault) != hipSuccess) { *out = NULL; return 1; }
+	return 0;
+}
+
+void vkr_host_free_pinned(void* pointer) {
+	if (pointer) hipHostFree(pointer);
+}
+
+int vkr_copy_to_device_async(void* device_pointer, const void* host, size_t size, const device_t* device) {
+	return check(hipMemcpyAsync(device_pointer, host, size, hipMemcpyHostToDevice, (hipStream_t) device->stream), "uploading");
+}
+
+int vkr_copy_to_host(void* host, const void* device_pointer, size_t size, const device_t* device) {
+	if (check(hipMemcpyAsync(host, device_pointer, size, hipMemcpyDeviceToHost, (hipStream_t) device->stream), "reading back")) return 1;
+	return check(hipStreamSynchronize((hipStream_t) device->stream), "reading back");
+}

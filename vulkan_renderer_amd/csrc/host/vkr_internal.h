@@ -1,0 +1,45 @@
+/* Internal helpers shared by the host-side C files of libvkr_shading.so. */
+#ifndef VKR_INTERNAL_H
+#define VKR_INTERNAL_H
+#include "vkr_shading_pass.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define VKR_PI_F 3.1415926535897932384626433832795f
+#define VKR_COUNT_OF(a) (sizeof(a) / sizeof((a)[0]))
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*! malloc'ed copy of a string, NULL for NULL */
+char* vkr_copy_string(const char* s);
+/*! malloc'ed concatenation of count strings */
+char* vkr_concatenate(uint32_t count, const char* const* pieces);
+
+/*! Device memory helpers (device.c).  All return 0 on success and print the
+	HIP error otherwise.  A NULL device makes uploads a no-op that yields NULL. */
+int vkr_device_alloc(void** out, const device_t* device, size_t size, const char* what);
+void vkr_device_free(void* pointer, const device_t* device);
+int vkr_device_upload(void** out, const device_t* device, const void* host, size_t size, const char* what);
+int vkr_host_alloc_pinned(void** out, size_t size);
+void vkr_host_free_pinned(void* pointer);
+int vkr_copy_to_device_async(void* device_pointer, const void* host, size_t size, const device_t* device);
+int vkr_copy_to_host(void* host, const void* device_pointer, size_t size, const device_t* device);
+
+/*! 4x4 inverse with the operation order of reference math_utilities.h:24-47 */
+void vkr_matrix_inverse(float inverse[4][4], const float matrix[4][4]);
+/*! reference math_utilities.h:50-57 */
+uint32_t vkr_wang_random_number(uint32_t seed);
+
+/*! LBVH construction and kernels live on the HIP side (the .hip files in csrc) */
+int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh);
+void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, const device_t* device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

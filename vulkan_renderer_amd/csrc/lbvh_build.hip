@@ -1,0 +1,216 @@
+// LBVH construction on the GPU (Karras 2012: Morton codes -> radix sort ->
+// binary radix tree -> bottom-up refit).  Replaces create_acceleration_structure
+// of the reference (src/scene.c:142-406), which hands the same de-quantised
+// triangle soup to the Vulkan driver.  Runs once per scene.
+#include "lbvh.h"
+#include "host/vkr_internal.h"
+#include <hipcub/hipcub.hpp>
+
+using namespace vkr;
+
+namespace {
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+struct build_params {
+	const uint2* quantized_positions;
+	uint32_t triangle_count;
+	float factor[3], summand[3];
+	float pad;
+};
+
+// De-quantisation with two roundings (multiply, then add) like scene.c:176-187; the
+// shading path uses a fused decode instead (mesh_quantization.glsl:38-45).
+__device__ __forceinline__ f3 dequantize(uint2 q, const build_params& p) {
+	float x = (float) (q.x & 0x1FFFFF);
+	float y = (float) (((q.x & 0xFFE00000u) >> 21) | ((q.y & 0x3FF) << 11));
+	float z = (float) ((q.y & 0x7FFFFC00u) >> 10);
+	return mk3(__fadd_rn(__fmul_rn(x, p.factor[0]), p.summand[0]), __fadd_rn(__fmul_rn(y, p.factor[1]), p.summand[1]), __fadd_rn(__fmul_rn(z, p.factor[2]), p.summand[2]));
+}
+
+__device__ __forceinline__ uint32_t spread_bits_10(uint32_t v) {
+	v &= 0x3FF;
+	v = (v | (v << 16)) & 0x030000FF;
+	v = (v | (v << 8)) & 0x0300F00F;
+	v = (v | (v << 4)) & 0x030C30C3;
+	v = (v | (v << 2)) & 0x09249249;
+	return v;
+}
+
+__global__ void __launch_bounds__(256) k_morton_keys(build_params p, uint64_t* keys) {
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= p.triangle_count) return;
+	// centroid in quantisation units: 21 bits per axis, keep the top 10
+	uint32_t sum[3] = {0, 0, 0};
+	for (int v = 0; v != 3; ++v) {
+		uint2 q = p.quantized_positions[3 * (size_t) t + v];
+		sum[0] += q.x & 0x1FFFFF;
+		sum[1] += ((q.x & 0xFFE00000u) >> 21) | ((q.y & 0x3FF) << 11);
+		sum[2] += (q.y & 0x7FFFFC00u) >> 10;
+	}
+	uint32_t cx = (sum[0] / 3) >> 11, cy = (sum[1] / 3) >> 11, cz = (sum[2] / 3) >> 11;
+	uint32_t morton = (spread_bits_10(cx) << 2) | (spread_bits_10(cy) << 1) | spread_bits_10(cz);
+	keys[t] = ((uint64_t) morton << 32) | t;
+}
+
+__global__ void __launch_bounds__(256) k_write_leaves(build_params p, const uint64_t* sorted_keys, float4* triangles, float* lo, float* hi) {
+	uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= p.triangle_count) return;
+	uint32_t t = (uint32_t) (sorted_keys[slot] & 0xFFFFFFFFu);
+	f3 v[3];
+	for (int i = 0; i != 3; ++i) v[i] = dequantize(p.quantized_positions[3 * (size_t) t + i], p);
+	triangles[3 * (size_t) slot + 0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(t));
+	triangles[3 * (size_t) slot + 1] = make_float4(v[1].x, v[1].y, v[1].z, 0.0f);
+	triangles[3 * (size_t) slot + 2] = make_float4(v[2].x, v[2].y, v[2].z, 0.0f);
+	// leaf boxes live behind the inner-node boxes
+	size_t n = p.triangle_count - 1 + slot;
+	lo[3 * n + 0] = fminf(v[0].x, fminf(v[1].x, v[2].x)) - p.pad;
+	lo[3 * n + 1] = fminf(v[0].y, fminf(v[1].y, v[2].y)) - p.pad;
+	lo[3 * n + 2] = fminf(v[0].z, fminf(v[1].z, v[2].z)) - p.pad;
+	hi[3 * n + 0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x)) + p.pad;
+	hi[3 * n + 1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y)) + p.pad;
+	hi[3 * n + 2] = fmaxf(v[0].z, fmaxf(v[1].z, v[2].z)) + p.pad;
+}
+
+__device__ __forceinline__ int common_prefix(const uint64_t* keys, int n, int i, int j) {
+	if (j < 0 || j >= n) return -1;
+	return __clzll((long long) (keys[i] ^ keys[j]));
+}
+
+// One thread per inner node: range and split of the binary radix tree.  Inner
+// node i covers leaves [first, last]; children are inner nodes or leaves.
+__global__ void __launch_bounds__(256) k_build_hierarchy(const uint64_t* keys, int leaf_count, bvh_node* nodes, uint32_t* leaf_parents) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= leaf_count - 1) return;
+	int direction = (common_prefix(keys, leaf_count, i, i + 1) - common_prefix(keys, leaf_count, i, i - 1)) >= 0 ? 1 : -1;
+	int min_prefix = common_prefix(keys, leaf_count, i, i - direction);
+	int max_length = 2;
+	while (common_prefix(keys, leaf_count, i, i + max_length * direction) > min_prefix) max_length *= 2;
+	int length = 0;
+	for (int step = max_length / 2; step >= 1; step /= 2)
+		if (common_prefix(keys, leaf_count, i, i + (length + step) * direction) > min_prefix) length += step;
+	int j = i + length * direction;
+	int node_prefix = common_prefix(keys, leaf_count, i, j);
+	int split_offset = 0;
+	int step = length;
+	do {
+		step = (step + 1) >> 1;
+		if (common_prefix(keys, leaf_count, i, i + (split_offset + step) * direction) > node_prefix) split_offset += step;
+	} while (step > 1);
+	int split = i + split_offset * direction + min(direction, 0);
+	int first = min(i, j), last = max(i, j);
+	uint32_t left = (split == first) ? (kLeafBit | (uint32_t) split) : (uint32_t) split;
+	uint32_t right = (split + 1 == last) ? (kLeafBit | (uint32_t) (split + 1)) : (uint32_t) (split + 1);
+	nodes[i].links.x = left;
+	nodes[i].links.y = right;
+	if (i == 0) nodes[0].links.z = 0xFFFFFFFFu;
+	if (left & kLeafBit) leaf_parents[left & ~kLeafBit] = (uint32_t) i; else nodes[left].links.z = (uint32_t) i;
+	if (right & kLeafBit) leaf_parents[right & ~kLeafBit] = (uint32_t) i; else nodes[right].links.z = (uint32_t) i;
+}
+
+__device__ __forceinline__ void load_box(const float* lo, const float* hi, size_t index, f3& out_lo, f3& out_hi) {
+	// boxes written by other workgroups: bypass the (non-coherent) vector L1
+	out_lo = mk3(__builtin_nontemporal_load(lo + 3 * index), __builtin_nontemporal_load(lo + 3 * index + 1), __builtin_nontemporal_load(lo + 3 * index + 2));
+	out_hi = mk3(__builtin_nontemporal_load(hi + 3 * index), __builtin_nontemporal_load(hi + 3 * index + 1), __builtin_nontemporal_load(hi + 3 * index + 2));
+}
+
+// Bottom-up refit: each leaf climbs; the second thread to reach a node merges the
+// child boxes.  Cross-workgroup visibility: agent-scope release before the arrival
+// counter, agent-scope acquire after it (per-XCD L2s are not coherent).
+__global__ void __launch_bounds__(256) k_refit(int leaf_count, bvh_node* nodes, const uint32_t* leaf_parents, float* lo, float* hi, uint32_t* arrivals) {
+	int slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= leaf_count) return;
+	uint32_t node = leaf_parents[slot];
+	while (node != 0xFFFFFFFFu) {
+		__threadfence();
+		if (atomicAdd(&arrivals[node], 1u) == 0) return;
+		__threadfence();
+		uint32_t left = nodes[node].links.x, right = nodes[node].links.y;
+		size_t il = (left & kLeafBit) ? (size_t) (leaf_count - 1) + (left & ~kLeafBit) : (size_t) left;
+		size_t ir = (right & kLeafBit) ? (size_t) (leaf_count - 1) + (right & ~kLeafBit) : (size_t) right;
+		f3 lo0, hi0, lo1, hi1;
+		load_box(lo, hi, il, lo0, hi0);
+		load_box(lo, hi, ir, lo1, hi1);
+		nodes[node].a = make_float4(lo0.x, lo0.y, lo0.z, hi0.x);
+		nodes[node].b = make_float4(hi0.y, hi0.z, lo1.x, lo1.y);
+		nodes[node].c = make_float4(lo1.z, hi1.x, hi1.y, hi1.z);
+		lo[3 * (size_t) node + 0] = fminf(lo0.x, lo1.x);
+		lo[3 * (size_t) node + 1] = fminf(lo0.y, lo1.y);
+		lo[3 * (size_t) node + 2] = fminf(lo0.z, lo1.z);
+		hi[3 * (size_t) node + 0] = fmaxf(hi0.x, hi1.x);
+		hi[3 * (size_t) node + 1] = fmaxf(hi0.y, hi1.y);
+		hi[3 * (size_t) node + 2] = fmaxf(hi0.z, hi1.z);
+		node = nodes[node].links.z;
+	}
+}
+
+}  // namespace
+
+extern "C" void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, const device_t* device) {
+	(void) device;
+	if (structure->triangle_vertices) (void) hipFree(structure->triangle_vertices);
+	if (structure->nodes) (void) hipFree(structure->nodes);
+	memset(structure, 0, sizeof(*structure));
+}
+
+extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh) {
+	memset(structure, 0, sizeof(*structure));
+	if (mesh->triangle_count > 0x7FFFFFFFull) {
+		printf("The LBVH supports at most 2^31 triangles.\n");
+		return 1;
+	}
+	hipStream_t stream = (hipStream_t) device->stream;
+	uint32_t n = (uint32_t) mesh->triangle_count;
+	build_params p;
+	p.quantized_positions = (const uint2*) mesh->positions;
+	p.triangle_count = n;
+	float extent = 0.0f;
+	for (int j = 0; j != 3; ++j) {
+		p.factor[j] = mesh->dequantization_factor[j];
+		p.summand[j] = mesh->dequantization_summand[j];
+		extent = fmaxf(extent, 2097152.0f * fabsf(mesh->dequantization_factor[j]));
+	}
+	// conservative padding: the triangle test may accept hits a few ulps outside
+	// the exact bounds
+	p.pad = 1.0e-4f * extent;
+	uint32_t inner_count = n > 1 ? n - 1 : 1;
+	uint64_t *keys = NULL, *sorted_keys = NULL;
+	float *lo = NULL, *hi = NULL;
+	uint32_t *leaf_parents = NULL, *arrivals = NULL;
+	void* sort_storage = NULL;
+	size_t sort_bytes = 0;
+	int failed = 1;
+	do {
+		if (hipMalloc(&structure->triangle_vertices, sizeof(float4) * 3 * (size_t) n) != hipSuccess) break;
+		if (hipMalloc(&structure->nodes, sizeof(bvh_node) * (size_t) inner_count) != hipSuccess) break;
+		if (hipMalloc(&keys, sizeof(uint64_t) * n) != hipSuccess || hipMalloc(&sorted_keys, sizeof(uint64_t) * n) != hipSuccess) break;
+		if (hipMalloc(&lo, sizeof(float) * 3 * (2 * (size_t) n)) != hipSuccess || hipMalloc(&hi, sizeof(float) * 3 * (2 * (size_t) n)) != hipSuccess) break;
+		if (hipMalloc(&leaf_parents, sizeof(uint32_t) * n) != hipSuccess || hipMalloc(&arrivals, sizeof(uint32_t) * inner_count) != hipSuccess) break;
+		if (hipMemsetAsync(arrivals, 0, sizeof(uint32_t) * inner_count, stream) != hipSuccess) break;
+		if (hipMemsetAsync(structure->nodes, 0, sizeof(bvh_node) * (size_t) inner_count, stream) != hipSuccess) break;
+		uint32_t blocks = (n + 255) / 256;
+		k_morton_keys<<<blocks, 256, 0, stream>>>(p, keys);
+		if (hipcub::DeviceRadixSort::SortKeys(NULL, sort_bytes, keys, sorted_keys, (int) n, 0, 62, stream) != hipSuccess) break;
+		if (hipMalloc(&sort_storage, sort_bytes ? sort_bytes : 1) != hipSuccess) break;
+		if (hipcub::DeviceRadixSort::SortKeys(sort_storage, sort_bytes, keys, sorted_keys, (int) n, 0, 62, stream) != hipSuccess) break;
+		k_write_leaves<<<blocks, 256, 0, stream>>>(p, sorted_keys, (float4*) structure->triangle_vertices, lo, hi);
+		if (n > 1) {
+			k_build_hierarchy<<<(n - 1 + 255) / 256, 256, 0, stream>>>(sorted_keys, (int) n, (bvh_node*) structure->nodes, leaf_parents);
+			k_refit<<<blocks, 256, 0, stream>>>((int) n, (bvh_node*) structure->nodes, leaf_parents, lo, hi, arrivals);
+			structure->root = 0;
+		}
+		else
+			structure->root = kLeafBit;
+		if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) break;
+		structure->node_count = inner_count;
+		structure->triangle_indices = NULL;
+		failed = 0;
+	} while (0);
+	(void) hipFree(keys); (void) hipFree(sorted_keys); (void) hipFree(lo); (void) hipFree(hi);
+	(void) hipFree(leaf_parents); (void) hipFree(arrivals); (void) hipFree(sort_storage);
+	if (failed) {
+		printf("Building the LBVH over %u triangles failed: %s\n", n, hipGetErrorString(hipGetLastError()));
+		vkr_destroy_acceleration_structure(structure, device);
+	}
+	return failed;
+}

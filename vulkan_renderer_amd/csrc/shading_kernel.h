@@ -1,0 +1,738 @@
+// The per-pixel shading program as a HIP kernel for gfx950 (CDNA4).
+//
+// One lane per pixel; a wave64 covers an 8x8 pixel patch and a 256-thread
+// workgroup a 16x16 block, so neighbouring lanes read neighbouring triangles,
+// LTC texels and noise texels and mostly agree on the clipping / sector branches.
+// All uniform inputs (frame constants, light records) are read through
+// wave-uniform addresses and end up in SGPRs.
+//
+// Follows reference src/shaders/shading_pass.frag.glsl (main :824-866,
+// evaluate_polygonal_light_shading :329-711, get_shading_data :721-822) with the
+// variant axes of src/main.c:752-792 as template parameters:
+//   STRATEGY  sampling_strategies_t          (SAMPLING_STRATEGIES_*)
+//   TECHNIQUE 0 projected solid angle, 1 its biased variant, 2 solid angle,
+//             3 clipped solid angle          (SAMPLE_POLYGON_*)
+//   V         MAX_POLYGON_VERTEX_COUNT
+//   RAYS      TRACE_SHADOW_RAYS
+// Light count, sample count and the MIS heuristic are wave-uniform run-time values.
+#pragma once
+#include "polygon_sampling.h"
+#include "lbvh.h"
+
+namespace vkr {
+
+enum { kStrategyDiffuseOnly = 0, kStrategyDiffuseGgxMis = 1, kStrategySeparately = 2, kStrategyMis = 3, kStrategyRandom = 4 };
+enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3 };
+enum { kMisBalance = 0, kMisPower = 1, kMisWeighted = 2, kMisOptimalClamped = 3, kMisOptimal = 4 };
+
+struct shade_params {
+	// per_frame_constants_t + packed lights, byte image of write_constants()
+	const uint8_t* constants;
+	uint32_t light_count, max_light_vertex_count, sample_count;
+	int32_t mis_heuristic;
+	int32_t show_polygonal_lights;
+	// mesh (layouts: include/vkr_scene.h)
+	const uint2* positions;
+	const uint2* normals_and_tex_coords;
+	const uint8_t* material_indices;
+	const float* material_constants;
+	// G-buffer in, radiance out
+	const uint32_t* visibility;
+	float4* out_radiance;
+	uint32_t width, height;
+	// tables
+	const uint2* ltc_rgba;
+	const uint32_t* ltc_rg;
+	uint32_t ltc_resolution, ltc_layer_count;
+	const uint2* noise;
+	uint32_t noise_width, noise_height;
+	bvh_view bvh;
+	// tile schedule (include/vkr_shading_pass.h tile_schedule_t)
+	uint32_t tile_size, rank, rank_count, tiles_x, tile_count;
+	unsigned long long* ray_counter;
+};
+
+VKR_DEV float load_f(const uint8_t* base, uint32_t offset) { return *(const float*) (base + offset); }
+VKR_DEV uint32_t load_u(const uint8_t* base, uint32_t offset) { return *(const uint32_t*) (base + offset); }
+VKR_DEV f3 load_f3(const uint8_t* base, uint32_t offset) { return mk3(load_f(base, offset), load_f(base, offset + 4), load_f(base, offset + 8)); }
+
+VKR_DEV float unorm16(uint32_t v) {
+#if VKR_FAST_MATH
+	return (float) v * (1.0f / 65535.0f);
+#else
+	return (float) v / 65535.0f;
+#endif
+}
+
+// ---- noise (noise_utility.glsl:63-103) ---------------------------------------------
+
+struct noise_accessor {
+	float n0, n1, n2, n3;
+	uint32_t available, px, py, sample_index;
+};
+
+VKR_DEV f2 next_noise_2(const shade_params& p, noise_accessor& a) {
+	if (a.available <= 1) {
+		const uint8_t* c = p.constants;
+		uint32_t s = a.sample_index;
+		uint32_t r0 = load_u(c, 208), r1 = load_u(c, 212), r2 = load_u(c, 216), r3 = load_u(c, 220);
+		if (s & 2) { uint32_t t0 = r0, t1 = r1; r0 = r2; r1 = r3; r2 = t0; r3 = t1; }
+		if (s & 1) { r0 = r1; r1 = r2; r2 = r3; }
+		uint32_t shift = (s & 124) >> 2;
+		uint32_t layer = (r2 + s) & load_u(c, 192);
+		uint32_t sx = (a.px + (r0 >> shift)) & load_u(c, 184);
+		uint32_t sy = (a.py + (r1 >> shift)) & load_u(c, 188);
+		uint2 texel = p.noise[((size_t) layer * p.noise_height + sy) * p.noise_width + sx];
+		a.n0 = unorm16(texel.x & 0xFFFF); a.n1 = unorm16(texel.x >> 16);
+		a.n2 = unorm16(texel.y & 0xFFFF); a.n3 = unorm16(texel.y >> 16);
+		a.available = 4;
+		++a.sample_index;
+	}
+	a.available -= 2;
+	f2 r = mk2(a.n0, a.n1);
+	a.n0 = a.n2; a.n1 = a.n3;
+	return r;
+}
+
+// ---- G-buffer reconstruction (shading_pass.frag.glsl:721-822) ------------------------
+
+struct shading_data {
+	f3 position, normal, outgoing;
+	float lambert_outgoing;
+	f3 diffuse_albedo, fresnel_0;
+	float roughness;
+};
+
+VKR_DEV f3 decode_position(uint2 q, f3 factor, f3 summand) {
+	float px = (float) (q.x & 0x1FFFFF);
+	float py = (float) (((q.x & 0xFFE00000u) >> 21) | ((q.y & 0x3FF) << 11));
+	float pz = (float) ((q.y & 0x7FFFFC00u) >> 10);
+	return mk3(fmaf(px, factor.x, summand.x), fmaf(py, factor.y, summand.y), fmaf(pz, factor.z, summand.z));
+}
+
+VKR_DEV f3 decode_normal(float ox, float oy) {
+	const float factor = 2.0f * (65534.0f / 65535.0f);
+	const float summand = -(32768.0f / 65535.0f) * factor;
+	ox = fmaf(ox, factor, summand);
+	oy = fmaf(oy, factor, summand);
+	f3 n = mk3(ox, oy, 1.0f - fabsf(ox) - fabsf(oy));
+	float sx = (ox >= 0.0f) ? 1.0f : -1.0f;
+	float sy = (oy >= 0.0f) ? 1.0f : -1.0f;
+	if (n.z < 0.0f) {
+		float nx = (1.0f - fabsf(n.y)) * sx;
+		float ny = (1.0f - fabsf(n.x)) * sy;
+		n.x = nx; n.y = ny;
+	}
+	return normalize(n);
+}
+
+VKR_DEV shading_data get_shading_data(const shade_params& p, uint32_t primitive, f3 ray_direction) {
+	const uint8_t* c = p.constants;
+	f3 factor = load_f3(c, 0), summand = load_f3(c, 16), camera = load_f3(c, 144);
+	shading_data r;
+	f3 pos[3], nrm[3];
+	f2 uv[3];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		size_t vi = (size_t) primitive * 3 + i;
+		pos[i] = decode_position(p.positions[vi], factor, summand);
+		uint2 q = p.normals_and_tex_coords[vi];
+		nrm[i] = decode_normal(unorm16(q.x & 0xFFFF), unorm16(q.x >> 16));
+		uv[i] = mk2(fmaf(unorm16(q.y & 0xFFFF), 8.0f, 0.0f), fmaf(unorm16(q.y >> 16), -8.0f, 1.0f));
+	}
+	f3 e0 = pos[1] - pos[0], e1 = pos[2] - pos[0];
+	f3 ray_cross_e1 = cross(ray_direction, e1);
+	float rcp_det = rcp(dot(e0, ray_cross_e1));
+	f3 to0 = camera - pos[0];
+	float b1 = rcp_det * dot(to0, ray_cross_e1);
+	f3 e0_cross_to0 = cross(e0, to0);
+	float b2 = -rcp_det * dot(ray_direction, e0_cross_to0);
+	float b0 = 1.0f - (b1 + b2);
+	// screen-space derivatives (:754-777) only feed textureGrad; with constant
+	// material texels they are dead code
+	r.position = fma3(b0, pos[0], fma3(b1, pos[1], pos[2] * b2));
+	f3 interpolated_normal = normalize(fma3(b0, nrm[0], fma3(b1, nrm[1], nrm[2] * b2)));
+	const float* mc = p.material_constants + 8 * (size_t) p.material_indices[primitive];
+	f3 base_color = mk3(mc[0], mc[1], mc[2]);
+	float linear_roughness = mc[4], metalicity = mc[5];
+	f3 nt;
+	nt.x = fmaf(mc[6], 2.0f, -1.0f);
+	nt.y = fmaf(mc[7], 2.0f, -1.0f);
+	nt.z = square_root(gmax(0.0f, fmaf(-nt.x, nt.x, fmaf(-nt.y, nt.y, 1.0f))));
+	r.diffuse_albedo = mk3(fmaf(base_color.x, -metalicity, base_color.x), fmaf(base_color.y, -metalicity, base_color.y), fmaf(base_color.z, -metalicity, base_color.z));
+	float dielectric = 0.02f * (1.0f - metalicity);
+	r.fresnel_0 = mk3(dielectric + base_color.x * metalicity, dielectric + base_color.y * metalicity, dielectric + base_color.z * metalicity);
+	r.roughness = linear_roughness * linear_roughness;
+	r.roughness = gclamp(r.roughness * load_f(c, 180), 0.0064f, 1.0f);
+	f2 uv_e0 = uv[1] - uv[0], uv_e1 = uv[2] - uv[0];
+	f3 n_cross_e0 = cross(interpolated_normal, e0);
+	f3 e1_cross_n = cross(e1, interpolated_normal);
+	f3 tangent = e1_cross_n * uv_e0.x + n_cross_e0 * uv_e1.x;
+	f3 bitangent = e1_cross_n * uv_e0.y + n_cross_e0 * uv_e1.y;
+	float mean_tangent_length = square_root(0.5f * (dot(tangent, tangent) + dot(bitangent, bitangent)));
+	m3 t2w;
+	t2w.c[0] = tangent; t2w.c[1] = bitangent; t2w.c[2] = interpolated_normal;
+	nt.z *= gmax(1.0e-10f, mean_tangent_length);
+	r.normal = normalize(mul(t2w, nt));
+	r.outgoing = normalize(camera - r.position);
+	float normal_offset = gmax(0.0f, 1.0e-3f - dot(r.normal, r.outgoing));
+	r.normal = fma3(normal_offset, r.outgoing, r.normal);
+	r.normal = normalize(r.normal);
+	r.lambert_outgoing = dot(r.normal, r.outgoing);
+	return r;
+}
+
+// ---- LTC (ltc_utility.glsl:58-108) ---------------------------------------------------
+
+struct ltc_coefficients {
+	m43 world_to_shading;
+	m43 world_to_cosine;
+	// shading_to_cosine = [[m00, 0, m02], [0, m11, 0], [m20, 0, m22]] (row, column)
+	float m00, m02, m11, m20, m22;
+	// cosine_to_shading, same sparsity
+	float i00, i02, i11, i20, i22;
+	float albedo, determinant;
+};
+
+VKR_DEV f3 shading_to_cosine(const ltc_coefficients& l, f3 v) {
+	// column-major product with the structural zeros kept (they matter for -0)
+	return mk3((l.m00 * v.x + 0.0f * v.y) + l.m02 * v.z, (0.0f * v.x + l.m11 * v.y) + 0.0f * v.z, (l.m20 * v.x + 0.0f * v.y) + l.m22 * v.z);
+}
+VKR_DEV f3 cosine_to_shading(const ltc_coefficients& l, f3 v) {
+	return mk3((l.i00 * v.x + 0.0f * v.y) + l.i02 * v.z, (0.0f * v.x + l.i11 * v.y) + 0.0f * v.z, (l.i20 * v.x + 0.0f * v.y) + l.i22 * v.z);
+}
+
+VKR_DEV float bilinear(float t00, float t10, float t01, float t11, float wx, float wy) {
+	float top = t00 * (1.0f - wx) + t10 * wx;
+	float bottom = t01 * (1.0f - wx) + t11 * wx;
+	return top * (1.0f - wy) + bottom * wy;
+}
+
+VKR_DEV ltc_coefficients get_ltc_coefficients(const shade_params& p, float fresnel_0, float roughness, f3 position, f3 normal, f3 outgoing) {
+	const uint8_t* c = p.constants;
+	ltc_coefficients l;
+	float n_dot_o = dot(normal, outgoing);
+	float inclination = arccos_unit(gclamp(n_dot_o, 0.0f, 1.0f));
+	float u = fmaf(square_root(gclamp(roughness, 0.0f, 1.0f)), load_f(c, 232), load_f(c, 236));
+	float v = fmaf(inclination, load_f(c, 240), load_f(c, 244));
+	float w = fmaf(gclamp(fresnel_0, 0.0f, 1.0f), load_f(c, 224), load_f(c, 228));
+	// bilinear, clamp to edge, nearest layer; exact fp32 weights, x first
+	int res = (int) p.ltc_resolution;
+	float fx = u * (float) res - 0.5f, fy = v * (float) res - 0.5f;
+	float flx = floorf(fx), fly = floorf(fy);
+	float wx = fx - flx, wy = fy - fly;
+	int x0 = (int) flx, y0 = (int) fly;
+	int x1 = min(max(x0 + 1, 0), res - 1), y1 = min(max(y0 + 1, 0), res - 1);
+	x0 = min(max(x0, 0), res - 1);
+	y0 = min(max(y0, 0), res - 1);
+	int layer = min(max((int) rintf(w), 0), (int) p.ltc_layer_count - 1);
+	size_t base = (size_t) layer * res * res;
+	size_t i00 = base + (size_t) y0 * res + x0, i10 = base + (size_t) y0 * res + x1;
+	size_t i01 = base + (size_t) y1 * res + x0, i11 = base + (size_t) y1 * res + x1;
+	uint2 a00 = p.ltc_rgba[i00], a10 = p.ltc_rgba[i10], a01 = p.ltc_rgba[i01], a11 = p.ltc_rgba[i11];
+	uint32_t b00 = p.ltc_rg[i00], b10 = p.ltc_rg[i10], b01 = p.ltc_rg[i01], b11 = p.ltc_rg[i11];
+	float d0 = bilinear(unorm16(a00.x & 0xFFFF), unorm16(a10.x & 0xFFFF), unorm16(a01.x & 0xFFFF), unorm16(a11.x & 0xFFFF), wx, wy);
+	float d1 = bilinear(unorm16(a00.x >> 16), unorm16(a10.x >> 16), unorm16(a01.x >> 16), unorm16(a11.x >> 16), wx, wy);
+	float d2 = bilinear(unorm16(a00.y & 0xFFFF), unorm16(a10.y & 0xFFFF), unorm16(a01.y & 0xFFFF), unorm16(a11.y & 0xFFFF), wx, wy);
+	float d3 = bilinear(unorm16(a00.y >> 16), unorm16(a10.y >> 16), unorm16(a01.y >> 16), unorm16(a11.y >> 16), wx, wy);
+	float d4 = bilinear(unorm16(b00 & 0xFFFF), unorm16(b10 & 0xFFFF), unorm16(b01 & 0xFFFF), unorm16(b11 & 0xFFFF), wx, wy);
+	float d5 = bilinear(unorm16(b00 >> 16), unorm16(b10 >> 16), unorm16(b01 >> 16), unorm16(b11 >> 16), wx, wy);
+	// mat3(d0, 0, -d1,  0, d2, 0,  d3, 0, d4) column by column
+	l.m00 = d0; l.m20 = -d1; l.m11 = d2; l.m02 = d3; l.m22 = d4;
+	l.albedo = d5;
+	float det2 = d0 * d4 + d1 * d3;
+	l.determinant = d2 * det2;
+	float inv_det2 = rcp(det2);
+	l.i00 = d4 * inv_det2; l.i20 = d1 * inv_det2; l.i11 = rcp(d2); l.i02 = -d3 * inv_det2; l.i22 = d0 * inv_det2;
+	f3 x_axis = normalize(fma3(-n_dot_o, normal, outgoing));
+	f3 y_axis = cross(normal, x_axis);
+	f3 r0 = mk3(x_axis.x, y_axis.x, normal.x);
+	f3 r1 = mk3(x_axis.y, y_axis.y, normal.y);
+	f3 r2 = mk3(x_axis.z, y_axis.z, normal.z);
+	l.world_to_shading.c[0] = r0;
+	l.world_to_shading.c[1] = r1;
+	l.world_to_shading.c[2] = r2;
+	m3 neg;
+	neg.c[0] = -r0; neg.c[1] = -r1; neg.c[2] = -r2;
+	l.world_to_shading.c[3] = mul(neg, position);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) l.world_to_cosine.c[i] = shading_to_cosine(l, l.world_to_shading.c[i]);
+	return l;
+}
+
+VKR_DEV float evaluate_ltc_density(const ltc_coefficients& l, f3 dir_shading, float rcp_psa) {
+	f3 dc = shading_to_cosine(l, dir_shading);
+	float len_sq = dot(dc, dc);
+	float density = divide(gmax(0.0f, dc.z) * l.determinant, len_sq * len_sq);
+	return density * rcp_psa;
+}
+
+// ---- BRDF (brdfs.glsl) -------------------------------------------------------------
+
+VKR_DEV float schlick(float f0, float f90, float cos_theta) {
+	float flipped = 1.0f - cos_theta;
+	float flipped_squared = flipped * flipped;
+	return f0 + (f90 - f0) * (flipped_squared * flipped * flipped_squared);
+}
+
+template <bool DIFFUSE, bool SPECULAR>
+VKR_DEV f3 evaluate_brdf(const shading_data& d, f3 incoming) {
+	f3 half_vector = normalize(incoming + d.outgoing);
+	float lambert_incoming = dot(d.normal, incoming);
+	float outgoing_dot_half = dot(d.outgoing, half_vector);
+	f3 brdf = mk3(0.0f, 0.0f, 0.0f);
+	if (DIFFUSE) {
+		float f90 = fmaf(outgoing_dot_half * outgoing_dot_half, 2.0f * d.roughness, 0.5f);
+		float product = schlick(1.0f, f90, d.lambert_outgoing) * schlick(1.0f, f90, lambert_incoming);
+		brdf = brdf + d.diffuse_albedo * product;
+	}
+	if (SPECULAR) {
+		float normal_dot_half = dot(d.normal, half_vector);
+		float a2 = d.roughness * d.roughness;
+		float ggx = fmaf(fmaf(normal_dot_half, a2, -normal_dot_half), normal_dot_half, 1.0f);
+		ggx = divide(a2, ggx * ggx);
+		float masking = lambert_incoming * square_root(fmaf(fmaf(-d.lambert_outgoing, a2, d.lambert_outgoing), d.lambert_outgoing, a2));
+		float shadowing = d.lambert_outgoing * square_root(fmaf(fmaf(-lambert_incoming, a2, lambert_incoming), lambert_incoming, a2));
+		float smith = divide(0.5f, masking + shadowing);
+		float ct = gclamp(outgoing_dot_half, 0.0f, 1.0f);
+		float gs = ggx * smith;
+		brdf = brdf + mk3(gs * schlick(d.fresnel_0.x, 1.0f, ct), gs * schlick(d.fresnel_0.y, 1.0f, ct), gs * schlick(d.fresnel_0.z, 1.0f, ct));
+	}
+	return brdf * kInvPi;
+}
+
+VKR_DEV float ggx_vndf_density(float out_dot_n, float micro_dot_n, float micro_dot_out, float roughness) {
+	float a2 = roughness * roughness;
+	float ggx = fmaf(fmaf(micro_dot_n, a2, -micro_dot_n), micro_dot_n, 1.0f);
+	ggx = divide(a2, ggx * ggx);
+	ggx *= kInvPi;
+	float masking = square_root(fmaf(fmaf(-out_dot_n, a2, out_dot_n), out_dot_n, a2));
+	masking = divide(2.0f, out_dot_n + masking);
+	return masking * micro_dot_out * ggx;
+}
+
+VKR_DEV f3 sample_ggx_vndf(f3 out_shading, float rx, float ry, f2 u) {
+	m3 e2h;
+	e2h.c[2] = normalize(mk3(rx * out_shading.x, ry * out_shading.y, 1.0f * out_shading.z));
+	float length_sq = e2h.c[2].x * e2h.c[2].x + e2h.c[2].y * e2h.c[2].y;
+	float inv_len = rsqrt(length_sq);
+	e2h.c[0] = mk3(-e2h.c[2].y * inv_len, e2h.c[2].x * inv_len, 0.0f * inv_len);
+	if (length_sq <= 0.0f) e2h.c[0] = mk3(1.0f, 0.0f, 0.0f);
+	e2h.c[1] = cross(e2h.c[2], e2h.c[0]);
+	float radius = square_root(u.x);
+	float azimuth = (2.0f * kPi) * u.y;
+	float sn, cs;
+	sincos_poly(azimuth, sn, cs);
+	f2 disk = mk2(radius * cs, radius * sn);
+	f3 s;
+	s.x = disk.x;
+	float lerp = fmaf(0.5f, e2h.c[2].z, 0.5f);
+	float a = square_root(fmaf(-disk.x, disk.x, 1.0f));
+	s.y = a * (1.0f - lerp) + disk.y * lerp;
+	s.z = square_root(gmax(0.0f, 1.0f - (s.x * s.x + s.y * s.y)));
+	f3 hemi = mul(e2h, s);
+	return normalize(mk3(rx * hemi.x, ry * hemi.y, 1.0f * hemi.z));
+}
+
+VKR_DEV f3 sample_ggx_reflected(float& out_density, f3 out_shading, float roughness, f2 u) {
+	f3 micro = sample_ggx_vndf(out_shading, roughness, roughness, u);
+	float micro_dot_out = dot(micro, out_shading);
+	float density = ggx_vndf_density(out_shading.z, micro.z, micro_dot_out, roughness);
+	f3 incoming = fma3(2.0f * micro_dot_out, micro, -out_shading);
+	out_density = divide(density, 4.0f * micro_dot_out);
+	return incoming;
+}
+
+VKR_DEV float ggx_reflected_density(float out_dot_n, f3 out_dir, f3 in_dir, f3 normal, float roughness) {
+	f3 micro = normalize(out_dir + in_dir);
+	float micro_dot_out = dot(micro, out_dir);
+	float micro_dot_n = dot(micro, normal);
+	float density = ggx_vndf_density(out_dot_n, micro_dot_n, micro_dot_out, roughness);
+	return divide(density, 4.0f * micro_dot_out);
+}
+
+// ---- lights ----------------------------------------------------------------------
+
+// Wave-uniform view of one packed light record (include/vkr_polygonal_light.h)
+struct light_ref {
+	const uint8_t* base;   // start of the 160-byte fixed part
+	const uint8_t* world;  // world-space vertices, 16 bytes each
+};
+
+VKR_DEV light_ref get_light(const shade_params& p, uint32_t index) {
+	uint32_t vmax = p.max_light_vertex_count;
+	uint32_t stride = 160 + 16 * vmax * 2 + 16 * (vmax - 2);
+	light_ref l;
+	l.base = p.constants + 256 + stride * index;
+	l.world = l.base + 160 + 16 * vmax;
+	return l;
+}
+VKR_DEV f3 light_vertex(const light_ref& l, uint32_t i) { return load_f3(l.world, 16 * i); }
+VKR_DEV uint32_t light_vertex_count(const light_ref& l) { return load_u(l.base, 80); }
+VKR_DEV f3 light_radiance(const light_ref& l) { return load_f3(l.base, 48); }
+VKR_DEV float plane_distance(const light_ref& l, f3 p) {
+	return ((p.x * load_f(l.base, 64) + p.y * load_f(l.base, 68)) + p.z * load_f(l.base, 72)) + 1.0f * load_f(l.base, 76);
+}
+VKR_DEV f3 plane_normal(const light_ref& l) { return load_f3(l.base, 64); }
+
+// polygonal_light_ray_intersection, polygonal_light_utility.glsl:93-112
+VKR_DEV bool light_ray_intersection(const light_ref& light, uint32_t vmax, f3 origin, f3 end_xyz, float end_w) {
+	float side_a = plane_distance(light, origin);
+	f3 n = plane_normal(light);
+	float side_b = ((n.x * end_xyz.x + n.y * end_xyz.y) + n.z * end_xyz.z) + load_f(light.base, 76) * end_w;
+	if (side_a * side_b > 0.0f) return false;
+	f3 dir = end_xyz - origin * end_w;
+	float previous_sign = 0.0f;
+	bool result = true;
+	uint32_t count = light_vertex_count(light);
+	for (uint32_t i = 0; i != vmax; ++i) {
+		f3 a = light_vertex(light, i) - origin;
+		f3 b = light_vertex(light, (i + 1) % vmax) - origin;
+		float sign = dir.x * (a.y * b.z - b.y * a.z) - a.x * (dir.y * b.z - b.y * dir.z) + b.x * (dir.y * a.z - a.y * dir.z);
+		result = result && ((i >= 3 && i >= count) || previous_sign * sign >= 0.0f);
+		previous_sign = sign;
+	}
+	return result;
+}
+
+struct pixel_context {
+	const shade_params& p;
+	uint32_t rays;
+};
+
+// get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231
+template <bool RAYS, bool DIFFUSE, bool SPECULAR>
+VKR_DEV f3 radiance_visibility_brdf(pixel_context& ctx, float& out_lambert, bool& out_visibility, f3 dir, const shading_data& sd, const light_ref& light) {
+	float lambert = dot(sd.normal, dir);
+	bool visibility = lambert > 0.0f;
+	if (RAYS && visibility) {
+		float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
+		++ctx.rays;
+		visibility = !any_hit(ctx.p.bvh, sd.position, dir, 1.0e-3f, max_t);
+	}
+	out_lambert = lambert;
+	out_visibility = visibility;
+	if (visibility) return light_radiance(light) * evaluate_brdf<DIFFUSE, SPECULAR>(sd, dir);
+	return mk3(0.0f, 0.0f, 0.0f);
+}
+
+VKR_DEV float mis_weight_over_density(int heuristic, float sampled, float other) {
+	if (heuristic == kMisBalance) return rcp(sampled + other);
+	if (heuristic == kMisPower) return divide(sampled, sampled * sampled + other * other);
+	return 0.0f;
+}
+
+VKR_DEV float mis_estimate_channel(int heuristic, float in, float s, float sd, float o, float od, float ve) {
+	if (heuristic == kMisWeighted) {
+		float weighted_sum = s * sd + o * od;
+		return divide(s * in, weighted_sum);
+	}
+	if (heuristic == kMisOptimalClamped || heuristic == kMisOptimal) {
+		float balance = rcp(sd + od);
+		float weighted_sum = s * sd + o * od;
+		if (heuristic == kMisOptimalClamped) {
+			float weighted = divide(s, weighted_sum);
+			float mixed = fmaf(-ve, balance, balance);
+			mixed = fmaf(ve, weighted, mixed);
+			return mixed * in;
+		}
+		return ve * s + balance * (in - ve * weighted_sum);
+	}
+	return mis_weight_over_density(heuristic, sd, od) * in;
+}
+
+VKR_DEV f3 mis_estimate(int heuristic, f3 integrand, f3 sw, float sd, f3 ow, float od, float ve) {
+	return mk3(mis_estimate_channel(heuristic, integrand.x, sw.x, sd, ow.x, od, ve),
+		mis_estimate_channel(heuristic, integrand.y, sw.y, sd, ow.y, od, ve),
+		mis_estimate_channel(heuristic, integrand.z, sw.z, sd, ow.z, od, ve));
+}
+
+// get_polygonal_light_mis_estimate, shading_pass.frag.glsl:305-323
+template <int STRATEGY, bool RAYS>
+VKR_DEV f3 light_mis_estimate(pixel_context& ctx, f3 dir, float density, const shading_data& sd, const light_ref& light) {
+	float lambert;
+	bool visibility;
+	f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, dir, sd, light);
+	if (STRATEGY == kStrategyDiffuseOnly)
+		return (density > 0.0f) ? rb * divide(lambert, density) : mk3(0.0f, 0.0f, 0.0f);
+	if (STRATEGY == kStrategyDiffuseGgxMis) {
+		float ggx_density = ggx_reflected_density(sd.lambert_outgoing, sd.outgoing, dir, sd.normal, sd.roughness);
+		return (rb * lambert) * mis_weight_over_density(ctx.p.mis_heuristic, density, ggx_density);
+	}
+	return mk3(0.0f, 0.0f, 0.0f);
+}
+
+// evaluate_polygonal_light_shading, shading_pass.frag.glsl:329-711
+template <int STRATEGY, int TECHNIQUE, int V, bool RAYS>
+VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_coefficients& ltc_in, const light_ref& light, noise_accessor& noise) {
+	const shade_params& p = ctx.p;
+	constexpr bool kBiased = TECHNIQUE == kTechniquePsaBiased;
+	constexpr bool kIsPsa = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased;
+	const uint32_t S = p.sample_count;
+	const uint32_t count = light_vertex_count(light);
+	const f3 zero = mk3(0.0f, 0.0f, 0.0f);
+	f3 result = zero;
+	float density_factor = 0.0f;
+	m43 world_to_shading = ltc_in.world_to_shading;
+
+	if constexpr (TECHNIQUE == kTechniqueSolidAngle) {
+		f3 vw[V];
+#pragma unroll
+		for (int i = 0; i < V; ++i) vw[i] = light_vertex(light, min((uint32_t) i, p.max_light_vertex_count - 1));
+		sa_polygon<V> pd;
+		prepare_sa<V>(pd, count, vw, sd.position);
+		density_factor = rcp(pd.solid_angle);
+		for (uint32_t s = 0; s != S; ++s) {
+			f3 dir = sample_sa<V>(pd, next_noise_2(p, noise));
+			result = result + light_mis_estimate<STRATEGY, RAYS>(ctx, dir, density_factor, sd, light);
+		}
+	}
+	else if constexpr (TECHNIQUE == kTechniqueClippedSolidAngle) {
+		f3 vs[V];
+#pragma unroll
+		for (int i = 0; i < V - 1; ++i) vs[i] = mul_point(world_to_shading, light_vertex(light, min((uint32_t) i, p.max_light_vertex_count - 1)));
+		vs[V - 1] = zero;
+		uint32_t clipped = clip_polygon<V>(count, vs);
+		if (clipped == 0) return zero;
+		sa_polygon<V> pd;
+		prepare_sa<V>(pd, clipped, vs, zero);
+		density_factor = rcp(pd.solid_angle);
+		for (uint32_t s = 0; s != S; ++s) {
+			f3 dir = sample_sa<V>(pd, next_noise_2(p, noise));
+			dir = mul_transposed(world_to_shading, dir);
+			result = result + light_mis_estimate<STRATEGY, RAYS>(ctx, dir, density_factor, sd, light);
+		}
+	}
+	else {
+		// projected solid angle sampling; flip the frame if the shading point is
+		// behind the light so that the winding stays clockwise (:444-449)
+		m43 world_to_cosine = ltc_in.world_to_cosine;
+		float side = plane_distance(light, sd.position);
+		if (side < 0.0f) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				world_to_shading.c[i].y = -world_to_shading.c[i].y;
+				world_to_cosine.c[i].y = -world_to_cosine.c[i].y;
+			}
+		}
+		if constexpr (STRATEGY == kStrategyDiffuseOnly || STRATEGY == kStrategyDiffuseGgxMis) {
+			f3 vs[V];
+#pragma unroll
+			for (int i = 0; i < V - 1; ++i) vs[i] = mul_point(world_to_shading, light_vertex(light, min((uint32_t) i, p.max_light_vertex_count - 1)));
+			vs[V - 1] = zero;
+			uint32_t clipped = clip_polygon<V>(count, vs);
+			if (clipped == 0) return zero;
+			psa_polygon<V> pd;
+			prepare_psa<V, kBiased>(pd, clipped, vs);
+			if (pd.total <= 0.0f) return zero;
+			for (uint32_t s = 0; s != S; ++s) {
+				f3 dir = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
+				float density = divide(dir.z, pd.total);
+				dir = mul_transposed(world_to_shading, dir);
+				result = result + light_mis_estimate<STRATEGY, RAYS>(ctx, dir, density, sd, light);
+			}
+			density_factor = rcp(pd.total);
+		}
+		else {
+			// both techniques are prepared by the same code path (:506-547)
+			psa_polygon<V> pd, ps;
+			ps.total = 0.0f;
+			ps.vertex_count = 0;
+			ps.inner_ellipse_0 = mk2(0.0f, 0.0f);
+			bool specular_culled = false;
+			for (int t = 0; t != 2; ++t) {
+				const m43& to_local = (t == 0) ? world_to_shading : world_to_cosine;
+				if (t > 0) pd = ps;
+				f3 vl[V];
+#pragma unroll
+				for (int j = 0; j < V - 1; ++j) vl[j] = mul_point(to_local, light_vertex(light, min((uint32_t) j, p.max_light_vertex_count - 1)));
+				vl[V - 1] = zero;
+				uint32_t clipped = clip_polygon<V>(count, vl);
+				if (clipped == 0 && t == 0) return zero;
+				else if (clipped == 0) { specular_culled = true; break; }
+				prepare_psa<V, kBiased>(ps, clipped, vl);
+			}
+			if (specular_culled) ps.total = 0.0f;
+			if (pd.total == 0.0f) return zero;
+			float specular_albedo = ltc_in.albedo;
+			float specular_weight = specular_albedo * ps.total;
+			if constexpr (STRATEGY == kStrategySeparately) {
+				for (uint32_t s = 0; s != S; ++s) {
+					f3 dd = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
+					dd = mul_transposed(world_to_shading, dd);
+					float lambert;
+					bool visibility;
+					f3 rb = radiance_visibility_brdf<RAYS, true, false>(ctx, lambert, visibility, dd, sd, light);
+					result = result + rb * pd.total;
+					if (ps.total > 0.0f) {
+						f3 dc = sample_psa<V, kBiased>(ps, next_noise_2(p, noise));
+						f3 ds = normalize(cosine_to_shading(ltc_in, dc));
+						float ltc_density = evaluate_ltc_density(ltc_in, ds, 1.0f);
+						f3 rb2 = radiance_visibility_brdf<RAYS, false, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
+						if (!(ds.z <= 0.0f || dc.z <= 0.0f))
+							result = result + rb2 * divide(ds.z * ps.total, ltc_density);
+					}
+				}
+			}
+			else if constexpr (STRATEGY == kStrategyMis) {
+				const int heuristic = p.mis_heuristic;
+				const float visibility_estimate = load_f(p.constants, 156);
+				f3 albedo = mk3(gmax(sd.diffuse_albedo.x, 0.01f), gmax(sd.diffuse_albedo.y, 0.01f), gmax(sd.diffuse_albedo.z, 0.01f));
+				f3 diffuse_weight = albedo * pd.total;
+				uint32_t technique_count = (ps.total > 0.0f) ? 2 : 1;
+				float rcp_d = rcp(pd.total);
+				float rcp_s = rcp(ps.total);
+				f3 specular_weight_rgb = mk3(specular_weight, specular_weight, specular_weight);
+				if (heuristic == kMisOptimal) {
+					f3 radiance_over_pi = light_radiance(light) * kInvPi;
+					diffuse_weight = diffuse_weight * radiance_over_pi;
+					specular_weight_rgb = specular_weight_rgb * radiance_over_pi;
+				}
+				for (uint32_t s = 0; s != S; ++s) {
+					f3 dir_d = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
+					f3 dir_s = zero;
+					if (ps.total > 0.0f) {
+						dir_s = sample_psa<V, kBiased>(ps, next_noise_2(p, noise));
+						dir_s = normalize(cosine_to_shading(ltc_in, dir_s));
+					}
+					for (uint32_t j = 0; j != technique_count; ++j) {
+						f3 ds = (j == 0) ? dir_d : dir_s;
+						if (ds.z <= 0.0f) continue;
+						float dens_d = ds.z * rcp_d;
+						float dens_s = evaluate_ltc_density(ltc_in, ds, rcp_s);
+						float lambert;
+						bool visibility;
+						f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
+						f3 integrand = rb * ds.z;
+						if (j == 0 && ps.total <= 0.0f)
+							result = result + (visibility ? integrand * rcp(dens_d) : zero);
+						else if (j == 0)
+							result = result + mis_estimate(heuristic, integrand, diffuse_weight, dens_d, specular_weight_rgb, dens_s, visibility_estimate);
+						else
+							result = result + mis_estimate(heuristic, integrand, specular_weight_rgb, dens_s, diffuse_weight, dens_d, visibility_estimate);
+					}
+				}
+			}
+			else if constexpr (STRATEGY == kStrategyRandom) {
+				float lum = (sd.diffuse_albedo.x * 0.21263901f + sd.diffuse_albedo.y * 0.71516868f) + sd.diffuse_albedo.z * 0.07219232f;
+				float diffuse_albedo = gmax(lum, 0.01f);
+				float diffuse_weight = diffuse_albedo * pd.total;
+				float diffuse_ratio = divide(diffuse_weight, diffuse_weight + specular_weight);
+				for (uint32_t s = 0; s != S; ++s) {
+					f2 u = next_noise_2(p, noise);
+					bool specular_selected = u.x >= diffuse_ratio;
+					float offset = specular_selected ? 1.0f : 0.0f;
+					u.x = divide(u.x - offset, diffuse_ratio - offset);
+					f3 ds = specular_selected ? sample_psa<V, kBiased>(ps, u) : sample_psa<V, kBiased>(pd, u);
+					if (specular_selected) ds = normalize(cosine_to_shading(ltc_in, ds));
+					float lambert = ds.z;
+					float dens_d = lambert * diffuse_albedo;
+					float dens_s = evaluate_ltc_density(ltc_in, ds, specular_albedo);
+					float density = divide(dens_d + dens_s, diffuse_weight + specular_weight);
+					bool visibility;
+					f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
+					if (!(ds.z <= 0.0f)) result = result + rb * divide(ds.z, density);
+				}
+			}
+		}
+	}
+
+	if constexpr (STRATEGY == kStrategyDiffuseGgxMis) {
+		// GGX VNDF samples that happen to hit the light (:676-709)
+		f3 out_shading = mul_direction(world_to_shading, sd.outgoing);
+		out_shading.y = 0.0f;
+		for (uint32_t s = 0; s != S; ++s) {
+			float ggx_density;
+			f3 dg = sample_ggx_reflected(ggx_density, out_shading, sd.roughness, next_noise_2(p, noise));
+			f3 dw = mul_transposed(world_to_shading, dg);
+			if (dg.z > 0.0f && light_ray_intersection(light, p.max_light_vertex_count, sd.position, dw, 0.0f)) {
+				float lambert;
+				bool visibility;
+				f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, dw, sd, light);
+				float polygon_density = kIsPsa ? (lambert * density_factor) : density_factor;
+				result = result + (rb * lambert) * mis_weight_over_density(p.mis_heuristic, ggx_density, polygon_density);
+			}
+		}
+	}
+	return result * (1.0f / (float) S);
+}
+
+// Maps the launch grid to a pixel and its output slot.  Workgroups are 16x16
+// pixel blocks of the tiles this rank owns; a wave is an 8x8 patch.
+VKR_DEV bool locate_pixel(const shade_params& p, uint32_t& px, uint32_t& py, size_t& out_index) {
+	uint32_t blocks_per_side = p.tile_size >> 4;
+	uint32_t blocks_per_tile = blocks_per_side * blocks_per_side;
+	uint32_t local_tile = blockIdx.x / blocks_per_tile;
+	uint32_t block_in_tile = blockIdx.x - local_tile * blocks_per_tile;
+	uint32_t tile = local_tile * p.rank_count + p.rank;
+	if (tile >= p.tile_count) return false;
+	uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+	uint32_t by = block_in_tile / blocks_per_side, bx = block_in_tile - by * blocks_per_side;
+	uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint32_t ix = (bx << 4) + ((wave & 1) << 3) + (lane & 7);
+	uint32_t iy = (by << 4) + ((wave >> 1) << 3) + (lane >> 3);
+	px = tx * p.tile_size + ix;
+	py = ty * p.tile_size + iy;
+	if (p.rank_count == 1) out_index = (size_t) py * p.width + px;
+	else out_index = (size_t) local_tile * p.tile_size * p.tile_size + (size_t) iy * p.tile_size + ix;
+	return px < p.width && py < p.height;
+}
+
+// main, shading_pass.frag.glsl:824-866
+template <int STRATEGY, int TECHNIQUE, int V, bool RAYS>
+__global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
+	uint32_t px, py;
+	size_t out_index;
+	bool inside = locate_pixel(p, px, py, out_index);
+	pixel_context ctx = {p, 0};
+	if (inside) {
+		const uint8_t* c = p.constants;
+		uint32_t primitive = p.visibility[(size_t) py * p.width + px];
+		f3 color = mk3(0.0f, 0.0f, 0.0f);
+		float fx = (float) (int32_t) px, fy = (float) (int32_t) py;
+		f3 ray = mk3(
+			(load_f(c, 96) * fx + load_f(c, 100) * fy) + load_f(c, 104) * 1.0f,
+			(load_f(c, 112) * fx + load_f(c, 116) * fy) + load_f(c, 120) * 1.0f,
+			(load_f(c, 128) * fx + load_f(c, 132) * fy) + load_f(c, 136) * 1.0f);
+		shading_data sd;
+		f3 end_xyz = ray;
+		float end_w = 0.0f;
+		if (primitive != 0xFFFFFFFFu) {
+			sd = get_shading_data(p, primitive, ray);
+			end_xyz = sd.position;
+			end_w = 1.0f;
+		}
+		if (p.show_polygonal_lights) {
+			f3 camera = load_f3(c, 144);
+			for (uint32_t i = 0; i != p.light_count; ++i) {
+				light_ref light = get_light(p, i);
+				if (light_ray_intersection(light, p.max_light_vertex_count, camera, end_xyz, end_w))
+					color = color + light_radiance(light);
+			}
+		}
+		if (primitive != 0xFFFFFFFFu) {
+			float fresnel_luminance = (sd.fresnel_0.x * 0.2126f + sd.fresnel_0.y * 0.7152f) + sd.fresnel_0.z * 0.0722f;
+			ltc_coefficients ltc = get_ltc_coefficients(p, fresnel_luminance, sd.roughness, sd.position, sd.normal, sd.outgoing);
+			noise_accessor noise;
+			noise.n0 = noise.n1 = noise.n2 = noise.n3 = 0.0f;
+			noise.available = 0; noise.px = px; noise.py = py; noise.sample_index = 0;
+			for (uint32_t i = 0; i != p.light_count; ++i) {
+				light_ref light = get_light(p, i);
+				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS>(ctx, sd, ltc, light, noise);
+			}
+		}
+		float exposure = load_f(c, 176);
+		bool broken = !(fabsf(color.x) < __builtin_inff()) || !(fabsf(color.y) < __builtin_inff()) || !(fabsf(color.z) < __builtin_inff());
+		if (broken) color = mk3(divide(1.0f, exposure), divide(0.0f, exposure), divide(0.8f, exposure));
+		p.out_radiance[out_index] = make_float4(color.x * exposure, color.y * exposure, color.z * exposure, 1.0f);
+	}
+	if (RAYS && p.ray_counter) {
+		// one atomic per wave
+		uint32_t rays = ctx.rays;
+#pragma unroll
+		for (int offset = 32; offset > 0; offset >>= 1) rays += __shfl_xor(rays, offset);
+		if ((threadIdx.x & 63) == 0 && rays) atomicAdd(p.ray_counter, (unsigned long long) rays);
+	}
+}
+
+}  // namespace vkr

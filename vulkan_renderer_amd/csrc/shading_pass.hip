@@ -1,0 +1,415 @@
+// Host side of the shading pass: variant selection, constant upload, launches,
+// output encoding and read-back behind the reference's entry points
+// (create_shading_pass src/main.c:598, write_constants :2114, the vkCmdDraw of
+// record_render_frame_commands :1428-1434, implement_screenshot :1719).
+#include "shading_kernel.h"
+#include "host/vkr_internal.h"
+#include <hip/hip_fp16.h>
+
+using namespace vkr;
+
+#define VKR_DECLARE_LAUNCH(mode, s) extern "C" int vkr_launch_shade_##mode##_##s(int technique, int capacity, int rays, const shade_params* p, unsigned int grid_x, void* stream);
+VKR_DECLARE_LAUNCH(exact, 0) VKR_DECLARE_LAUNCH(exact, 1) VKR_DECLARE_LAUNCH(exact, 2) VKR_DECLARE_LAUNCH(exact, 3) VKR_DECLARE_LAUNCH(exact, 4)
+VKR_DECLARE_LAUNCH(fast, 0) VKR_DECLARE_LAUNCH(fast, 1) VKR_DECLARE_LAUNCH(fast, 2) VKR_DECLARE_LAUNCH(fast, 3) VKR_DECLARE_LAUNCH(fast, 4)
+
+typedef int (*launch_function_t)(int, int, int, const shade_params*, unsigned int, void*);
+static const launch_function_t g_launchers[2][5] = {
+	{vkr_launch_shade_exact_0, vkr_launch_shade_exact_1, vkr_launch_shade_exact_2, vkr_launch_shade_exact_3, vkr_launch_shade_exact_4},
+	{vkr_launch_shade_fast_0, vkr_launch_shade_fast_1, vkr_launch_shade_fast_2, vkr_launch_shade_fast_3, vkr_launch_shade_fast_4},
+};
+
+static int hip_failed(hipError_t error, const char* what) {
+	if (error == hipSuccess) return 0;
+	printf("HIP error while %s: %s\n", what, hipGetErrorString(error));
+	return 1;
+}
+
+static int technique_index(sample_polygon_technique_t technique) {
+	switch (technique) {
+	case sample_polygon_projected_solid_angle: return kTechniquePsa;
+	case sample_polygon_projected_solid_angle_biased: return kTechniquePsaBiased;
+	case sample_polygon_solid_angle: return kTechniqueSolidAngle;
+	case sample_polygon_clipped_solid_angle: return kTechniqueClippedSolidAngle;
+	default: return -1;
+	}
+}
+
+// ---- render targets --------------------------------------------------------------
+
+extern "C" void destroy_render_targets(render_targets_t* targets, const device_t* device) {
+	vkr_device_free(targets->visibility_buffer, device);
+	vkr_device_free(targets->radiance, device);
+	vkr_device_free(targets->encoded, device);
+	memset(targets, 0, sizeof(*targets));
+}
+
+extern "C" int create_render_targets(render_targets_t* targets, const device_t* device, const swapchain_t* swapchain) {
+	memset(targets, 0, sizeof(*targets));
+	if (!device) {
+		printf("Render targets live in device memory; a HIP device is required.\n");
+		return 1;
+	}
+	size_t pixels = (size_t) swapchain->extent.width * swapchain->extent.height;
+	if (pixels == 0) return 2;  // reference main.c:1865: a minimised window is not an error
+	targets->extent = swapchain->extent;
+	// slabs are padded to whole tiles, so leave room for one extra row and column of 64-pixel tiles
+	size_t padded = ((size_t) swapchain->extent.width + 64) * ((size_t) swapchain->extent.height + 64);
+	if (vkr_device_alloc(&targets->visibility_buffer, device, sizeof(uint32_t) * pixels, "the visibility buffer")
+		|| vkr_device_alloc(&targets->radiance, device, sizeof(float) * 4 * padded, "the radiance target")
+		|| vkr_device_alloc(&targets->encoded, device, 4 * pixels, "the encoded output"))
+	{
+		destroy_render_targets(targets, device);
+		return 1;
+	}
+	hipStream_t stream = (hipStream_t) device->stream;
+	if (hip_failed(hipMemsetAsync(targets->visibility_buffer, 0xFF, sizeof(uint32_t) * pixels, stream), "clearing the visibility buffer")) {
+		destroy_render_targets(targets, device);
+		return 1;
+	}
+	return 0;
+}
+
+// ---- shading pass ----------------------------------------------------------------
+
+// device counter of traced shadow rays, shared by all passes of the process
+static unsigned long long* g_ray_counter = NULL;
+
+extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
+	vkr_device_free(pass->constants_device, device);
+	vkr_host_free_pinned(pass->constants_host);
+	if (pass->timing_events[0]) (void) hipEventDestroy((hipEvent_t) pass->timing_events[0]);
+	if (pass->timing_events[1]) (void) hipEventDestroy((hipEvent_t) pass->timing_events[1]);
+	memset(pass, 0, sizeof(*pass));
+}
+
+// The same legality rules the reference enforces in its GUI
+// (src/user_interface.cpp:90-180), as hard errors.
+static int validate_settings(const application_t* app) {
+	const render_settings_t* s = &app->render_settings;
+	const scene_specification_t* spec = &app->scene_specification;
+	int technique = technique_index(s->polygon_sampling_technique);
+	if (technique < 0) {
+		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Use solid angle, clipped solid angle or (biased) projected solid angle sampling.\n", (int) s->polygon_sampling_technique);
+		return 1;
+	}
+	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased;
+	if (s->sampling_strategies >= sampling_strategies_count || s->mis_heuristic >= mis_heuristic_count) {
+		printf("Invalid sampling strategy or MIS heuristic.\n");
+		return 1;
+	}
+	bool needs_specular = s->sampling_strategies == sampling_strategies_diffuse_specular_separately
+		|| s->sampling_strategies == sampling_strategies_diffuse_specular_mis
+		|| s->sampling_strategies == sampling_strategies_diffuse_specular_random;
+	if (needs_specular && !is_psa) {
+		printf("Sampling strategies with LTC importance sampling require projected solid angle sampling.\n");
+		return 1;
+	}
+	if ((s->mis_heuristic == mis_heuristic_weighted || s->mis_heuristic == mis_heuristic_optimal_clamped || s->mis_heuristic == mis_heuristic_optimal)
+		&& s->sampling_strategies == sampling_strategies_diffuse_ggx_mis)
+	{
+		printf("The weighted and optimal MIS heuristics are only defined for the diffuse+specular MIS strategy.\n");
+		return 1;
+	}
+	if (s->error_display != error_display_none) {
+		printf("Error display modes are not implemented in the kernels.\n");
+		return 1;
+	}
+	if (s->sample_count == 0) {
+		printf("The sample count must be positive.\n");
+		return 1;
+	}
+	for (uint32_t i = 0; i != spec->polygonal_light_count; ++i) {
+		const polygonal_light_t* light = &spec->polygonal_lights[i];
+		if (light->vertex_count < 3 || light->vertex_count > 7) {
+			printf("Polygonal light %u has %u vertices; the clipping and sorting code covers 3 to 7.\n", i, light->vertex_count);
+			return 1;
+		}
+		if (light->texturing_technique != polygon_texturing_none) {
+			printf("Polygonal light %u uses a texture; light textures are not part of the shading pass.\n", i);
+			return 1;
+		}
+	}
+	return 0;
+}
+
+extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
+	int32_t fast_math = pass->fast_math;
+	memset(pass, 0, sizeof(*pass));
+	pass->fast_math = fast_math ? 1 : 0;
+	pass->variant = -1;
+	const device_t* device = &app->device;
+	if (validate_settings(app)) return 1;
+	pass->use_ray_tracing = app->render_settings.trace_shadow_rays && app->scene.acceleration_structure.triangle_vertices != NULL;
+	if (app->render_settings.trace_shadow_rays && !pass->use_ray_tracing)
+		printf("Shadow rays were requested but the scene has no acceleration structure; rendering without shadows.\n");
+	pass->max_polygon_vertex_count = get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings);
+	pass->variant = (int32_t) app->render_settings.sampling_strategies * 4 + technique_index(app->render_settings.polygon_sampling_technique);
+	pass->constants_size = get_constant_buffer_size(app);
+	if (vkr_device_alloc(&pass->constants_device, device, pass->constants_size, "the constant buffer")
+		|| vkr_host_alloc_pinned(&pass->constants_host, pass->constants_size)
+		|| hip_failed(hipEventCreate((hipEvent_t*) &pass->timing_events[0]), "creating timing events")
+		|| hip_failed(hipEventCreate((hipEvent_t*) &pass->timing_events[1]), "creating timing events"))
+	{
+		printf("Failed to create the shading pass.\n");
+		destroy_shading_pass(pass, device);
+		return 1;
+	}
+	memset(pass->constants_host, 0, pass->constants_size);
+	return 0;
+}
+
+static void fill_tile_schedule(shade_params& p, const application_t* app, uint32_t& grid_blocks) {
+	tile_schedule_t schedule = app->tile_schedule;
+	if (schedule.rank_count <= 1) { schedule.rank = 0; schedule.rank_count = 1; }
+	if (schedule.tile_size < 16) schedule.tile_size = 16;
+	schedule.tile_size = (schedule.tile_size + 15) & ~15u;
+	p.tile_size = schedule.tile_size;
+	p.rank = schedule.rank;
+	p.rank_count = schedule.rank_count;
+	p.tiles_x = (p.width + p.tile_size - 1) / p.tile_size;
+	uint32_t tiles_y = (p.height + p.tile_size - 1) / p.tile_size;
+	p.tile_count = p.tiles_x * tiles_y;
+	uint32_t own_tiles = (p.tile_count + p.rank_count - 1 - p.rank) / p.rank_count;
+	uint32_t blocks_per_tile = (p.tile_size / 16) * (p.tile_size / 16);
+	grid_blocks = own_tiles * blocks_per_tile;
+}
+
+extern "C" uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank) {
+	shade_params p;
+	memset(&p, 0, sizeof(p));
+	p.width = app->swapchain.extent.width;
+	p.height = app->swapchain.extent.height;
+	application_t copy = *app;
+	copy.tile_schedule.rank = rank;
+	uint32_t grid_blocks = 0;
+	fill_tile_schedule(p, &copy, grid_blocks);
+	return (uint64_t) grid_blocks * 256;
+}
+
+extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
+	shading_pass_t* pass = &app->shading_pass;
+	const device_t* device = &app->device;
+	if (pass->variant < 0 || !pass->constants_device) {
+		printf("render_shading_pass() needs a shading pass created by create_shading_pass().\n");
+		return 1;
+	}
+	if (get_constant_buffer_size(app) != pass->constants_size
+		|| get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings) != pass->max_polygon_vertex_count
+		|| (int32_t) app->render_settings.sampling_strategies * 4 + technique_index(app->render_settings.polygon_sampling_technique) != pass->variant)
+	{
+		printf("Lights or render settings changed in a way that needs a different kernel variant. Recreate the shading pass (the reference recompiles its shader in this situation, main.c:1833-1881).\n");
+		return 1;
+	}
+	hipStream_t stream = (hipStream_t) device->stream;
+	write_constants(pass->constants_host, app);
+	if (vkr_copy_to_device_async(pass->constants_device, pass->constants_host, pass->constants_size, device)) return 1;
+	shade_params p;
+	memset(&p, 0, sizeof(p));
+	p.constants = (const uint8_t*) pass->constants_device;
+	p.light_count = app->scene_specification.polygonal_light_count;
+	p.max_light_vertex_count = get_max_polygonal_light_vertex_count(&app->scene_specification);
+	p.sample_count = app->render_settings.sample_count;
+	p.mis_heuristic = (int32_t) app->render_settings.mis_heuristic;
+	p.show_polygonal_lights = app->render_settings.show_polygonal_lights ? 1 : 0;
+	p.positions = (const uint2*) app->scene.mesh.positions;
+	p.normals_and_tex_coords = (const uint2*) app->scene.mesh.normals_and_tex_coords;
+	p.material_indices = (const uint8_t*) app->scene.mesh.material_indices;
+	p.material_constants = (const float*) app->scene.materials.constants;
+	p.visibility = (const uint32_t*) app->render_targets.visibility_buffer;
+	p.out_radiance = (float4*) (out_radiance ? out_radiance : app->render_targets.radiance);
+	p.width = app->swapchain.extent.width;
+	p.height = app->swapchain.extent.height;
+	p.ltc_rgba = (const uint2*) app->ltc_table.device_rgba;
+	p.ltc_rg = (const uint32_t*) app->ltc_table.device_rg;
+	p.ltc_resolution = app->ltc_table.roughness_count;
+	p.ltc_layer_count = app->ltc_table.fresnel_count;
+	p.noise = (const uint2*) app->noise_table.device_data;
+	p.noise_width = app->noise_table.resolution.width;
+	p.noise_height = app->noise_table.resolution.height;
+	p.bvh.nodes = (const bvh_node*) app->scene.acceleration_structure.nodes;
+	p.bvh.triangles = (const float4*) app->scene.acceleration_structure.triangle_vertices;
+	p.bvh.root = app->scene.acceleration_structure.root;
+	if (!p.positions || !p.visibility || !p.out_radiance || !p.ltc_rgba || !p.noise || !p.material_constants) {
+		printf("render_shading_pass() needs a loaded scene, LTC table, noise table and render targets on the device.\n");
+		return 1;
+	}
+	if (p.width != app->render_targets.extent.width || p.height != app->render_targets.extent.height) {
+		printf("The render targets do not match the swapchain extent.\n");
+		return 1;
+	}
+	uint32_t grid_blocks = 0;
+	fill_tile_schedule(p, app, grid_blocks);
+	if (pass->use_ray_tracing) {
+		if (!g_ray_counter && hip_failed(hipMalloc(&g_ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
+		if (hip_failed(hipMemsetAsync(g_ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
+		p.ray_counter = g_ray_counter;
+	}
+	int strategy = (int) app->render_settings.sampling_strategies;
+	int technique = technique_index(app->render_settings.polygon_sampling_technique);
+	bool is_clipped = technique != kTechniqueSolidAngle;
+	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
+	(void) hipEventRecord((hipEvent_t) pass->timing_events[0], stream);
+	int status = g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, pass->use_ray_tracing ? 1 : 0, &p, grid_blocks, stream);
+	(void) hipEventRecord((hipEvent_t) pass->timing_events[1], stream);
+	if (status < 0) {
+		printf("No kernel variant was built for strategy %d, technique %d, vertex capacity %d.\n", strategy, technique, capacity);
+		return 1;
+	}
+	if (status > 0) {
+		printf("Launching the shading kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
+		return 1;
+	}
+	return 0;
+}
+
+extern "C" float get_last_dispatch_milliseconds(application_t* app) {
+	shading_pass_t* pass = &app->shading_pass;
+	float ms = 0.0f;
+	if (!pass->timing_events[0]) return 0.0f;
+	if (hipEventSynchronize((hipEvent_t) pass->timing_events[1]) != hipSuccess) return 0.0f;
+	if (hipEventElapsedTime(&ms, (hipEvent_t) pass->timing_events[0], (hipEvent_t) pass->timing_events[1]) != hipSuccess) return 0.0f;
+	pass->last_dispatch_ms = ms;
+	return ms;
+}
+
+extern "C" uint64_t get_last_ray_count(const application_t* app) {
+	unsigned long long rays = 0;
+	if (!g_ray_counter || !app->shading_pass.use_ray_tracing) return 0;
+	if (vkr_copy_to_host(&rays, g_ray_counter, sizeof(rays), &app->device)) return 0;
+	return rays;
+}
+
+// ---- slabs -> frame ----------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_assemble_frame(const float4* slabs, float4* frame, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tiles_x, uint32_t rank_count, uint64_t slab_stride) {
+	uint32_t px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+	if (px >= width || py >= height) return;
+	uint32_t tx = px / tile_size, ty = py / tile_size;
+	uint32_t tile = ty * tiles_x + tx;
+	uint32_t rank = tile % rank_count, local_tile = tile / rank_count;
+	uint32_t ix = px - tx * tile_size, iy = py - ty * tile_size;
+	frame[(size_t) py * width + px] = slabs[rank * slab_stride + (size_t) local_tile * tile_size * tile_size + (size_t) iy * tile_size + ix];
+}
+
+extern "C" int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance) {
+	shade_params p;
+	memset(&p, 0, sizeof(p));
+	p.width = app->swapchain.extent.width;
+	p.height = app->swapchain.extent.height;
+	uint32_t grid_blocks = 0;
+	application_t first = *app;
+	first.tile_schedule.rank = 0;
+	fill_tile_schedule(p, &first, grid_blocks);
+	uint64_t slab_stride = (uint64_t) grid_blocks * 256;
+	dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
+	k_assemble_frame<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const float4*) gathered_slabs, (float4*) (out_radiance ? out_radiance : app->render_targets.radiance),
+		p.width, p.height, p.tile_size, p.tiles_x, p.rank_count, slab_stride);
+	return hip_failed(hipGetLastError(), "assembling the frame");
+}
+
+// ---- output encoding (shading_pass.frag.glsl:871-892, srgb_utility.glsl) --------------
+
+__device__ __forceinline__ float linear_to_srgb(float v) {
+	v = gclamp(v, 0.0f, 1.0f);
+	return (v <= 0.0031308f) ? (12.92f * v) : (1.055f * powf(v, 1.0f / 2.4f) - 0.055f);
+}
+__device__ __forceinline__ float srgb_to_linear(float v) {
+	v = gclamp(v, 0.0f, 1.0f);
+	return (v <= 0.04045f) ? ((1.0f / 12.92f) * v) : powf(fmaf(v, 1.0f / 1.055f, 0.055f / 1.055f), 2.4f);
+}
+__device__ __forceinline__ uint32_t to_unorm8(float v) {
+	v = gclamp(v, 0.0f, 1.0f);
+	return (uint32_t) (v * 255.0f + 0.5f);
+}
+
+__global__ void __launch_bounds__(256) k_encode_output(const float4* radiance, uint32_t* encoded, uint64_t pixel_count, uint32_t frame_bits, int output_linear_rgb) {
+	uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= pixel_count) return;
+	float4 c = radiance[i];
+	uint32_t r, g, b, a;
+	if (frame_bits == 0) {
+		// an *_SRGB target encodes in hardware, any other gets the transfer function in the shader
+		r = to_unorm8(linear_to_srgb(c.x)); g = to_unorm8(linear_to_srgb(c.y)); b = to_unorm8(linear_to_srgb(c.z));
+		a = to_unorm8(c.w);
+	}
+	else {
+		uint32_t mask = (frame_bits == 1) ? 0xFF : 0xFF00, shift = (frame_bits == 1) ? 0 : 8;
+		uint32_t h0 = (uint32_t) __half_as_ushort(__float2half_rn(c.x)) | ((uint32_t) __half_as_ushort(__float2half_rn(c.y)) << 16);
+		uint32_t h1 = (uint32_t) __half_as_ushort(__float2half_rn(c.z));
+		float v[3] = {
+			(float) ((h0 & mask) >> shift) * (1.0f / 255.0f),
+			(float) ((((h0 & 0xFFFF0000u) >> 16) & mask) >> shift) * (1.0f / 255.0f),
+			(float) ((h1 & mask) >> shift) * (1.0f / 255.0f)};
+		uint32_t out[3];
+		for (int j = 0; j != 3; ++j) out[j] = to_unorm8(output_linear_rgb ? linear_to_srgb(srgb_to_linear(v[j])) : v[j]);
+		r = out[0]; g = out[1]; b = out[2];
+		a = 255;
+	}
+	encoded[i] = r | (g << 8) | (b << 16) | (a << 24);
+}
+
+extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
+	uint64_t pixels = (uint64_t) app->swapchain.extent.width * app->swapchain.extent.height;
+	if (!app->render_targets.radiance || !app->render_targets.encoded) return 1;
+	k_encode_output<<<(uint32_t) ((pixels + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) app->render_targets.radiance, (uint32_t*) app->render_targets.encoded,
+		pixels, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
+	return hip_failed(hipGetLastError(), "encoding the output");
+}
+
+// ---- primary visibility ------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_primary_visibility(const uint8_t* constants, bvh_view bvh, uint32_t* visibility, uint32_t width, uint32_t height, float near, float far) {
+	uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint32_t px = blockIdx.x * 16 + ((wave & 1) << 3) + (lane & 7);
+	uint32_t py = blockIdx.y * 16 + ((wave >> 1) << 3) + (lane >> 3);
+	if (px >= width || py >= height) return;
+	float fx = (float) px, fy = (float) py;
+	f3 ray = mk3(
+		(load_f(constants, 96) * fx + load_f(constants, 100) * fy) + load_f(constants, 104),
+		(load_f(constants, 112) * fx + load_f(constants, 116) * fy) + load_f(constants, 120),
+		(load_f(constants, 128) * fx + load_f(constants, 132) * fy) + load_f(constants, 136));
+	f3 origin = load_f3(constants, 144);
+	// The unnormalised ray direction has view-space depth 1 (it is the unprojection of
+	// clip-space w = 1), so the depth range [near, far] is the parameter range.
+	visibility[(size_t) py * width + px] = closest_front_hit(bvh, origin, ray, near, far);
+}
+
+extern "C" int render_visibility_pass(application_t* app) {
+	shading_pass_t* pass = &app->shading_pass;
+	const acceleration_structure_t* as = &app->scene.acceleration_structure;
+	if (!as->triangle_vertices || !pass->constants_device) {
+		printf("The visibility pass needs an acceleration structure and a shading pass.\n");
+		return 1;
+	}
+	write_constants(pass->constants_host, app);
+	if (vkr_copy_to_device_async(pass->constants_device, pass->constants_host, pass->constants_size, &app->device)) return 1;
+	bvh_view bvh;
+	bvh.nodes = (const bvh_node*) as->nodes;
+	bvh.triangles = (const float4*) as->triangle_vertices;
+	bvh.root = as->root;
+	uint32_t width = app->swapchain.extent.width, height = app->swapchain.extent.height;
+	dim3 grid((width + 15) / 16, (height + 15) / 16);
+	k_primary_visibility<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const uint8_t*) pass->constants_device, bvh, (uint32_t*) app->render_targets.visibility_buffer,
+		width, height, app->scene_specification.camera.near, app->scene_specification.camera.far);
+	return hip_failed(hipGetLastError(), "rendering the visibility pass");
+}
+
+// ---- transfers -------------------------------------------------------------------
+
+extern "C" int read_back_radiance(application_t* app, float* host_rgba) {
+	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
+	return vkr_copy_to_host(host_rgba, app->render_targets.radiance, sizeof(float) * 4 * pixels, &app->device);
+}
+extern "C" int read_back_encoded(application_t* app, uint8_t* host_rgba8) {
+	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
+	return vkr_copy_to_host(host_rgba8, app->render_targets.encoded, 4 * pixels, &app->device);
+}
+extern "C" int read_back_visibility(application_t* app, uint32_t* host_primitives) {
+	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
+	return vkr_copy_to_host(host_primitives, app->render_targets.visibility_buffer, sizeof(uint32_t) * pixels, &app->device);
+}
+extern "C" int upload_visibility(application_t* app, const uint32_t* host_primitives) {
+	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
+	if (hip_failed(hipMemcpy(app->render_targets.visibility_buffer, host_primitives, sizeof(uint32_t) * pixels, hipMemcpyHostToDevice), "uploading the visibility buffer")) return 1;
+	return 0;
+}

@@ -1,0 +1,56 @@
+// Instantiates the shade_pixels variants of one sampling strategy and one
+// arithmetic mode.  Built once per (VKR_STRATEGY, VKR_FAST_MATH) pair so that the
+// translation units compile in parallel; the exact-mode units are compiled with
+// -ffp-contract=off, the fast-mode units with -ffp-contract=fast.
+#include "shading_kernel.h"
+
+#ifndef VKR_STRATEGY
+#error "define VKR_STRATEGY (0..4)"
+#endif
+
+#define VKR_CAT2(a, b, c, d) a##b##c##d
+#define VKR_CAT(a, b, c, d) VKR_CAT2(a, b, c, d)
+#if VKR_FAST_MATH
+#define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_fast_, VKR_STRATEGY, , )
+#else
+#define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_exact_, VKR_STRATEGY, , )
+#endif
+
+using namespace vkr;
+
+template <int TECHNIQUE, int V>
+static int launch_rays(bool rays, const shade_params& p, dim3 grid, hipStream_t stream) {
+	if (rays) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, true><<<grid, 256, 0, stream>>>(p);
+	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, false><<<grid, 256, 0, stream>>>(p);
+	return hipGetLastError() != hipSuccess;
+}
+
+template <int TECHNIQUE>
+static int launch_capacity(int capacity, bool rays, const shade_params& p, dim3 grid, hipStream_t stream) {
+	switch (capacity) {
+	case 3: if constexpr (TECHNIQUE == kTechniqueSolidAngle) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
+	case 4: return launch_rays<TECHNIQUE, 4>(rays, p, grid, stream);
+	case 5: return launch_rays<TECHNIQUE, 5>(rays, p, grid, stream);
+	case 6: return launch_rays<TECHNIQUE, 6>(rays, p, grid, stream);
+	case 7: return launch_rays<TECHNIQUE, 7>(rays, p, grid, stream);
+	case 8: if constexpr (TECHNIQUE != kTechniqueSolidAngle) return launch_rays<TECHNIQUE, 8>(rays, p, grid, stream); else return -1;
+	default: return -1;
+	}
+}
+
+// Returns 0 on success, 1 on a launch error, -1 if this combination is not built
+extern "C" int VKR_LAUNCH_NAME(int technique, int capacity, int rays, const shade_params* p, unsigned int grid_x, void* stream) {
+	dim3 grid(grid_x, 1, 1);
+	hipStream_t s = (hipStream_t) stream;
+	switch (technique) {
+	case kTechniquePsa: return launch_capacity<kTechniquePsa>(capacity, rays != 0, *p, grid, s);
+	case kTechniquePsaBiased: return launch_capacity<kTechniquePsaBiased>(capacity, rays != 0, *p, grid, s);
+#if VKR_STRATEGY == 0 || VKR_STRATEGY == 1
+	// the solid-angle samplers only pair with these two strategies
+	// (reference shading_pass.frag.glsl:305-323 returns black otherwise)
+	case kTechniqueSolidAngle: return launch_capacity<kTechniqueSolidAngle>(capacity, rays != 0, *p, grid, s);
+	case kTechniqueClippedSolidAngle: return launch_capacity<kTechniqueClippedSolidAngle>(capacity, rays != 0, *p, grid, s);
+#endif
+	default: return -1;
+	}
+}

@@ -1,0 +1,271 @@
+"""Host-side driver of the shading pass, written against the C-ABI only.
+
+It plays the role of the reference's startup_application / render_frame
+(src/main.c:1896, :2197) for tests and bench.py: load the scene, LTC table and
+noise table, specify lights and settings, create the pass, render, read back.
+All arithmetic happens inside libvkr_shading.so; if the library or a GPU is
+missing, construction fails loudly - there is no CPU fallback."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import capi
+
+STRATEGY = {"diffuse_only": 0, "diffuse_ggx_mis": 1, "diffuse_specular_separately": 2,
+            "diffuse_specular_mis": 3, "diffuse_specular_random": 4}
+MIS = {"balance": 0, "power": 1, "weighted": 2, "optimal_clamped": 3, "optimal": 4}
+TECHNIQUE = {"solid_angle": 4, "clipped_solid_angle": 5, "projected_solid_angle": 11,
+             "projected_solid_angle_biased": 12}
+NOISE = {"white": 0, "blue": 1, "ahmed": 2}
+
+
+def _enum(table, value):
+    return table[value] if isinstance(value, str) else int(value)
+
+
+class HostScene:
+    """Device-less use of the loader surface (parsing, quantisation, constants)."""
+
+    def __init__(self):
+        self.lib = capi.load()
+        self.app = capi.Application()
+        self._device = None
+        self._lights_keepalive = None
+
+    # -- loaders -------------------------------------------------------------------
+    def _dev(self):
+        return C.byref(self.app.device) if self._device else None
+
+    def load_scene(self, path, texture_path=None, acceleration_structure=False):
+        rc = self.lib.load_scene(C.byref(self.app.scene), self._dev(), path.encode(),
+                                 texture_path.encode() if texture_path else None, int(acceleration_structure))
+        if rc:
+            raise RuntimeError("load_scene failed for %s" % path)
+
+    def load_ltc_table(self, directory, fresnel_count=51):
+        if self.lib.load_ltc_table(C.byref(self.app.ltc_table), self._dev(), directory.encode(), fresnel_count):
+            raise RuntimeError("load_ltc_table failed for %s" % directory)
+
+    def load_noise_table(self, noise_type="white", resolution=None):
+        t = _enum(NOISE, noise_type)
+        res = self.lib.get_default_noise_resolution(t)
+        if resolution is not None:
+            res = capi.Extent3D(*resolution)
+        if self.lib.load_noise_table(C.byref(self.app.noise_table), self._dev(), res, t):
+            raise RuntimeError("load_noise_table failed")
+
+    # -- scene specification ---------------------------------------------------------
+    def set_camera(self, position, rotation_x, rotation_z, vertical_fov, near=0.05, far=1.0e3):
+        cam = self.app.scene_specification.camera
+        cam.position_world_space[:] = position
+        cam.rotation_x, cam.rotation_z, cam.vertical_fov = rotation_x, rotation_z, vertical_fov
+        cam.near, cam.far, cam.speed = near, far, 2.0
+
+    def set_lights(self, lights):
+        """lights: list of dicts from synthetic.light_spec()."""
+        spec = self.app.scene_specification
+        for i in range(spec.polygonal_light_count):
+            self.lib.destroy_polygonal_light(C.byref(spec.polygonal_lights[i]))
+        array = (capi.PolygonalLight * max(len(lights), 1))()
+        for i, l in enumerate(lights):
+            light = array[i]
+            light.rotation_angles[:] = l["rotation_angles"]
+            light.translation[:] = l["translation"]
+            light.radiant_flux[:] = l["radiant_flux"]
+            light.scaling_x, light.scaling_y = l["scaling"]
+            v = np.asarray(l["vertices_plane_space"], np.float32)
+            self.lib.set_polygonal_light_vertex_count(C.byref(light), len(v))
+            for j in range(len(v)):
+                light.vertices_plane_space[4 * j + 0] = float(v[j, 0])
+                light.vertices_plane_space[4 * j + 1] = float(v[j, 1])
+            self.lib.update_polygonal_light(C.byref(light))
+        self._lights_keepalive = array
+        spec.polygonal_lights = C.cast(array, C.POINTER(capi.PolygonalLight))
+        spec.polygonal_light_count = len(lights)
+
+    def set_settings(self, **kw):
+        s = self.app.render_settings
+        if "exposure_factor" not in kw and s.exposure_factor == 0.0:
+            self.lib.specify_default_render_settings(C.byref(s))
+            s.show_polygonal_lights = 0
+            s.animate_noise = 0
+            s.noise_type = 0
+        for key, value in kw.items():
+            if key == "sampling_strategies":
+                s.sampling_strategies = _enum(STRATEGY, value)
+            elif key == "mis_heuristic":
+                s.mis_heuristic = _enum(MIS, value)
+            elif key in ("polygon_technique", "polygon_sampling_technique"):
+                s.polygon_sampling_technique = _enum(TECHNIQUE, value)
+            elif key in ("width", "height"):
+                pass
+            elif key in ("trace_shadow_rays", "show_polygonal_lights", "animate_noise"):
+                setattr(s, key, int(bool(value)))
+            else:
+                setattr(s, key, value)
+        if "width" in kw:
+            self.app.swapchain.extent.width = kw["width"]
+        if "height" in kw:
+            self.app.swapchain.extent.height = kw["height"]
+
+    # -- constants --------------------------------------------------------------------
+    def constants(self):
+        """Byte image of write_constants() as a numpy array."""
+        size = self.lib.get_constant_buffer_size(C.byref(self.app))
+        buf = np.zeros(size, np.uint8)
+        self.lib.write_constants(buf.ctypes.data, C.byref(self.app))
+        return buf
+
+    def max_light_vertex_count(self):
+        return self.lib.get_max_polygonal_light_vertex_count(C.byref(self.app.scene_specification))
+
+    # -- host views of the loaded data (inputs for the CPU oracle in tests) -------------
+    def host_inputs(self, visibility=None):
+        app = self.app
+        T = app.scene.mesh.triangle_count
+        ltc = app.ltc_table
+        n = app.noise_table.resolution
+        layers, res = ltc.fresnel_count, ltc.roughness_count
+        inputs = {
+            "constants": self.constants(),
+            "light_count": app.scene_specification.polygonal_light_count,
+            "max_light_vertex_count": self.max_light_vertex_count(),
+            "quantized_positions": np.ctypeslib.as_array(app.scene.mesh.host_positions, (T * 3, 2)).copy(),
+            "normals_and_tex_coords": np.ctypeslib.as_array(app.scene.mesh.host_normals_and_tex_coords, (T * 3, 4)).copy(),
+            "material_indices": np.ctypeslib.as_array(app.scene.mesh.host_material_indices, (T,)).copy(),
+            "material_constants": np.ctypeslib.as_array(app.scene.materials.host_constants, (app.scene.materials.material_count * 8,)).copy(),
+            "ltc_rgba": np.ctypeslib.as_array(ltc.host_rgba, (layers, res, res, 4)).copy(),
+            "ltc_rg": np.ctypeslib.as_array(ltc.host_rg, (layers, res, res, 2)).copy(),
+            "noise": np.ctypeslib.as_array(app.noise_table.host_data, (n.depth, n.height, n.width, 4)).copy(),
+            "dequantization_factor": np.array(app.scene.mesh.dequantization_factor[:], np.float32),
+            "dequantization_summand": np.array(app.scene.mesh.dequantization_summand[:], np.float32),
+        }
+        if visibility is not None:
+            inputs["visibility"] = np.ascontiguousarray(visibility, np.uint32)
+        return inputs
+
+    def oracle_settings(self):
+        s = self.app.render_settings
+        return {"sampling_strategies": s.sampling_strategies, "mis_heuristic": s.mis_heuristic,
+                "polygon_technique": s.polygon_sampling_technique, "sample_count": s.sample_count,
+                "trace_shadow_rays": bool(s.trace_shadow_rays), "show_polygonal_lights": bool(s.show_polygonal_lights)}
+
+    def close(self):
+        app = self.app
+        dev = self._dev()
+        if app.shading_pass.constants_device:
+            self.lib.destroy_shading_pass(C.byref(app.shading_pass), dev)
+        if app.render_targets.radiance:
+            self.lib.destroy_render_targets(C.byref(app.render_targets), dev)
+        self.lib.destroy_scene(C.byref(app.scene), dev)
+        self.lib.destroy_ltc_table(C.byref(app.ltc_table), dev)
+        self.lib.destroy_noise_table(C.byref(app.noise_table), dev)
+        spec = app.scene_specification
+        for i in range(spec.polygonal_light_count):
+            self.lib.destroy_polygonal_light(C.byref(spec.polygonal_lights[i]))
+        spec.polygonal_light_count = 0
+        self._lights_keepalive = None
+
+
+class Renderer(HostScene):
+    """The shading pass on one MI355X."""
+
+    def __init__(self, hip_device=0, stream=None, fast_math=False):
+        super().__init__()
+        if self.lib.create_hip_device(C.byref(self.app.device), hip_device, stream):
+            raise RuntimeError("no usable HIP device: the shading pass has no CPU fallback")
+        self._device = True
+        self.fast_math = fast_math
+
+    def create_targets(self):
+        if self.app.render_targets.radiance:
+            self.lib.destroy_render_targets(C.byref(self.app.render_targets), self._dev())
+        if self.lib.create_render_targets(C.byref(self.app.render_targets), self._dev(), C.byref(self.app.swapchain)):
+            raise RuntimeError("create_render_targets failed")
+
+    def create_pass(self):
+        if self.app.shading_pass.constants_device:
+            self.lib.destroy_shading_pass(C.byref(self.app.shading_pass), self._dev())
+        self.app.shading_pass.fast_math = int(self.fast_math)
+        if self.lib.create_shading_pass(C.byref(self.app.shading_pass), C.byref(self.app)):
+            raise RuntimeError("create_shading_pass failed")
+
+    def set_tiles(self, tile_size=16, rank=0, rank_count=1):
+        t = self.app.tile_schedule
+        t.tile_size, t.rank, t.rank_count = tile_size, rank, rank_count
+
+    def upload_visibility(self, visibility):
+        v = np.ascontiguousarray(visibility, np.uint32)
+        if self.lib.upload_visibility(C.byref(self.app), v.ctypes.data):
+            raise RuntimeError("upload_visibility failed")
+
+    def render_visibility(self):
+        if self.lib.render_visibility_pass(C.byref(self.app)):
+            raise RuntimeError("render_visibility_pass failed")
+
+    def render(self, out_pointer=None):
+        if self.lib.render_shading_pass(C.byref(self.app), out_pointer):
+            raise RuntimeError("render_shading_pass failed")
+
+    def last_ms(self):
+        return float(self.lib.get_last_dispatch_milliseconds(C.byref(self.app)))
+
+    def last_ray_count(self):
+        return int(self.lib.get_last_ray_count(C.byref(self.app)))
+
+    def sync(self):
+        self.lib.wait_for_device(C.byref(self.app.device))
+
+    def read_radiance(self):
+        e = self.app.swapchain.extent
+        out = np.zeros((e.height, e.width, 4), np.float32)
+        if self.lib.read_back_radiance(C.byref(self.app), out.ctypes.data):
+            raise RuntimeError("read_back_radiance failed")
+        return out
+
+    def read_visibility(self):
+        e = self.app.swapchain.extent
+        out = np.zeros((e.height, e.width), np.uint32)
+        if self.lib.read_back_visibility(C.byref(self.app), out.ctypes.data):
+            raise RuntimeError("read_back_visibility failed")
+        return out
+
+    def read_encoded(self, output_linear_rgb=False, frame_bits=0):
+        e = self.app.swapchain.extent
+        self.app.screenshot.frame_bits = frame_bits
+        if self.lib.encode_output(C.byref(self.app), int(output_linear_rgb)):
+            raise RuntimeError("encode_output failed")
+        out = np.zeros((e.height, e.width, 4), np.uint8)
+        if self.lib.read_back_encoded(C.byref(self.app), out.ctypes.data):
+            raise RuntimeError("read_back_encoded failed")
+        self.app.screenshot.frame_bits = 0
+        return out
+
+    def slab_pixel_count(self, rank=0):
+        return int(self.lib.get_slab_pixel_count(C.byref(self.app), rank))
+
+    def assemble(self, gathered_pointer, out_pointer=None):
+        if self.lib.assemble_frame_from_slabs(C.byref(self.app), gathered_pointer, out_pointer):
+            raise RuntimeError("assemble_frame_from_slabs failed")
+
+
+def setup_config(scene, config, dataset, width=None, height=None, **overrides):
+    """Applies one of the BASELINE.json configurations to a HostScene / Renderer."""
+    from . import synthetic
+    settings = dict(synthetic.CONFIG_SETTINGS[config])
+    if width:
+        settings["width"] = width
+    if height:
+        settings["height"] = height
+    settings.update(overrides)
+    wants_rays = bool(settings.get("trace_shadow_rays", False))
+    scene.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=wants_rays or overrides.get("acceleration_structure", False))
+    scene.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
+    scene.load_noise_table("white")
+    cam = synthetic.DEFAULT_CAMERA
+    scene.set_camera(cam["position"], cam["rotation_x"], cam["rotation_z"], cam["vertical_fov"], cam["near"], cam["far"])
+    scene.set_lights(synthetic.config_lights(config))
+    settings.pop("acceleration_structure", None)
+    scene.set_settings(**settings)
+    return settings

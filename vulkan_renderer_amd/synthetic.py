@@ -1,0 +1,265 @@
+"""Synthetic inputs in the reference's binary formats (no downloads possible).
+
+Writers for: .vks scenes (format: reference src/scene.c:419-483, written the way
+tools/io_export_vulkan_blender28.py:472-530 quantises), LTC fit files
+(src/ltc_table.c:31-82), constant .vkt material textures (src/textures.c:101-172)
+and the light / camera set-ups of the BASELINE.json configurations.  Everything
+is seeded and deterministic."""
+import math
+import os
+import struct
+
+import numpy as np
+
+# ---- .vks -----------------------------------------------------------------------
+
+
+def _morton_10(v):
+    v = v.astype(np.uint64) & 0x3FF
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    v = (v | (v << 2)) & 0x09249249
+    return v
+
+
+def encode_octahedral_normals(normals):
+    """(..., 3) unit normals -> two uint16 arrays (octahedral map, -1 -> 1, 0 -> 32768, +1 -> 65535)."""
+    n = np.asarray(normals, np.float64)
+    o = n[..., :2] / np.abs(n).sum(axis=-1, keepdims=True)
+    sign = np.where(o >= 0.0, 1.0, -1.0)
+    folded = (1.0 - np.abs(o[..., ::-1])) * sign
+    o = np.where(n[..., 2:3] <= 0.0, folded, o)
+    q = np.floor(o * 32767.0 + 32768.5)
+    q = np.clip(q, 0, 65535).astype(np.uint16)
+    return q[..., 0], q[..., 1]
+
+
+def write_vks(path, positions, normals, uvs, material_indices, material_names, sort_triangles=True):
+    """positions, normals: (T, 3, 3); uvs: (T, 3, 2); material_indices: (T,).
+    Returns the dict of buffers exactly as they are stored in the file."""
+    positions = np.asarray(positions, np.float32)
+    normals = np.asarray(normals, np.float32)
+    uvs = np.asarray(uvs, np.float32).copy()
+    material_indices = np.asarray(material_indices, np.uint8)
+    T = positions.shape[0]
+    flat = positions.reshape(-1, 3).astype(np.float64)
+    box_min, box_max = flat.min(axis=0), flat.max(axis=0)
+    box_max = np.maximum(box_max, box_min + 1e-6)
+    if sort_triangles:
+        c = positions.astype(np.float64).mean(axis=1)
+        g = np.clip(((c - c.min(axis=0)) / np.maximum(np.ptp(c, axis=0), 1e-12) * 1023.0), 0, 1023).astype(np.uint64)
+        code = (_morton_10(g[:, 0]) << np.uint64(2)) | (_morton_10(g[:, 1]) << np.uint64(1)) | _morton_10(g[:, 2])
+        order = np.argsort(code, kind="stable")
+        positions, normals, uvs, material_indices = positions[order], normals[order], uvs[order], material_indices[order]
+        flat = positions.reshape(-1, 3).astype(np.float64)
+    # 21 bits per coordinate; the summand places samples at cell centres
+    qf = (2.0 ** 21) / (box_max - box_min)
+    q = np.minimum((flat * qf - box_min * qf).astype(np.uint64), 2 ** 21 - 1).astype(np.uint32)
+    factor = (1.0 / qf).astype(np.float32)
+    summand = (box_min + 0.5 / qf).astype(np.float32)
+    packed = np.zeros((T * 3, 2), np.uint32)
+    packed[:, 0] = q[:, 0] | ((q[:, 1] & 0x7FF) << 21)
+    packed[:, 1] = ((q[:, 1] & 0x1FF800) >> 11) | (q[:, 2] << 10)
+    # texture coordinates: shift each triangle into [0, 8), 16-bit UNORM of uv / 8
+    uvs -= np.floor(uvs.min(axis=1, keepdims=True))
+    nuv = np.zeros((T * 3, 4), np.uint16)
+    nuv[:, 2:4] = np.clip(uvs.reshape(-1, 2) * (65535.0 / 8.0) + 0.5, 0.0, 65535.0).astype(np.uint16)
+    nx, ny = encode_octahedral_normals(normals.reshape(-1, 3))
+    nuv[:, 0], nuv[:, 1] = nx, ny
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 0x00ABCABC, 1))
+        f.write(struct.pack("<QQ", len(material_names), T))
+        f.write(struct.pack("<fff", *factor))
+        f.write(struct.pack("<fff", *summand))
+        for name in material_names:
+            b = name.encode("utf-8")
+            f.write(struct.pack("<Q", len(b)))
+            f.write(b + b"\0")
+        f.write(packed.tobytes())
+        f.write(nuv.tobytes())
+        f.write(material_indices.tobytes())
+        f.write(struct.pack("<I", 0x00E0FE0F))
+    return {"quantized_positions": packed, "normals_and_tex_coords": nuv, "material_indices": material_indices,
+            "dequantization_factor": factor, "dequantization_summand": summand}
+
+
+def _box_triangles(center, half, rotation_z):
+    c, s = math.cos(rotation_z), math.sin(rotation_z)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    corners = np.array([[x, y, z] for z in (-1, 1) for y in (-1, 1) for x in (-1, 1)], np.float64) * half
+    corners = corners @ R.T + center
+    # faces with outward counter-clockwise winding (corner index = x + 2y + 4z)
+    faces = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)]
+    tris, nrms = [], []
+    for f in faces:
+        p = corners[list(f)]
+        n = np.cross(p[1] - p[0], p[2] - p[0])
+        n /= np.linalg.norm(n)
+        for a, b, c2 in ((0, 1, 2), (0, 2, 3)):
+            tris.append([p[a], p[b], p[c2]])
+            nrms.append([n, n, n])
+    return np.array(tris), np.array(nrms)
+
+
+def make_scene_geometry(grid=256, box_count=64, seed=1234, extent=10.0, materials=3):
+    """Ground plane [-extent, extent]^2 at z = 0 with 2 * grid^2 triangles plus
+    `box_count` random boxes standing on it.  Returns positions, normals, uvs,
+    material indices."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-extent, extent, grid + 1)
+    X, Y = np.meshgrid(xs, xs, indexing="xy")
+    p00 = np.stack([X[:-1, :-1], Y[:-1, :-1], np.zeros((grid, grid))], -1)
+    p10 = np.stack([X[:-1, 1:], Y[:-1, 1:], np.zeros((grid, grid))], -1)
+    p01 = np.stack([X[1:, :-1], Y[1:, :-1], np.zeros((grid, grid))], -1)
+    p11 = np.stack([X[1:, 1:], Y[1:, 1:], np.zeros((grid, grid))], -1)
+    t0 = np.stack([p00, p10, p11], -2).reshape(-1, 3, 3)
+    t1 = np.stack([p00, p11, p01], -2).reshape(-1, 3, 3)
+    positions = [np.concatenate([t0, t1], 0)]
+    normals = [np.tile(np.array([0.0, 0.0, 1.0]), (2 * grid * grid, 3, 1))]
+    # material stripes on the ground echo the reference's "roughness planes" scene
+    stripe = ((positions[0][:, :, 1].mean(axis=1) + extent) / (2 * extent) * materials).astype(np.int64)
+    mats = [np.clip(stripe, 0, materials - 1)]
+    for b in range(box_count):
+        half = rng.uniform(0.15, 0.6, 3)
+        center = np.array([rng.uniform(-extent * 0.8, extent * 0.8), rng.uniform(-extent * 0.8, extent * 0.8), half[2]])
+        t, n = _box_triangles(center, half, rng.uniform(0, math.pi))
+        positions.append(t)
+        normals.append(n)
+        mats.append(np.full(len(t), b % materials))
+    positions = np.concatenate(positions, 0)
+    normals = np.concatenate(normals, 0)
+    mats = np.concatenate(mats, 0)
+    uvs = positions[:, :, :2] * 0.5
+    return positions, normals, uvs, mats
+
+
+# ---- .vkt constant textures --------------------------------------------------------
+
+def write_constant_vkt(path, rgba):
+    """1x1 RGBA32F texture (VkFormat 109)."""
+    payload = struct.pack("<ffff", *rgba)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiiiii", 0xBC1BC1, 1, 1, 1, 1, 109))
+        f.write(struct.pack("<Q", len(payload)))
+        f.write(struct.pack("<iiQQ", 1, 1, len(payload), 0))
+        f.write(payload)
+        f.write(struct.pack("<I", 0xE0FE0F))
+
+
+DEFAULT_MATERIALS = {
+    # name: (base colour, (occlusion, linear roughness, metalicity))
+    "rough_grey": ((0.8, 0.8, 0.8), (1.0, 0.7, 0.0)),
+    "glossy_red": ((0.7, 0.25, 0.2), (1.0, 0.35, 0.0)),
+    "brushed_metal": ((0.9, 0.8, 0.6), (1.0, 0.25, 1.0)),
+}
+
+
+def write_material_textures(directory, materials=None):
+    materials = materials or DEFAULT_MATERIALS
+    os.makedirs(directory, exist_ok=True)
+    for name, (base, spec) in materials.items():
+        write_constant_vkt(os.path.join(directory, name + "_BaseColor.vkt"), (*base, 1.0))
+        write_constant_vkt(os.path.join(directory, name + "_Specular.vkt"), (*spec, 1.0))
+        write_constant_vkt(os.path.join(directory, name + "_Normal.vkt"), (0.5, 0.5, 1.0, 1.0))
+    return list(materials.keys())
+
+
+# ---- LTC fit files ------------------------------------------------------------------
+
+def write_ltc_fits(directory, resolution=32, fresnel_count=51):
+    """Writes fit<i>.dat files with a smooth synthetic GGX-like fit.  NOT a real
+    LTC fit (those are downloads, reference README.md:9-13): the matrix is
+    diag-dominant with a lobe that narrows with roughness and tilts away from the
+    viewer at grazing angles, which is all the parity tests need.  File layout:
+    u64 resolution, then resolution^2 x (d0, d1, d2, d3, albedo) float32 with
+    index y * R + x, x = roughness axis, y = inclination axis."""
+    os.makedirs(directory, exist_ok=True)
+    R = resolution
+    x = (np.arange(R) / (R - 1)) ** 2          # roughness alpha (table axis is sqrt(alpha))
+    theta = np.arange(R) / (R - 1) * (0.5 * math.pi)
+    A, TH = np.meshgrid(np.maximum(x, 0.0064), theta, indexing="xy")
+    sin_t, cos_t = np.sin(TH), np.cos(TH)
+    # cosine -> shading matrix [[a, 0, b], [0, c, 0], [e, 0, 1]]; the file stores
+    # (d0, d1, d2, d3) = (a, e, c, b) (reference ltc_table.c:86-90 + ltc_utility.glsl:71-74)
+    a = A * (1.0 + 0.8 * sin_t ** 2) + 0.02
+    c = A * (1.0 + 0.2 * sin_t ** 2) + 0.02
+    b = -(1.0 - A) ** 2 * sin_t / np.maximum(cos_t, 0.25) * 0.6
+    e = 0.15 * A * sin_t
+    for i in range(fresnel_count):
+        f0 = i / max(fresnel_count - 1, 1)
+        fres = f0 + (1.0 - f0) * (1.0 - cos_t) ** 5
+        albedo = np.clip(fres * (1.0 - 0.35 * A), 0.0, 1.0)
+        data = np.stack([a, e, c, b, albedo], -1).astype(np.float32)
+        with open(os.path.join(directory, "fit%d.dat" % i), "wb") as f:
+            f.write(struct.pack("<Q", R))
+            f.write(data.tobytes())
+
+
+# ---- lights and cameras of the BASELINE configurations ---------------------------------
+
+def regular_polygon(n, radius=0.5, phase=0.0):
+    ang = phase + np.arange(n) * (2.0 * math.pi / n)
+    return np.stack([0.5 + radius * np.cos(ang), 0.5 + radius * np.sin(ang)], -1).astype(np.float32)
+
+
+def light_spec(vertices_plane, translation, rotation_angles, flux=(10.0, 10.0, 10.0), scaling=(1.0, 1.0)):
+    return {"vertices_plane_space": np.asarray(vertices_plane, np.float32), "translation": tuple(translation),
+            "rotation_angles": tuple(rotation_angles), "radiant_flux": tuple(flux), "scaling": tuple(scaling)}
+
+
+DEFAULT_CAMERA = {"position": (-3.0, -2.0, 1.65), "rotation_x": 0.43 * math.pi, "rotation_z": 1.3 * math.pi,
+                  "vertical_fov": 0.33 * math.pi, "near": 0.05, "far": 1.0e3}
+
+QUAD = [(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)]
+
+
+def config_lights(config):
+    """Light set-ups for BASELINE.json configs 1-4."""
+    pi = math.pi
+    if config == 1:
+        return [light_spec([(0, 0), (1, 0), (0, 1)], (-1.0, 0.5, 3.0), (pi, 0.0, 0.0), (10, 10, 10), (1.5, 1.5))]
+    if config == 2:
+        return [light_spec(regular_polygon(5), (-0.5, 1.0, 2.5), (0.85 * pi, 0.1, 0.3), (12, 11, 10), (1.6, 1.6))]
+    if config == 3:
+        out = []
+        for k, (tx, ty) in enumerate([(-1.5, 1.5), (1.5, 1.5), (-1.5, 4.0), (1.5, 4.0)]):
+            out.append(light_spec(QUAD, (tx, ty, 2.2 + 0.2 * k), (0.5 * pi + 0.45 * (k % 2) + 0.3, 0.0, 0.4 * k),
+                                  (6 + k, 6, 8 - k), (1.0, 0.8)))
+        return out
+    if config == 4:
+        out = []
+        rng = np.random.default_rng(77)
+        for k in range(8):
+            n = 3 + (k % 4)
+            out.append(light_spec(regular_polygon(n, 0.5, 0.2 * k),
+                                  (rng.uniform(-4, 4), rng.uniform(0, 7), rng.uniform(1.5, 3.5)),
+                                  (rng.uniform(0.6, 1.0) * pi, rng.uniform(-0.3, 0.3), rng.uniform(0, 2 * pi)),
+                                  tuple(rng.uniform(3, 9, 3)), (rng.uniform(0.7, 1.5), rng.uniform(0.7, 1.5))))
+        return out
+    raise ValueError("unknown config %r" % (config,))
+
+
+CONFIG_SETTINGS = {
+    # BASELINE.json configs; S = samples per technique per light
+    1: dict(width=512, height=512, sample_count=1, sampling_strategies="diffuse_only", mis_heuristic="balance",
+            polygon_technique="projected_solid_angle", trace_shadow_rays=False),
+    2: dict(width=1920, height=1080, sample_count=1, sampling_strategies="diffuse_ggx_mis", mis_heuristic="balance",
+            polygon_technique="projected_solid_angle", trace_shadow_rays=True),
+    3: dict(width=1920, height=1080, sample_count=4, sampling_strategies="diffuse_specular_mis", mis_heuristic="optimal_clamped",
+            polygon_technique="projected_solid_angle", trace_shadow_rays=True),
+    4: dict(width=3840, height=2160, sample_count=8, sampling_strategies="diffuse_specular_mis", mis_heuristic="optimal_clamped",
+            polygon_technique="projected_solid_angle", trace_shadow_rays=True),
+}
+
+
+def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51):
+    """Writes scene.vks, textures/, ltc/ below `directory` and returns the paths."""
+    os.makedirs(directory, exist_ok=True)
+    names = write_material_textures(os.path.join(directory, "textures"))
+    positions, normals, uvs, mats = make_scene_geometry(grid, box_count, seed, materials=len(names))
+    scene_path = os.path.join(directory, "scene.vks")
+    write_vks(scene_path, positions, normals, uvs, mats, names)
+    ltc_dir = os.path.join(directory, "ltc")
+    write_ltc_fits(ltc_dir, ltc_resolution, fresnel_count)
+    return {"scene": scene_path, "textures": os.path.join(directory, "textures"), "ltc": ltc_dir, "fresnel_count": fresnel_count}
