@@ -149,7 +149,9 @@ typedef struct shading_pass_s {
 	int32_t fast_math;
 	/*! timing of the last dispatch in milliseconds (HIP events on device->stream) */
 	float last_dispatch_ms;
-	void* timing_events[2];
+	/*! ring of HIP event pairs, one pair per render_shading_pass call */
+	void* timing_ring;
+	uint32_t timing_ring_size, timing_cursor;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
@@ -209,6 +211,10 @@ VKR_API int render_visibility_pass(application_t* app);
 VKR_API int render_shading_pass(application_t* app, void* out_radiance);
 /*! Number of pixels / floats of one rank's slab for the current schedule */
 VKR_API uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank);
+/*! Pixel (x, y) of every slot of rank `rank`'s slab (0xFFFFFFFF for padding), so a
+	host can scatter gathered slabs itself.  Returns the slot count; writes at most
+	`capacity` slots. */
+VKR_API uint64_t get_slab_pixel_coordinates(const application_t* app, uint32_t rank, uint32_t* out_xy, uint64_t capacity);
 /*! Scatters the all-gathered slabs (rank-major, each padded to
 	get_slab_pixel_count(app, 0) pixels) back into a row-major frame */
 VKR_API int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance);
@@ -223,6 +229,9 @@ VKR_API int upload_visibility(application_t* app, const uint32_t* host_primitive
 /*! GPU time of the last render_shading_pass launch in milliseconds, measured with
 	HIP events on the device's stream (blocks until the launch has finished) */
 VKR_API float get_last_dispatch_milliseconds(application_t* app);
+/*! Durations of the most recent `count` launches (oldest first, at most 256 are
+	kept).  Returns how many were written. */
+VKR_API uint32_t get_dispatch_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
 /*! Number of shadow rays the last render_shading_pass traced (0 when the variant
 	was built without counters) */
 VKR_API uint64_t get_last_ray_count(const application_t* app);

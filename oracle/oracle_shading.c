@@ -1087,7 +1087,11 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 						float ltc_density = evaluate_ltc_density(&ltc, ds, 1.0f);
 						v3 rb2 = radiance_visibility_brdf(ctx, NULL, NULL, m43_mul_transposed(&ltc.world_to_shading, ds), sd, light, 0, 1);
 						if (!(ds.z <= 0.0f || dc.z <= 0.0f))
-							result = add3(result, scale3(rb2, ds.z * ps.psa / ltc_density));
+							{
+							/* vec3 * float * float / float, evaluated left to right (:584) */
+							v3 t = scale3(scale3(rb2, ds.z), ps.psa);
+							result = add3(result, mk3(t.x / ltc_density, t.y / ltc_density, t.z / ltc_density));
+						}
 					}
 				}
 			}
@@ -1147,7 +1151,10 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 					float dens_s = evaluate_ltc_density(&ltc, ds, specular_albedo);
 					float density = (dens_d + dens_s) / (diffuse_weight + specular_weight);
 					v3 rb = radiance_visibility_brdf(ctx, &lambert, NULL, m43_mul_transposed(&ltc.world_to_shading, ds), sd, light, 1, 1);
-					if (!(ds.z <= 0.0f)) result = add3(result, scale3(rb, ds.z / density));
+					if (!(ds.z <= 0.0f)) {
+						v3 t = scale3(rb, ds.z);
+						result = add3(result, mk3(t.x / density, t.y / density, t.z / density));
+					}
 				}
 			}
 		}

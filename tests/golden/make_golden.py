@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from the REFERENCE ITSELF.
+
+Needs /root/reference (oracle/_ref is built from it: the reference's shader GLSL
+compiled as C++ and its polygonal_light.c / camera.c compiled unmodified), so it
+runs in the authoring container only.  The fixtures travel; the GPU box checks
+the oracle and the HIP kernels against them without the reference.
+
+  frames.npz     one small frame per reference shader variant: vec4 g_out_color of
+                 src/shaders/shading_pass.frag.glsl main() for every pixel
+  functions.npz  known-answer vectors of the sub-functions (clipping for every sign
+                 mask, projected-solid-angle prepare / sample / error, solid-angle
+                 sampling, BRDF, de-quantisation, kahan, fast atan, sRGB)
+  host.npz       update_polygonal_light, camera matrices, matrix_inverse,
+                 wang_random_number, half_to_float of the reference's C code
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import oracle  # noqa: E402
+from oracle import reference  # noqa: E402
+from vulkan_renderer_amd import renderer, synthetic  # noqa: E402
+
+import golden_cases  # noqa: E402
+
+
+def frames():
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        dataset = synthetic.write_dataset(d, **golden_cases.DATASET)
+        for case in golden_cases.FRAME_CASES:
+            hs, frame, name = golden_cases.build_frame(case, dataset)
+            image = reference.shade(name, frame)
+            out[case["key"]] = image
+            print("%-28s %-60s mean %.5f" % (case["key"], name, image[..., :3].mean()))
+            hs.close()
+    np.savez_compressed(os.path.join(HERE, "frames.npz"), **out)
+
+
+def functions():
+    rng = np.random.default_rng(2021)
+    out = {}
+    # -- clipping: every sign mask for 3..7 vertices, on random convex-ish fans --------
+    clip_in, clip_n, clip_out, clip_count = [], [], [], []
+    for n in range(3, 8):
+        name = golden_cases.capacity_variant(n)
+        for bits in range(1 << n):
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+            v = np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], -1) * rng.uniform(0.5, 2.0)
+            v[:, 2] = np.where([(bits >> i) & 1 for i in range(n)], rng.uniform(0.1, 1.0, n), -rng.uniform(0.1, 1.0, n))
+            v = v.astype(np.float32)
+            count, buf = reference.clip_polygon(name, v, n)
+            pad_in = np.zeros((8, 3), np.float32); pad_in[:n] = v
+            pad_out = np.zeros((8, 3), np.float32); pad_out[:buf.shape[0]] = buf
+            clip_in.append(pad_in); clip_n.append(n); clip_out.append(pad_out); clip_count.append(count)
+    out["clip_in"], out["clip_n"], out["clip_out"], out["clip_count"] = map(np.array, (clip_in, clip_n, clip_out, clip_count))
+    # -- projected solid angle: prepare / sample / error on clipped random polygons ------
+    P_in, P_n, P_state, P_u, P_dir, P_err = [], [], [], [], [], []
+    while len(P_in) < 600:
+        n = int(rng.integers(3, 8))
+        name = golden_cases.capacity_variant(n)
+        poly = golden_cases.random_polygon(rng, n)
+        count, buf = reference.clip_polygon(name, poly, n)
+        if count == 0:
+            continue
+        state = reference.psa_prepare(name, buf, count)
+        if not np.isfinite(state[48]) or state[48] <= 1e-5:
+            poly = poly[::-1].copy()
+            count, buf = reference.clip_polygon(name, poly, n)
+            if count == 0:
+                continue
+            state = reference.psa_prepare(name, buf, count)
+            if not np.isfinite(state[48]) or state[48] <= 1e-5:
+                continue
+        u = rng.uniform(0, 1, (4, 2)).astype(np.float32)
+        dirs = np.array([reference.psa_sample(name, state, float(a), float(b)) for a, b in u])
+        errs = np.array([reference.psa_error(name, state, float(a), float(b), dd) for (a, b), dd in zip(u, dirs)])
+        pad = np.zeros((8, 3), np.float32); pad[:buf.shape[0]] = buf
+        P_in.append(pad); P_n.append([n, count]); P_state.append(state); P_u.append(u); P_dir.append(dirs); P_err.append(errs)
+    out["psa_in"], out["psa_n"], out["psa_state"], out["psa_u"], out["psa_dir"], out["psa_err"] = map(np.array, (P_in, P_n, P_state, P_u, P_dir, P_err))
+    # -- solid angle sampling --------------------------------------------------------------
+    S_in, S_n, S_pos, S_u, S_dir, S_sa = [], [], [], [], [], []
+    sa_name = reference.variant_name(strategy=0, technique="solid_angle", lights=1, max_light_vertices=4, samples=1)
+    L = reference.shader(sa_name)
+    for _ in range(200):
+        n = int(rng.integers(3, 5))
+        poly = golden_cases.random_polygon(rng, n) + np.array([0, 0, 1.5], np.float32)
+        pos = rng.normal(size=3).astype(np.float32) * 0.3
+        buf = np.zeros((4, 3), np.float32); buf[:n] = poly
+        if n < 4:
+            buf[n] = poly[0]
+        u = rng.uniform(0, 1, 2).astype(np.float32)
+        d = np.zeros(3, np.float32)
+        sa = L.ref_solid_angle_sample(n, buf.ctypes.data_as(C.POINTER(C.c_float)), pos.ctypes.data_as(C.POINTER(C.c_float)), float(u[0]), float(u[1]), d.ctypes.data_as(C.POINTER(C.c_float)))
+        S_in.append(buf); S_n.append(n); S_pos.append(pos); S_u.append(u); S_dir.append(d); S_sa.append(sa)
+    out["sa_in"], out["sa_n"], out["sa_pos"], out["sa_u"], out["sa_dir"], out["sa_value"] = map(np.array, (S_in, S_n, S_pos, S_u, S_dir, S_sa))
+    # -- scalar helpers ---------------------------------------------------------------------
+    any_name = golden_cases.capacity_variant(3)
+    L = reference.shader(any_name)
+    xs = np.concatenate([rng.normal(size=500) * 3, rng.normal(size=200) * 1e3, [0.0, 1.0, -1.0, 1e-8, -1e-8, 1e9]]).astype(np.float32)
+    out["atan_x"] = xs
+    out["atan_fast"] = np.array([L.ref_fast_positive_atan(float(x)) for x in xs], np.float32)
+    k = (rng.normal(size=(400, 4)) * np.exp(rng.uniform(-8, 8, (400, 1)))).astype(np.float32)
+    k[:100, 2:] = k[:100, :2] * (1 + rng.normal(size=(100, 2)) * 1e-6).astype(np.float32)  # cancellation cases
+    out["kahan_in"] = k
+    out["kahan_out"] = np.array([L.ref_kahan(*map(float, r)) for r in k], np.float32)
+    q = rng.integers(0, 2 ** 32, (300, 2), dtype=np.uint64).astype(np.uint32)
+    fac, summ = np.array([3e-5, 2e-5, 1e-5], np.float32), np.array([-10.0, -10.0, 0.0], np.float32)
+    pos_out = np.zeros((300, 3), np.float32)
+    fp = C.POINTER(C.c_float)
+    for i in range(300):
+        L.ref_decode_position(int(q[i, 0]), int(q[i, 1]), fac.ctypes.data_as(fp), summ.ctypes.data_as(fp), pos_out[i].ctypes.data_as(fp))
+    out["position_q"], out["position_factor"], out["position_summand"], out["position_out"] = q, fac, summ, pos_out
+    nq = rng.integers(0, 65536, (300, 2)).astype(np.uint16)
+    nq[:4] = [[0, 0], [65535, 65535], [32768, 32768], [1, 65535]]
+    n_out = np.zeros((300, 3), np.float32)
+    for i in range(300):
+        L.ref_decode_normal(int(nq[i, 0]), int(nq[i, 1]), n_out[i].ctypes.data_as(fp))
+    out["normal_q"], out["normal_out"] = nq, n_out
+    # BRDF
+    sd = np.zeros((300, 17), np.float32)
+    wi = np.zeros((300, 3), np.float32)
+    brdf = np.zeros((300, 4, 3), np.float32)
+    for i in range(300):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        o = rng.normal(size=3); o /= np.linalg.norm(o)
+        if np.dot(n, o) < 0: o = -o
+        w = rng.normal(size=3); w /= np.linalg.norm(w)
+        if np.dot(n, w) < 0: w = -w
+        sd[i, 0:3] = rng.normal(size=3); sd[i, 3:6] = n; sd[i, 6:9] = o; sd[i, 9] = np.float32(np.dot(n.astype(np.float32), o.astype(np.float32)))
+        sd[i, 10:13] = rng.uniform(0, 1, 3); sd[i, 13:16] = rng.uniform(0, 1, 3); sd[i, 16] = rng.uniform(0.0064, 1)
+        wi[i] = w
+        for j, (dif, spec) in enumerate([(1, 1), (1, 0), (0, 1), (0, 0)]):
+            L.ref_evaluate_brdf(sd[i].ctypes.data_as(fp), wi[i].ctypes.data_as(fp), dif, spec, brdf[i, j].ctypes.data_as(fp))
+    out["brdf_sd"], out["brdf_wi"], out["brdf_out"] = sd, wi, brdf
+    lin = np.concatenate([np.linspace(-0.1, 1.1, 121), [0.0031308, 0.003, 0.0032]]).astype(np.float32)
+    srgb = np.zeros((len(lin), 2), np.float32)
+    for i, v in enumerate(lin):
+        a, b = C.c_float(), C.c_float()
+        L.ref_srgb(float(v), C.byref(a), C.byref(b))
+        srgb[i] = (a.value, b.value)
+    out["srgb_in"], out["srgb_out"] = lin, srgb
+    np.savez_compressed(os.path.join(HERE, "functions.npz"), **out)
+    print("functions.npz: %d arrays" % len(out))
+
+
+def host():
+    from vulkan_renderer_amd import capi
+    H = reference.host()
+    rng = np.random.default_rng(7)
+    out = {}
+    # update_polygonal_light of the reference (same struct layout as the product's mirror)
+    lights_in, lights_out = [], []
+    for i in range(40):
+        n = int(rng.integers(3, 8))
+        light = capi.PolygonalLight()
+        light.rotation_angles[:] = rng.uniform(-np.pi, np.pi, 3)
+        light.translation[:] = rng.normal(size=3) * 3
+        light.radiant_flux[:] = rng.uniform(0.1, 20, 3)
+        light.scaling_x, light.scaling_y = rng.uniform(0.2, 3, 2)
+        H.set_polygonal_light_vertex_count(C.byref(light), n)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        if i % 3 == 0:
+            ang = ang[::-1]  # clockwise winding flips the plane
+        pts = np.stack([0.5 + 0.5 * np.cos(ang), 0.5 + 0.5 * np.sin(ang)], -1).astype(np.float32)
+        for j in range(n):
+            light.vertices_plane_space[4 * j], light.vertices_plane_space[4 * j + 1] = float(pts[j, 0]), float(pts[j, 1])
+        lights_in.append(np.concatenate([np.array(light.rotation_angles[:] + light.translation[:] + light.radiant_flux[:] + [light.scaling_x, light.scaling_y], np.float32), [n], pts.ravel(), np.zeros(14 - 2 * n)]).astype(np.float32))
+        H.update_polygonal_light(C.byref(light))
+        fixed = np.frombuffer(C.string_at(C.addressof(light), 160), np.uint8).copy()
+        world = np.ctypeslib.as_array(light.vertices_world_space, (4 * n,)).copy()
+        fan = np.ctypeslib.as_array(light.fan_areas, (4 * (n - 2),)).copy()
+        rec = np.zeros(160 + 4 * (28 + 20), np.uint8)
+        rec[:160] = fixed
+        rec[160:160 + 16 * n] = world.view(np.uint8)
+        rec[160 + 112:160 + 112 + 16 * (n - 2)] = fan.view(np.uint8)
+        lights_out.append(rec)
+        H.destroy_polygonal_light(C.byref(light))
+    out["light_in"], out["light_out"] = np.array(lights_in), np.array(lights_out)
+    # camera matrices
+    cams, mats = [], []
+    M = (C.c_float * 4) * 4
+    for i in range(20):
+        cam = capi.Camera()
+        cam.position_world_space[:] = rng.normal(size=3) * 5
+        cam.rotation_x, cam.rotation_z = rng.uniform(0, np.pi), rng.uniform(0, 2 * np.pi)
+        cam.vertical_fov, cam.near, cam.far = rng.uniform(0.3, 1.5), 0.05, 1000.0
+        aspect = float(rng.uniform(0.5, 2.5))
+        w2v, v2p, w2p = M(), M(), M()
+        H.get_world_to_view_space(w2v, C.byref(cam))
+        H.get_view_to_projection_space(v2p, C.byref(cam), C.c_float(aspect))
+        H.get_world_to_projection_space(w2p, C.byref(cam), C.c_float(aspect))
+        inv = M()
+        H.ref_matrix_inverse(inv, w2p)
+        cams.append([*cam.position_world_space[:], cam.rotation_x, cam.rotation_z, cam.vertical_fov, cam.near, cam.far, aspect])
+        mats.append(np.stack([np.array(w2v), np.array(v2p), np.array(w2p), np.array(inv)]))
+    out["camera_in"], out["camera_out"] = np.array(cams, np.float32), np.array(mats, np.float32)
+    seeds = np.concatenate([np.arange(64), rng.integers(0, 2 ** 32, 192, dtype=np.uint64)]).astype(np.uint32)
+    out["wang_in"] = seeds
+    out["wang_out"] = np.array([H.ref_wang_random_number(int(s)) for s in seeds], np.uint32)
+    halves = np.concatenate([np.arange(0, 65536, 257), [0x7C00, 0xFC00, 0x0001, 0x8001, 0x3C00]]).astype(np.uint16)
+    out["half_in"] = halves
+    out["half_out"] = np.array([H.ref_half_to_float(int(h)) for h in halves], np.float32)
+    np.savez_compressed(os.path.join(HERE, "host.npz"), **out)
+    print("host.npz: %d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    if not reference.available():
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
+    frames()
+    functions()
+    host()

@@ -126,7 +126,7 @@ class TileSchedule(C.Structure):
 class ShadingPass(C.Structure):
     _fields_ = [("use_ray_tracing", C.c_uint32), ("variant", C.c_int32), ("max_polygon_vertex_count", C.c_uint32),
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t),
-                ("fast_math", C.c_int32), ("last_dispatch_ms", C.c_float), ("timing_events", C.c_void_p * 2)]
+                ("fast_math", C.c_int32), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32)]
 
 
 class Application(C.Structure):
@@ -186,6 +186,8 @@ SIGNATURES = {
     "upload_visibility": (C.c_int, [P(Application), C.c_void_p]),
     "get_last_dispatch_milliseconds": (C.c_float, [P(Application)]),
     "get_last_ray_count": (C.c_uint64, [P(Application)]),
+    "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
+    "get_slab_pixel_coordinates": (C.c_uint64, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
     "get_abi_struct_sizes": (C.c_uint32, [P(C.c_uint64), C.c_uint32]),
 }
 

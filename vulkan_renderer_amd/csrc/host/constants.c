@@ -260,3 +260,31 @@ VKR_API uint32_t get_abi_struct_sizes(uint64_t* sizes, uint32_t capacity) {
 	for (uint32_t i = 0; i != count && i != capacity; ++i) sizes[i] = all[i];
 	return count;
 }
+
+/* Host-side description of the slab layout that render_shading_pass() writes for
+   app->tile_schedule with the given rank: pixel (x, y) of every slab slot, or
+   0xFFFFFFFF twice for padding slots.  Same arithmetic as locate_pixel() in
+   csrc/shading_kernel.h; lets hosts (and the CPU tests of the multi-process path)
+   scatter gathered slabs without touching a GPU. */
+VKR_API uint64_t get_slab_pixel_coordinates(const application_t* app, uint32_t rank, uint32_t* out_xy, uint64_t capacity) {
+	uint32_t width = app->swapchain.extent.width, height = app->swapchain.extent.height;
+	uint32_t rank_count = app->tile_schedule.rank_count > 1 ? app->tile_schedule.rank_count : 1;
+	uint32_t tile_size = app->tile_schedule.tile_size < 16 ? 16 : app->tile_schedule.tile_size;
+	tile_size = (tile_size + 15) & ~15u;
+	if (rank_count == 1) rank = 0;
+	uint32_t tiles_x = (width + tile_size - 1) / tile_size, tiles_y = (height + tile_size - 1) / tile_size;
+	uint32_t tile_count = tiles_x * tiles_y;
+	uint32_t own_tiles = (tile_count + rank_count - 1 - rank) / rank_count;
+	uint64_t slots = (uint64_t) own_tiles * tile_size * tile_size;
+	for (uint64_t s = 0; s != slots && s != capacity; ++s) {
+		uint32_t local_tile = (uint32_t) (s / ((uint64_t) tile_size * tile_size));
+		uint32_t within = (uint32_t) (s % ((uint64_t) tile_size * tile_size));
+		uint32_t tile = local_tile * rank_count + rank;
+		uint32_t px = (tile % tiles_x) * tile_size + within % tile_size;
+		uint32_t py = (tile / tiles_x) * tile_size + within / tile_size;
+		int valid = tile < tile_count && px < width && py < height;
+		out_xy[2 * s + 0] = valid ? px : 0xFFFFFFFFu;
+		out_xy[2 * s + 1] = valid ? py : 0xFFFFFFFFu;
+	}
+	return slots;
+}

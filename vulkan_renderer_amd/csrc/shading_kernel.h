@@ -570,7 +570,10 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 						float ltc_density = evaluate_ltc_density(ltc_in, ds, 1.0f);
 						f3 rb2 = radiance_visibility_brdf<RAYS, false, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
 						if (!(ds.z <= 0.0f || dc.z <= 0.0f))
-							result = result + rb2 * divide(ds.z * ps.total, ltc_density);
+							{
+							f3 t = (rb2 * ds.z) * ps.total;
+							result = result + mk3(divide(t.x, ltc_density), divide(t.y, ltc_density), divide(t.z, ltc_density));
+						}
 					}
 				}
 			}
@@ -631,7 +634,10 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					float density = divide(dens_d + dens_s, diffuse_weight + specular_weight);
 					bool visibility;
 					f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
-					if (!(ds.z <= 0.0f)) result = result + rb * divide(ds.z, density);
+					if (!(ds.z <= 0.0f)) {
+						f3 t = rb * ds.z;
+						result = result + mk3(divide(t.x, density), divide(t.y, density), divide(t.z, density));
+					}
 				}
 			}
 		}

@@ -77,8 +77,11 @@ static unsigned long long* g_ray_counter = NULL;
 extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
 	vkr_device_free(pass->constants_device, device);
 	vkr_host_free_pinned(pass->constants_host);
-	if (pass->timing_events[0]) (void) hipEventDestroy((hipEvent_t) pass->timing_events[0]);
-	if (pass->timing_events[1]) (void) hipEventDestroy((hipEvent_t) pass->timing_events[1]);
+	if (pass->timing_ring) {
+		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
+		for (uint32_t i = 0; i != 2 * pass->timing_ring_size; ++i) if (ring[i]) (void) hipEventDestroy(ring[i]);
+		free(ring);
+	}
 	memset(pass, 0, sizeof(*pass));
 }
 
@@ -132,6 +135,15 @@ static int validate_settings(const application_t* app) {
 	return 0;
 }
 
+static int create_timing_ring(shading_pass_t* pass) {
+	pass->timing_ring_size = 256;
+	hipEvent_t* ring = (hipEvent_t*) calloc(2 * pass->timing_ring_size, sizeof(hipEvent_t));
+	pass->timing_ring = ring;
+	for (uint32_t i = 0; i != 2 * pass->timing_ring_size; ++i)
+		if (hip_failed(hipEventCreate(&ring[i]), "creating timing events")) return 1;
+	return 0;
+}
+
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	int32_t fast_math = pass->fast_math;
 	memset(pass, 0, sizeof(*pass));
@@ -147,8 +159,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	pass->constants_size = get_constant_buffer_size(app);
 	if (vkr_device_alloc(&pass->constants_device, device, pass->constants_size, "the constant buffer")
 		|| vkr_host_alloc_pinned(&pass->constants_host, pass->constants_size)
-		|| hip_failed(hipEventCreate((hipEvent_t*) &pass->timing_events[0]), "creating timing events")
-		|| hip_failed(hipEventCreate((hipEvent_t*) &pass->timing_events[1]), "creating timing events"))
+		|| create_timing_ring(pass))
 	{
 		printf("Failed to create the shading pass.\n");
 		destroy_shading_pass(pass, device);
@@ -248,9 +259,12 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
 	bool is_clipped = technique != kTechniqueSolidAngle;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
-	(void) hipEventRecord((hipEvent_t) pass->timing_events[0], stream);
+	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
+	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
+	(void) hipEventRecord(ring[2 * slot], stream);
 	int status = g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, pass->use_ray_tracing ? 1 : 0, &p, grid_blocks, stream);
-	(void) hipEventRecord((hipEvent_t) pass->timing_events[1], stream);
+	(void) hipEventRecord(ring[2 * slot + 1], stream);
+	++pass->timing_cursor;
 	if (status < 0) {
 		printf("No kernel variant was built for strategy %d, technique %d, vertex capacity %d.\n", strategy, technique, capacity);
 		return 1;
@@ -262,13 +276,25 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	return 0;
 }
 
-extern "C" float get_last_dispatch_milliseconds(application_t* app) {
+extern "C" uint32_t get_dispatch_milliseconds(application_t* app, float* out, uint32_t count) {
 	shading_pass_t* pass = &app->shading_pass;
+	if (!pass->timing_ring) return 0;
+	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
+	uint32_t available = pass->timing_cursor < pass->timing_ring_size ? pass->timing_cursor : pass->timing_ring_size;
+	if (count > available) count = available;
+	for (uint32_t i = 0; i != count; ++i) {
+		uint32_t slot = (pass->timing_cursor - count + i) % pass->timing_ring_size;
+		float ms = 0.0f;
+		if (hipEventSynchronize(ring[2 * slot + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1]) != hipSuccess) ms = 0.0f;
+		out[i] = ms;
+	}
+	return count;
+}
+
+extern "C" float get_last_dispatch_milliseconds(application_t* app) {
 	float ms = 0.0f;
-	if (!pass->timing_events[0]) return 0.0f;
-	if (hipEventSynchronize((hipEvent_t) pass->timing_events[1]) != hipSuccess) return 0.0f;
-	if (hipEventElapsedTime(&ms, (hipEvent_t) pass->timing_events[0], (hipEvent_t) pass->timing_events[1]) != hipSuccess) return 0.0f;
-	pass->last_dispatch_ms = ms;
+	if (get_dispatch_milliseconds(app, &ms, 1) != 1) return 0.0f;
+	app->shading_pass.last_dispatch_ms = ms;
 	return ms;
 }
 

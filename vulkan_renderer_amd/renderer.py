@@ -211,6 +211,11 @@ class Renderer(HostScene):
     def last_ms(self):
         return float(self.lib.get_last_dispatch_milliseconds(C.byref(self.app)))
 
+    def dispatch_ms(self, count):
+        out = (C.c_float * count)()
+        n = self.lib.get_dispatch_milliseconds(C.byref(self.app), out, count)
+        return [float(out[i]) for i in range(n)]
+
     def last_ray_count(self):
         return int(self.lib.get_last_ray_count(C.byref(self.app)))
 
