@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Benchmark of the shading pass (BASELINE.json: Msamples/s = pixels x spp / s).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the shading kernel over one frame: write_constants ->
+upload -> one launch over the rank's tiles (+ for N > 1 an RCCL all-gather of the
+tile slabs over xGMI and the scatter back into a frame).  Inputs (scene, LBVH,
+LTC and noise tables, visibility buffer) are resident in HBM before the timed
+region; data is synthetic (seeded generators, vulkan_renderer_amd/synthetic.py).
+
+N = 1 runs BASELINE config 2 (1920x1080, 1 spp, one pentagon light, GGX MIS with
+projected-solid-angle sampling, LBVH shadow rays) unless --config says otherwise.
+For N > 1 the scaling is weak: the frame grows to 1920 x (1080 N) pixels, tiles
+are dealt round-robin to the ranks, so every GPU shades one 1080p frame worth of
+pixels per step.
+
+PyTorch is plumbing here: device selection, the stream, torch.distributed.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_pixel(light_count, sample_count, techniques):
+    """visibility id + 3 vertices (positions, normals/uv) + material id
+    + 4 LTC texels + noise texels + RGBA32F out."""
+    noise_fetches = math.ceil(light_count * sample_count * techniques / 2)
+    return 4 + 49 + 48 + 8 * noise_fetches + 16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4])
+    ap.add_argument("--mode", default="exact", choices=["fast", "exact"],
+                    help="exact: IEEE arithmetic, bit-identical to the CPU oracle (default; it is as fast); fast: approximate reciprocals + contraction")
+    ap.add_argument("--tile-size", type=int, default=32)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from vulkan_renderer_amd import renderer, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1 or args.force_distributed
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the shading pass")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    config = args.config
+    settings = dict(synthetic.CONFIG_SETTINGS[config])
+    width = args.width or settings["width"]
+    height_per_gpu = args.height or settings["height"]
+    height = height_per_gpu * world
+    if args.spp:
+        settings["sample_count"] = args.spp
+    sample_count = settings["sample_count"]
+
+    tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % rank)
+    dataset = synthetic.write_dataset(tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51)
+    stream = torch.cuda.current_stream()
+    r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"))
+    renderer.setup_config(r, config, dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=True)
+    r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.sync()
+    light_count = r.app.scene_specification.polygonal_light_count
+    techniques = 1 if settings["sampling_strategies"] == "diffuse_only" else 2
+
+    if distributed:
+        slab_pixels = r.slab_pixel_count(0)
+        slab = torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world, slab_pixels, 4), dtype=torch.float32, device="cuda")
+        frame = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+
+        def step():
+            r.render(slab.data_ptr())
+            dist.all_gather_into_tensor(gathered, slab)
+            r.assemble(gathered.data_ptr(), frame.data_ptr())
+    else:
+        def step():
+            r.render()
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_pixels = width * height
+    value = total_pixels * sample_count / (elapsed / args.steps) / 1e6
+
+    # ---- roofline of the shading kernel, from HIP events recorded inside the timed region --------
+    kernel_ms = r.dispatch_ms(min(args.steps, 256))
+    kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    visibility = r.read_visibility()
+    own_pixels = r.slab_pixel_count(rank) if distributed else total_pixels
+    if distributed:
+        # shaded fraction of the pixels this rank owns
+        import ctypes as C
+        xy = np.zeros((own_pixels, 2), np.uint32)
+        slots = r.lib.get_slab_pixel_coordinates(C.byref(r.app), rank, xy.ctypes.data, own_pixels)
+        valid = xy[:slots, 0] != 0xFFFFFFFF
+        own_visibility = visibility[xy[:slots][valid, 1], xy[:slots][valid, 0]]
+    else:
+        own_visibility = visibility.ravel()
+    shaded = int((own_visibility != 0xFFFFFFFF).sum())
+    background = int(own_visibility.size - shaded)
+    bytes_per_launch = shaded * algorithmic_bytes_per_pixel(light_count, sample_count, techniques) + background * 20
+    achieved = bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            entry = json.load(open(pmc_path)).get("config%d_%s" % (config, args.mode))
+            if entry and world == 1 and width == entry.get("width") and height == entry.get("height"):
+                traffic = entry["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    rays = r.last_ray_count()
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                "kernel_ms": round(kernel_avg_ms, 4), "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count,
+                                                                   int(r.app.shading_pass.use_ray_tracing), args.mode),
+                "note": "compute-bound pass: FP32 VALU + transcendental issue and BVH latency limit it, not HBM (SURVEY.md 8d)"}
+
+    # ---- CPU baseline and parity on a bounded sample (rank 0, N = 1 only) ------------------------
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        gpu_image = r.read_radiance()
+        inputs = r.host_inputs(visibility)
+        bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
+        frame_o = oracle.make_frame(inputs, r.oracle_settings(), bvh)
+        cores = os.cpu_count() or 1
+        # calibrate on 8 rows in the middle, then spread bands over the frame for ~12 s of CPU time
+        mid = height // 2
+        # exact mode is compared with the oracle's matching polynomial math (bit-comparable),
+        # fast mode with the libm oracle
+        oracle.set_math_mode(1 if args.mode == "exact" else 0)
+        oracle.shade(frame_o, mid, mid + 24)
+        t = time.perf_counter()
+        oracle.shade(frame_o, mid, mid + 24)
+        per_row = max((time.perf_counter() - t) / 24, 1e-6)
+        rows_budget = int(min(height, max(16, 12.0 / per_row)))
+        band = 24
+        bands = max(1, rows_budget // band)
+        starts = [int(i * (height - band) / max(bands - 1, 1)) for i in range(bands)]
+        starts = sorted(set(starts))
+        cpu_time = 0.0
+        sq, cnt, worst, nan = 0.0, 0, 0.0, int(np.isnan(gpu_image).sum())
+        flipped, sq_without_flips, mismatched = 0, 0.0, 0
+        for y0 in starts:
+            t = time.perf_counter()
+            cpu = oracle.shade(frame_o, y0, y0 + band)
+            cpu_time += time.perf_counter() - t
+            d = gpu_image[y0:y0 + band, :, :3].astype(np.float64) - cpu[y0:y0 + band, :, :3]
+            sq += float((d ** 2).sum())
+            cnt += d.size
+            worst = max(worst, float(np.abs(d).max()))
+            per_pixel = np.abs(d).max(axis=-1)
+            flipped += int((per_pixel > 1e-2).sum())
+            mismatched += int((per_pixel > 0).sum())
+            sq_without_flips += float((d[per_pixel <= 1e-2] ** 2).sum())
+        sample_pixels = len(starts) * band * width
+        cpu_baseline = {"value": round(sample_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                        "kind": "port", "sample": "%d bands of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP, libm)" % (len(starts), band, sample_pixels, total_pixels)}
+        oracle.set_math_mode(0)
+        parity = {"rmse_vs_oracle": math.sqrt(sq / max(cnt, 1)), "max_abs": worst, "nan": nan, "tolerance_rmse": 1e-4,
+                  "sample_pixels": sample_pixels, "pixels_differing": mismatched, "pixels_over_1e-2": flipped,
+                  "rmse_without_those": math.sqrt(sq_without_flips / max(cnt, 1)),
+                  "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
+
+    if rank == 0:
+        result = {
+            "metric": "Msamples/s (pixels x spp / s), shading pass", "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: %dx%d, %d spp per technique, %d polygonal light(s), %s + %s, %s, %s arithmetic"
+                                   % (config, width, height, sample_count, light_count, settings["sampling_strategies"],
+                                      settings["polygon_technique"], "LBVH shadow rays" if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
+                       "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
+                       "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, " + RCCL all-gather" if distributed else ""),
+                       "scene_triangles": int(r.app.scene.mesh.triangle_count)},
+            "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (kernel_avg_ms * 1e-3) / 1e6, 2) if rays else 0.0,
+            "roofline": roofline,
+        }
+        if cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline
+            result["speedup_vs_cpu"] = round(value / cpu_baseline["value"], 1)
+        if parity:
+            result["parity"] = parity
+        print(json.dumps(result))
+    r.close()
+    if distributed:
+        dist.destroy_process_group()
+    tmp.cleanup()
+
+
+if __name__ == "__main__":
+    main()

@@ -1233,11 +1233,15 @@ void oracle_shade_rows(const oracle_frame_t* frame, float* out_rgba, uint32_t y0
 	if (thread_count > 0) omp_set_num_threads(thread_count);
 #endif
 	(void) thread_count;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays)
-	for (int64_t y = y0; y < (int64_t) y1; ++y) {
+	/* chunks of 64 consecutive pixels so that even a few rows keep every core busy */
+	int64_t first = (int64_t) y0 * frame->width, last = (int64_t) y1 * frame->width;
+	int64_t chunks = (last - first + 63) / 64;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays)
+	for (int64_t c = 0; c < chunks; ++c) {
 		pixel_ctx_t ctx = {frame, &k, 0};
-		for (uint32_t x = 0; x != frame->width; ++x)
-			shade_pixel(&ctx, x, (uint32_t) y, out_rgba + 4 * ((size_t) y * frame->width + x));
+		int64_t end = first + (c + 1) * 64 < last ? first + (c + 1) * 64 : last;
+		for (int64_t i = first + c * 64; i < end; ++i)
+			shade_pixel(&ctx, (uint32_t) (i % frame->width), (uint32_t) (i / frame->width), out_rgba + 4 * (size_t) i);
 		rays += ctx.rays;
 	}
 	g_ray_count = rays;

@@ -37,3 +37,40 @@ def compare(gpu, cpu):
         "nan": int(np.isnan(gpu).sum()),
         "bit_exact": bool(np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))),
     }
+
+
+class DeviceBuffer:
+    """Plain HIP device memory through ctypes on the HIP runtime that
+    libvkr_shading.so already loaded (keeps torch out of the GPU tests)."""
+    import ctypes as _C
+    _hip = None
+
+    def __init__(self, nbytes):
+        C = self._C
+        if DeviceBuffer._hip is None:
+            DeviceBuffer._hip = C.CDLL("libamdhip64.so")
+        self.nbytes = nbytes
+        self.ptr = C.c_void_p()
+        assert DeviceBuffer._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+        assert DeviceBuffer._hip.hipMemset(self.ptr, 0, C.c_size_t(nbytes)) == 0
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        assert DeviceBuffer._hip.hipMemcpy(self.ptr, self._C.c_void_p(a.ctypes.data), self._C.c_size_t(a.nbytes), 1) == 0
+
+    def download(self, shape, dtype):
+        out = np.zeros(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        assert DeviceBuffer._hip.hipDeviceSynchronize() == 0
+        assert DeviceBuffer._hip.hipMemcpy(self._C.c_void_p(out.ctypes.data), self.ptr, self._C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def zero(self):
+        assert DeviceBuffer._hip.hipMemset(self.ptr, 0, self._C.c_size_t(self.nbytes)) == 0
+        assert DeviceBuffer._hip.hipDeviceSynchronize() == 0
+
+    def free(self):
+        if self.ptr:
+            DeviceBuffer._hip.hipFree(self.ptr)
+            self.ptr = None

@@ -1,0 +1,139 @@
+"""The HIP shading pass against (a) the golden frames rendered by the reference's
+own shader and (b) the CPU oracle, through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases
+from helpers import DeviceBuffer, compare, oracle_render
+from vulkan_renderer_amd import renderer
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# stated tolerance of BASELINE.json: RMSE <= 1e-4 on exposure-scaled linear radiance
+RMSE_TOLERANCE = 1.0e-4
+
+
+@pytest.fixture(scope="module")
+def golden_dataset(tmp_path_factory):
+    from vulkan_renderer_amd import synthetic
+    return synthetic.write_dataset(str(tmp_path_factory.mktemp("golden_dataset")), **golden_cases.DATASET)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    return np.load(os.path.join(GOLDEN, "frames.npz"))
+
+
+def render_case(case, dataset, fast_math, width=golden_cases.WIDTH, height=golden_cases.HEIGHT):
+    r = renderer.Renderer(fast_math=fast_math)
+    golden_cases.apply_case(r, case, dataset, width, height)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.render()
+    return r, r.read_radiance()
+
+
+LINEAR_CASES = [c for c in golden_cases.FRAME_CASES if c.get("output_linear_rgb", True)]
+
+
+@pytest.mark.parametrize("case", LINEAR_CASES, ids=[c["key"] for c in LINEAR_CASES])
+@pytest.mark.parametrize("fast_math", [False, True], ids=["exact", "fast"])
+def test_golden_frames_of_the_reference_shader(case, fast_math, golden_dataset, frames):
+    """The golden frames were computed with libm transcendentals; the kernels use
+    their own polynomials, so the comparison is by tolerance, not by bits."""
+    r, image = render_case(case, golden_dataset, fast_math)
+    r.close()
+    stats = compare(image, frames[case["key"]])
+    print(case["key"], "fast" if fast_math else "exact", stats)
+    assert stats["nan"] == 0
+    assert stats["rmse"] <= RMSE_TOLERANCE, stats
+    assert stats["max_abs"] <= 2.0e-3, stats
+
+
+@pytest.mark.parametrize("case", LINEAR_CASES, ids=[c["key"] for c in LINEAR_CASES])
+def test_exact_mode_equals_oracle_bit_for_bit(case, golden_dataset):
+    r, image = render_case(case, golden_dataset, False, 96, 64)
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+    r.close()
+    stats = compare(image, cpu)
+    assert stats["bit_exact"], stats
+
+
+def test_srgb_and_half_encodings(golden_dataset, frames):
+    import oracle
+    case = golden_cases.FRAME_CASES[0]
+    r, image = render_case(case, golden_dataset, False)
+    srgb = r.read_encoded(output_linear_rgb=False, frame_bits=0)
+    low = r.read_encoded(output_linear_rgb=False, frame_bits=1)
+    high = r.read_encoded(output_linear_rgb=True, frame_bits=2)
+    r.close()
+    # the sRGB frame of the reference shader (variant with OUTPUT_LINEAR_RGB=0), stored as UNORM8
+    expected = (np.clip(frames["cfg1_srgb_encoded"], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert np.abs(srgb[..., :3].astype(int) - expected[..., :3].astype(int)).max() <= 1
+    assert (srgb[..., :3] != expected[..., :3]).mean() < 0.01
+    assert np.array_equal(low, oracle.encode_half_bits(image, 1, False))
+    assert np.array_equal(high, oracle.encode_half_bits(image, 2, True))
+    # reassembling the two bytes gives the half-float image (reference main.c:1700-1710)
+    halves = (high[..., :3].astype(np.uint16) << 8) | low[..., :3].astype(np.uint16)
+    assert np.allclose(halves.view(np.float16).astype(np.float32), image[..., :3], rtol=1e-3, atol=1e-4)
+
+
+def test_tiles_of_virtual_ranks_reassemble_bit_exactly(golden_dataset):
+    """Multi-GPU layout on one GPU: render every rank's slab, gather, scatter back."""
+    import ctypes as C
+    case = golden_cases.FRAME_CASES[3]
+    r, full = render_case(case, golden_dataset, False, 200, 120)  # not a multiple of the tile size
+    lib = r.lib
+    for tile_size, ranks in ((16, 2), (32, 3), (64, 8)):
+        r.set_tiles(tile_size, 0, ranks)
+        slab_pixels = r.slab_pixel_count(0)
+        gathered = np.zeros((ranks, slab_pixels, 4), np.float32)
+        dev = DeviceBuffer(slab_pixels * 16)
+        for rank in range(ranks):
+            r.set_tiles(tile_size, rank, ranks)
+            dev.zero()
+            r.render(dev.ptr.value)
+            r.sync()
+            gathered[rank] = dev.download((slab_pixels, 4), np.float32)
+        # host-side scatter using the library's own slab description
+        out = np.zeros_like(full)
+        for rank in range(ranks):
+            r.set_tiles(tile_size, rank, ranks)
+            xy = np.zeros((slab_pixels, 2), np.uint32)
+            slots = lib.get_slab_pixel_coordinates(C.byref(r.app), rank, xy.ctypes.data, slab_pixels)
+            valid = xy[:slots, 0] != 0xFFFFFFFF
+            out[xy[:slots][valid, 1], xy[:slots][valid, 0]] = gathered[rank, :slots][valid]
+        assert np.array_equal(out.view(np.uint32), full.view(np.uint32)), (tile_size, ranks)
+        # device-side scatter
+        all_slabs = DeviceBuffer(gathered.nbytes)
+        all_slabs.upload(gathered)
+        frame = DeviceBuffer(120 * 200 * 16)
+        r.set_tiles(tile_size, 0, ranks)
+        r.assemble(all_slabs.ptr.value, frame.ptr.value)
+        r.sync()
+        assert np.array_equal(frame.download((120, 200, 4), np.float32).view(np.uint32), full.view(np.uint32)), (tile_size, ranks)
+        for b in (dev, all_slabs, frame):
+            b.free()
+    r.set_tiles(16, 0, 1)
+    r.close()
+
+
+def test_missing_variant_and_bad_settings_fail_loudly(golden_dataset):
+    import ctypes as C
+    r = renderer.Renderer()
+    golden_cases.apply_case(r, golden_cases.FRAME_CASES[0], golden_dataset)
+    r.create_targets()
+    r.app.render_settings.polygon_sampling_technique = 1  # Turk area sampling: related work, out of scope
+    assert r.lib.create_shading_pass(C.byref(r.app.shading_pass), C.byref(r.app)) == 1
+    r.app.render_settings.polygon_sampling_technique = 4  # solid angle cannot drive LTC strategies
+    r.app.render_settings.sampling_strategies = 3
+    assert r.lib.create_shading_pass(C.byref(r.app.shading_pass), C.byref(r.app)) == 1
+    r.app.render_settings.polygon_sampling_technique = 11
+    r.create_pass()
+    r.app.render_settings.sampling_strategies = 0  # changing the variant without recreating the pass
+    assert r.lib.render_shading_pass(C.byref(r.app), None) == 1
+    r.close()
