@@ -46,7 +46,8 @@ typedef struct acceleration_structure_s {
 	void* triangle_vertices;
 	/*! original triangle index per leaf slot */
 	void* triangle_indices;
-	/*! (2 * triangle_count - 1) nodes, see vulkan_renderer_amd/csrc/lbvh.h */
+	/*! (2 * triangle_count - 1) nodes of 32 bytes in depth-first order, see
+		vulkan_renderer_amd/csrc/lbvh.h */
 	void* nodes;
 	uint32_t node_count;
 	uint32_t root;

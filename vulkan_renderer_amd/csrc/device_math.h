@@ -53,6 +53,10 @@ VKR_DEV float gmax(float x, float y) { return (x < y) ? y : x; }
 VKR_DEV float gmin(float x, float y) { return (y < x) ? y : x; }
 VKR_DEV float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 VKR_DEV float positive_part(float x) { return (x > 0.0f) ? x : 0.0f; }
+// Identity the optimiser cannot see through.  Used where it would otherwise fold
+// select(load a[i], load a[j]) into load a[select(i, j)], which forces register
+// arrays into scratch memory.
+VKR_DEV float opaque(float x) { asm("" : "+v"(x)); return x; }
 
 VKR_DEV float rcp(float x) {
 #if VKR_FAST_MATH

@@ -1,4 +1,4 @@
-// LBVH node layout and ray traversal (device code, gfx950).
+// LBVH layout and stackless ray traversal (device code, gfx950).
 //
 // The reference has no BVH code: shadow rays go through VK_KHR_ray_query against
 // a driver-built acceleration structure (reference src/scene.c:142-406,
@@ -6,29 +6,38 @@
 // ray-query semantics: opaque geometry, first hit terminates, no face culling,
 // t in [t_min, t_max], triangle soup de-quantised like scene.c:176-187.
 //
-// Layout in HBM: one 64-byte node per inner node holding BOTH child boxes, so a
-// visit is four coalescable 16-byte loads; leaves are single triangles stored as
-// three float4 in Morton order (w of vertex 0 carries the original primitive
-// index).  Child links with bit 31 set point at triangle slots.
+// Layout in HBM ("threaded" BVH): all 2n-1 nodes of the binary radix tree, inner
+// nodes and leaves alike, stored in depth-first order as 32 bytes each:
+//     float4 a = (lo.x, lo.y, lo.z, hi.x)
+//     float4 b = (hi.y, hi.z, bits(skip), bits(leaf))
+// The left child of an inner node is the next node; `skip` is the index of the
+// node that follows the whole subtree; `leaf` is the triangle slot or 0xFFFFFFFF.
+// A ray walks the array with a single cursor: hit -> next node (testing the
+// triangle first if it is a leaf), miss -> skip.  No stack, hence no scratch
+// memory and no LDS: the only per-ray state is the cursor.  Triangles are three
+// float4 per slot in the same (Morton) order, w of vertex 0 carries the original
+// primitive index.
 #pragma once
 #include "device_math.h"
 
 namespace vkr {
 
-struct alignas(16) bvh_node {
-	// a = (lo0.xyz, hi0.x)  b = (hi0.yz, lo1.xy)  c = (lo1.z, hi1.xyz)
-	float4 a, b, c;
-	// x = child 0, y = child 1 (bit 31: leaf), z = parent, w = unused
+// build-time node of the binary radix tree (Karras 2012); not used for traversal
+struct alignas(16) bvh_build_node {
+	// x = child 0, y = child 1 (bit 31: leaf slot), z = parent, w = first leaf of the range
 	uint4 links;
+	// x = last leaf of the range, y = number of leaves under child 0
+	uint2 range;
+	uint2 pad;
 };
 
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr int kTraversalStack = 64;
+constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
 
 struct bvh_view {
-	const bvh_node* nodes;
-	const float4* triangles;  // 3 per leaf slot
-	uint32_t root;            // inner node index, or kLeafBit | slot for 1 triangle
+	const float4* nodes;      // 2 float4 per node, depth-first order
+	const float4* triangles;  // 3 float4 per leaf slot
+	uint32_t node_count;      // 2 * triangle_count - 1
 };
 
 // Moeller-Trumbore, fp32, same operation order as oracle/oracle_bvh.c ray_triangle.
@@ -54,10 +63,10 @@ VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_m
 
 // Conservative slab test; boxes are padded at build time, so approximate
 // reciprocals are fine here in every arithmetic mode.
-VKR_DEV bool ray_box(f3 lo, f3 hi, f3 o, f3 inv, float t_min, float t_max) {
-	float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-	float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-	float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+VKR_DEV bool ray_box(float4 a, float4 b, f3 o, f3 inv, float t_min, float t_max) {
+	float x0 = (a.x - o.x) * inv.x, x1 = (a.w - o.x) * inv.x;
+	float y0 = (a.y - o.y) * inv.y, y1 = (b.x - o.y) * inv.y;
+	float z0 = (a.z - o.z) * inv.z, z1 = (b.y - o.z) * inv.z;
 	float near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
 	float far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
 	return near <= far * 1.0000004f;
@@ -68,74 +77,48 @@ VKR_DEV bool ray_box(f3 lo, f3 hi, f3 o, f3 inv, float t_min, float t_max) {
 VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) {
 	if (!(t_max >= t_min)) return false;
 	f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-	uint32_t stack[kTraversalStack];
-	int top = 0;
-	uint32_t current = bvh.root;
+	uint32_t node = 0;
+	const uint32_t end = bvh.node_count;
 	float dist;
-	while (true) {
-		if (current & kLeafBit) {
-			const float4* t = bvh.triangles + 3 * (size_t) (current & ~kLeafBit);
+	while (node < end) {
+		float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
+		uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
+		bool hit = ray_box(a, b, o, inv, t_min, t_max);
+		if (hit && leaf != kNoLeaf) {
+			const float4* t = bvh.triangles + 3 * (size_t) leaf;
 			if (ray_triangle<false>(t[0], t[1], t[2], o, d, t_min, t_max, dist)) return true;
-			if (top == 0) return false;
-			current = stack[--top];
-			continue;
 		}
-		const bvh_node& n = bvh.nodes[current];
-		float4 a = n.a, b = n.b, c = n.c;
-		uint4 links = n.links;
-		bool hit0 = ray_box(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), o, inv, t_min, t_max);
-		bool hit1 = ray_box(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), o, inv, t_min, t_max);
-		if (hit0 && hit1) {
-			if (top < kTraversalStack) stack[top++] = links.y;
-			current = links.x;
-		}
-		else if (hit0) current = links.x;
-		else if (hit1) current = links.y;
-		else {
-			if (top == 0) return false;
-			current = stack[--top];
-		}
+		// inner node that was hit: descend (the left child is the next node);
+		// everything else: leave the subtree
+		node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
 	}
+	return false;
 }
 
 // Closest hit with back-face culling (primary visibility).  Returns the original
 // primitive index or 0xFFFFFFFF.
 VKR_DEV uint32_t closest_front_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) {
 	f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-	uint32_t stack[kTraversalStack];
-	int top = 0;
-	uint32_t current = bvh.root;
+	uint32_t node = 0;
+	const uint32_t end = bvh.node_count;
 	uint32_t best = 0xFFFFFFFFu;
 	float dist;
-	while (true) {
-		if (current & kLeafBit) {
-			const float4* t = bvh.triangles + 3 * (size_t) (current & ~kLeafBit);
+	while (node < end) {
+		float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
+		uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
+		bool hit = ray_box(a, b, o, inv, t_min, t_max);
+		if (hit && leaf != kNoLeaf) {
+			const float4* t = bvh.triangles + 3 * (size_t) leaf;
 			float4 p0 = t[0];
 			if (ray_triangle<true>(p0, t[1], t[2], o, d, t_min, t_max, dist)) {
 				uint32_t primitive = __float_as_uint(p0.w);
 				// depth test LESS; ties go to the smaller primitive index for determinism
 				if (dist < t_max || primitive < best) { t_max = dist; best = primitive; }
 			}
-			if (top == 0) return best;
-			current = stack[--top];
-			continue;
 		}
-		const bvh_node& n = bvh.nodes[current];
-		float4 a = n.a, b = n.b, c = n.c;
-		uint4 links = n.links;
-		bool hit0 = ray_box(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), o, inv, t_min, t_max);
-		bool hit1 = ray_box(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), o, inv, t_min, t_max);
-		if (hit0 && hit1) {
-			if (top < kTraversalStack) stack[top++] = links.y;
-			current = links.x;
-		}
-		else if (hit0) current = links.x;
-		else if (hit1) current = links.y;
-		else {
-			if (top == 0) return best;
-			current = stack[--top];
-		}
+		node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
 	}
+	return best;
 }
 
 }  // namespace vkr

@@ -1,5 +1,5 @@
 // LBVH construction on the GPU (Karras 2012: Morton codes -> radix sort ->
-// binary radix tree -> bottom-up refit).  Replaces create_acceleration_structure
+// binary radix tree -> bottom-up refit -> depth-first "threaded" layout).  Replaces create_acceleration_structure
 // of the reference (src/scene.c:142-406), which hands the same de-quantised
 // triangle soup to the Vulkan driver.  Runs once per scene.
 #include "lbvh.h"
@@ -79,7 +79,7 @@ __device__ __forceinline__ int common_prefix(const uint64_t* keys, int n, int i,
 
 // One thread per inner node: range and split of the binary radix tree.  Inner
 // node i covers leaves [first, last]; children are inner nodes or leaves.
-__global__ void __launch_bounds__(256) k_build_hierarchy(const uint64_t* keys, int leaf_count, bvh_node* nodes, uint32_t* leaf_parents) {
+__global__ void __launch_bounds__(256) k_build_hierarchy(const uint64_t* keys, int leaf_count, bvh_build_node* nodes, uint32_t* leaf_parents) {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= leaf_count - 1) return;
 	int direction = (common_prefix(keys, leaf_count, i, i + 1) - common_prefix(keys, leaf_count, i, i - 1)) >= 0 ? 1 : -1;
@@ -103,6 +103,8 @@ __global__ void __launch_bounds__(256) k_build_hierarchy(const uint64_t* keys, i
 	uint32_t right = (split + 1 == last) ? (kLeafBit | (uint32_t) (split + 1)) : (uint32_t) (split + 1);
 	nodes[i].links.x = left;
 	nodes[i].links.y = right;
+	nodes[i].links.w = (uint32_t) first;
+	nodes[i].range = make_uint2((uint32_t) last, (uint32_t) (split - first + 1));
 	if (i == 0) nodes[0].links.z = 0xFFFFFFFFu;
 	if (left & kLeafBit) leaf_parents[left & ~kLeafBit] = (uint32_t) i; else nodes[left].links.z = (uint32_t) i;
 	if (right & kLeafBit) leaf_parents[right & ~kLeafBit] = (uint32_t) i; else nodes[right].links.z = (uint32_t) i;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void load_box(const float* lo, const float* hi, size_
 // Bottom-up refit: each leaf climbs; the second thread to reach a node merges the
 // child boxes.  Cross-workgroup visibility: agent-scope release before the arrival
 // counter, agent-scope acquire after it (per-XCD L2s are not coherent).
-__global__ void __launch_bounds__(256) k_refit(int leaf_count, bvh_node* nodes, const uint32_t* leaf_parents, float* lo, float* hi, uint32_t* arrivals) {
+__global__ void __launch_bounds__(256) k_refit(int leaf_count, const bvh_build_node* nodes, const uint32_t* leaf_parents, float* lo, float* hi, uint32_t* arrivals) {
 	int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= leaf_count) return;
 	uint32_t node = leaf_parents[slot];
@@ -131,9 +133,6 @@ __global__ void __launch_bounds__(256) k_refit(int leaf_count, bvh_node* nodes, 
 		f3 lo0, hi0, lo1, hi1;
 		load_box(lo, hi, il, lo0, hi0);
 		load_box(lo, hi, ir, lo1, hi1);
-		nodes[node].a = make_float4(lo0.x, lo0.y, lo0.z, hi0.x);
-		nodes[node].b = make_float4(hi0.y, hi0.z, lo1.x, lo1.y);
-		nodes[node].c = make_float4(lo1.z, hi1.x, hi1.y, hi1.z);
 		lo[3 * (size_t) node + 0] = fminf(lo0.x, lo1.x);
 		lo[3 * (size_t) node + 1] = fminf(lo0.y, lo1.y);
 		lo[3 * (size_t) node + 2] = fminf(lo0.z, lo1.z);
@@ -142,6 +141,32 @@ __global__ void __launch_bounds__(256) k_refit(int leaf_count, bvh_node* nodes, 
 		hi[3 * (size_t) node + 2] = fmaxf(hi0.z, hi1.z);
 		node = nodes[node].links.z;
 	}
+}
+
+// Depth-first ("threaded") layout.  One thread per node of the radix tree (inner
+// nodes first, then leaves).  The position of a node in depth-first order is the
+// number of nodes visited before it: walking up to the root, every step from a left
+// child adds the parent itself, every step from a right child adds the parent and
+// the parent's whole left subtree (2 * leaves - 1 nodes).
+__global__ void __launch_bounds__(256) k_thread_nodes(int leaf_count, const bvh_build_node* nodes, const uint32_t* leaf_parents, const float* lo, const float* hi, float4* threaded) {
+	int id = blockIdx.x * blockDim.x + threadIdx.x;
+	int total = 2 * leaf_count - 1;
+	if (id >= total) return;
+	bool is_leaf = id >= leaf_count - 1;
+	uint32_t slot = is_leaf ? (uint32_t) (id - (leaf_count - 1)) : 0u;
+	uint32_t code = is_leaf ? (kLeafBit | slot) : (uint32_t) id;
+	uint32_t leaves = is_leaf ? 1u : (nodes[id].range.x - nodes[id].links.w + 1u);
+	uint32_t parent = is_leaf ? (leaf_count > 1 ? leaf_parents[slot] : 0xFFFFFFFFu) : nodes[id].links.z;
+	uint32_t position = 0;
+	while (parent != 0xFFFFFFFFu) {
+		bool right = nodes[parent].links.y == code;
+		position += right ? 2u * nodes[parent].range.y : 1u;
+		code = parent;
+		parent = nodes[parent].links.z;
+	}
+	uint32_t skip = position + 2u * leaves - 1u;
+	threaded[2 * (size_t) position] = make_float4(lo[3 * (size_t) id], lo[3 * (size_t) id + 1], lo[3 * (size_t) id + 2], hi[3 * (size_t) id]);
+	threaded[2 * (size_t) position + 1] = make_float4(hi[3 * (size_t) id + 1], hi[3 * (size_t) id + 2], __uint_as_float(skip), __uint_as_float(is_leaf ? slot : kNoLeaf));
 }
 
 }  // namespace
@@ -174,6 +199,8 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	// the exact bounds
 	p.pad = 1.0e-4f * extent;
 	uint32_t inner_count = n > 1 ? n - 1 : 1;
+	uint32_t total_nodes = 2 * n - 1;
+	bvh_build_node* build_nodes = NULL;
 	uint64_t *keys = NULL, *sorted_keys = NULL;
 	float *lo = NULL, *hi = NULL;
 	uint32_t *leaf_parents = NULL, *arrivals = NULL;
@@ -182,12 +209,13 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	int failed = 1;
 	do {
 		if (hipMalloc(&structure->triangle_vertices, sizeof(float4) * 3 * (size_t) n) != hipSuccess) break;
-		if (hipMalloc(&structure->nodes, sizeof(bvh_node) * (size_t) inner_count) != hipSuccess) break;
+		if (hipMalloc(&structure->nodes, sizeof(float4) * 2 * (size_t) total_nodes) != hipSuccess) break;
+		if (hipMalloc(&build_nodes, sizeof(bvh_build_node) * (size_t) inner_count) != hipSuccess) break;
 		if (hipMalloc(&keys, sizeof(uint64_t) * n) != hipSuccess || hipMalloc(&sorted_keys, sizeof(uint64_t) * n) != hipSuccess) break;
 		if (hipMalloc(&lo, sizeof(float) * 3 * (2 * (size_t) n)) != hipSuccess || hipMalloc(&hi, sizeof(float) * 3 * (2 * (size_t) n)) != hipSuccess) break;
 		if (hipMalloc(&leaf_parents, sizeof(uint32_t) * n) != hipSuccess || hipMalloc(&arrivals, sizeof(uint32_t) * inner_count) != hipSuccess) break;
 		if (hipMemsetAsync(arrivals, 0, sizeof(uint32_t) * inner_count, stream) != hipSuccess) break;
-		if (hipMemsetAsync(structure->nodes, 0, sizeof(bvh_node) * (size_t) inner_count, stream) != hipSuccess) break;
+		if (hipMemsetAsync(build_nodes, 0, sizeof(bvh_build_node) * (size_t) inner_count, stream) != hipSuccess) break;
 		uint32_t blocks = (n + 255) / 256;
 		k_morton_keys<<<blocks, 256, 0, stream>>>(p, keys);
 		if (hipcub::DeviceRadixSort::SortKeys(NULL, sort_bytes, keys, sorted_keys, (int) n, 0, 62, stream) != hipSuccess) break;
@@ -195,19 +223,18 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 		if (hipcub::DeviceRadixSort::SortKeys(sort_storage, sort_bytes, keys, sorted_keys, (int) n, 0, 62, stream) != hipSuccess) break;
 		k_write_leaves<<<blocks, 256, 0, stream>>>(p, sorted_keys, (float4*) structure->triangle_vertices, lo, hi);
 		if (n > 1) {
-			k_build_hierarchy<<<(n - 1 + 255) / 256, 256, 0, stream>>>(sorted_keys, (int) n, (bvh_node*) structure->nodes, leaf_parents);
-			k_refit<<<blocks, 256, 0, stream>>>((int) n, (bvh_node*) structure->nodes, leaf_parents, lo, hi, arrivals);
-			structure->root = 0;
+			k_build_hierarchy<<<(n - 1 + 255) / 256, 256, 0, stream>>>(sorted_keys, (int) n, build_nodes, leaf_parents);
+			k_refit<<<blocks, 256, 0, stream>>>((int) n, build_nodes, leaf_parents, lo, hi, arrivals);
 		}
-		else
-			structure->root = kLeafBit;
+		k_thread_nodes<<<(total_nodes + 255) / 256, 256, 0, stream>>>((int) n, build_nodes, leaf_parents, lo, hi, (float4*) structure->nodes);
+		structure->root = 0;
 		if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) break;
-		structure->node_count = inner_count;
+		structure->node_count = total_nodes;
 		structure->triangle_indices = NULL;
 		failed = 0;
 	} while (0);
 	(void) hipFree(keys); (void) hipFree(sorted_keys); (void) hipFree(lo); (void) hipFree(hi);
-	(void) hipFree(leaf_parents); (void) hipFree(arrivals); (void) hipFree(sort_storage);
+	(void) hipFree(leaf_parents); (void) hipFree(arrivals); (void) hipFree(sort_storage); (void) hipFree(build_nodes);
 	if (failed) {
 		printf("Building the LBVH over %u triangles failed: %s\n", n, hipGetErrorString(hipGetLastError()));
 		vkr_destroy_acceleration_structure(structure, device);

@@ -540,6 +540,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			ps.vertex_count = 0;
 			ps.inner_ellipse_0 = mk2(0.0f, 0.0f);
 			bool specular_culled = false;
+#pragma unroll
 			for (int t = 0; t != 2; ++t) {
 				const m43& to_local = (t == 0) ? world_to_shading : world_to_cosine;
 				if (t > 0) pd = ps;

@@ -237,9 +237,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	p.noise = (const uint2*) app->noise_table.device_data;
 	p.noise_width = app->noise_table.resolution.width;
 	p.noise_height = app->noise_table.resolution.height;
-	p.bvh.nodes = (const bvh_node*) app->scene.acceleration_structure.nodes;
+	p.bvh.nodes = (const float4*) app->scene.acceleration_structure.nodes;
 	p.bvh.triangles = (const float4*) app->scene.acceleration_structure.triangle_vertices;
-	p.bvh.root = app->scene.acceleration_structure.root;
+	p.bvh.node_count = app->scene.acceleration_structure.node_count;
 	if (!p.positions || !p.visibility || !p.out_radiance || !p.ltc_rgba || !p.noise || !p.material_constants) {
 		printf("render_shading_pass() needs a loaded scene, LTC table, noise table and render targets on the device.\n");
 		return 1;
@@ -410,9 +410,9 @@ extern "C" int render_visibility_pass(application_t* app) {
 	write_constants(pass->constants_host, app);
 	if (vkr_copy_to_device_async(pass->constants_device, pass->constants_host, pass->constants_size, &app->device)) return 1;
 	bvh_view bvh;
-	bvh.nodes = (const bvh_node*) as->nodes;
+	bvh.nodes = (const float4*) as->nodes;
 	bvh.triangles = (const float4*) as->triangle_vertices;
-	bvh.root = as->root;
+	bvh.node_count = as->node_count;
 	uint32_t width = app->swapchain.extent.width, height = app->swapchain.extent.height;
 	dim3 grid((width + 15) / 16, (height + 15) / 16);
 	k_primary_visibility<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const uint8_t*) pass->constants_device, bvh, (uint32_t*) app->render_targets.visibility_buffer,
