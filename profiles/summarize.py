@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>/ (written by profiles/collect.sh on the GPU box) into the
+committed summaries profiles/<tag>_summary.md and profiles/pmc_traffic.json.
+
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB
+per dispatch; on gfx950 FETCH_SIZE under-reports wide coalesced reads by up to 2x
+and is uncalibrated for other widths, so both the raw and the doubled figure are
+listed and bench.py reports the raw sum (lower bound)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(directory):
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for path in files:
+        for row in csv.DictReader(open(path)):
+            name = row["Kernel_Name"].split("(")[0]
+            per_kernel[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            meta[name] = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Grid_Size", "Workgroup_Size")}
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in per_kernel.items()}, meta
+
+
+def kernel_stats(directory):
+    out = []
+    for path in glob.glob(os.path.join(directory, "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            out.append(row)
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    base = os.path.join(ROOT, "gpurun_out", tag)
+    lines = ["# rocprofv3 summary %s" % tag, "",
+             "Collected by `profiles/collect.sh %s` on an MI355X (gfx950), summarised by `profiles/summarize.py`." % tag, ""]
+    traffic = {}
+    traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(traffic_path):
+        traffic = json.load(open(traffic_path))
+    for cfg in (2, 3):
+        lines += ["## BASELINE config %d" % cfg, ""]
+        bench = os.path.join(base, "cfg%d_bench.json" % cfg)
+        if os.path.exists(bench):
+            text = [l for l in open(bench).read().splitlines() if l.startswith("{")]
+            if text:
+                d = json.loads(text[-1])
+                lines += ["bench.py (un-profiled): **%.1f %s**, %.4f ms/step, kernel %.4f ms (HIP events), %.0f Mrays/s, parity %s" % (
+                    d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d.get("Mrays_per_s", 0), json.dumps(d.get("parity"))), ""]
+        stats = kernel_stats(os.path.join(base, "cfg%d_trace" % cfg))
+        if stats:
+            lines += ["`rocprofv3 --kernel-trace --stats` (top kernels):", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+            for row in stats[:8]:
+                lines.append("| `%s` | %s | %.1f | %.1f | %.1f | %s |" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3, row["Percentage"]))
+            lines.append("")
+        merged, meta = {}, {}
+        for p in (1, 2, 3, 4):
+            c, m = counters(os.path.join(base, "cfg%d_pmc%d" % (cfg, p)))
+            for k, v in c.items():
+                merged.setdefault(k, {}).update(v)
+            meta.update(m)
+        for kernel, c in merged.items():
+            lines += ["PMC, per dispatch of `%s` (%s):" % (kernel[:70], ", ".join("%s=%s" % kv for kv in meta.get(kernel, {}).items() if kv[1] is not None)), ""]
+            lines += ["| counter | value |", "|---|---|"]
+            for name in sorted(c):
+                lines.append("| %s | %.5g |" % (name, c[name]))
+            gui = c.get("GRBM_GUI_ACTIVE")
+            if gui and "SQ_WAVE_CYCLES" in c:
+                cycles = gui / 8.0  # summed over the 8 XCDs
+                simds = 1024.0
+                lines += ["", "Derived (SQ_* count quad-cycles; GRBM_GUI_ACTIVE is summed over 8 XCDs):", "",
+                          "- kernel length ~ %.0f cycles; mean resident waves per SIMD = %.2f" % (cycles, 4 * c["SQ_WAVE_CYCLES"] / (simds * cycles)),
+                          "- VALU busy = %.1f %% of SIMD cycles; lane utilisation of VALU instructions = %.1f %%" % (
+                              100 * 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (simds * cycles), 100 * c.get("SQ_THREAD_CYCLES_VALU", 0) / max(64 * c.get("SQ_ACTIVE_INST_VALU", 1), 1)),
+                          "- wave time: %.1f %% issuing, %.1f %% waiting on memory (s_waitcnt), %.1f %% issue stalls" % (
+                              100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"])]
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+                lines += ["- HBM traffic per dispatch: FETCH_SIZE %.1f MiB (x2 correction: %.1f MiB) + WRITE_SIZE %.1f MiB = %.1f MB raw" % (
+                    c["FETCH_SIZE"] / 1024, 2 * c["FETCH_SIZE"] / 1024, c["WRITE_SIZE"] / 1024, raw / 1e6)]
+                if "TCC_HIT_sum" in c:
+                    lines.append("- L2 hit rate %.1f %%" % (100 * c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)))
+                if "shade_pixels" in kernel:
+                    w, h = (1920, 1080)
+                    traffic["config%d_exact" % cfg] = {"width": w, "height": h, "hbm_bytes_per_launch": int(raw), "source": "profiles/%s_summary.md" % tag}
+            lines.append("")
+    open(os.path.join(ROOT, "profiles", "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
+    json.dump(traffic, open(traffic_path, "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
