@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-rays", action="store_true", help="disable shadow rays (TRACE_SHADOW_RAYS=0) for experiments")
+    ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
@@ -92,7 +93,7 @@ def main():
     tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % rank)
     dataset = synthetic.write_dataset(tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51)
     stream = torch.cuda.current_stream()
-    r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"))
+    r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays)
     renderer.setup_config(r, config, dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=True,
                           trace_shadow_rays=settings["trace_shadow_rays"])
     r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1)

@@ -147,6 +147,12 @@ typedef struct shading_pass_s {
 	/*! arithmetic mode: 0 = exact (IEEE division/sqrt, no contraction; bit-comparable
 		with the CPU oracle), 1 = fast (approximate reciprocals, contraction) */
 	int32_t fast_math;
+	/*! shadow rays: 0 = wavefront (shade -> compacted ray queue -> trace kernel ->
+		ordered resolve; default), 1 = every lane walks the BVH inside the shading
+		kernel.  Both give identical results. */
+	int32_t inline_rays;
+	/*! buffers of the wavefront ray path (ray queue, term streams) */
+	void* wavefront;
 	/*! timing of the last dispatch in milliseconds (HIP events on device->stream) */
 	float last_dispatch_ms;
 	/*! ring of HIP event pairs, one pair per render_shading_pass call */

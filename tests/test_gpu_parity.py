@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 RMSE_TOLERANCE = 1.0e-4
 
 
-def gpu_render(dataset, config, width, height, fast_math, **overrides):
-    r = renderer.Renderer(fast_math=fast_math)
+def gpu_render(dataset, config, width, height, fast_math, inline_rays=False, **overrides):
+    r = renderer.Renderer(fast_math=fast_math, inline_rays=inline_rays)
     renderer.setup_config(r, config, dataset, width=width, height=height, acceleration_structure=True, **overrides)
     r.create_targets()
     r.create_pass()
@@ -26,9 +26,10 @@ def gpu_render(dataset, config, width, height, fast_math, **overrides):
     return r, image, visibility
 
 
+@pytest.mark.parametrize("inline_rays", [False, True], ids=["wavefront", "inline"])
 @pytest.mark.parametrize("config", [1, 2, 3])
-def test_exact_mode_matches_oracle_bitwise(dataset, config):
-    r, image, visibility = gpu_render(dataset, config, 256, 144, fast_math=False)
+def test_exact_mode_matches_oracle_bitwise(dataset, config, inline_rays):
+    r, image, visibility = gpu_render(dataset, config, 256, 144, fast_math=False, inline_rays=inline_rays)
     cpu, inputs, bvh = oracle_render(r, visibility=visibility, math_mode=1)
     stats = compare(image, cpu)
     r.close()

@@ -63,10 +63,13 @@ VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_m
 
 // Conservative slab test; boxes are padded at build time, so approximate
 // reciprocals are fine here in every arithmetic mode.
-VKR_DEV bool ray_box(float4 a, float4 b, f3 o, f3 inv, float t_min, float t_max) {
-	float x0 = (a.x - o.x) * inv.x, x1 = (a.w - o.x) * inv.x;
-	float y0 = (a.y - o.y) * inv.y, y1 = (b.x - o.y) * inv.y;
-	float z0 = (a.z - o.z) * inv.z, z1 = (b.y - o.z) * inv.z;
+VKR_DEV bool ray_box(float4 a, float4 b, f3 inv, f3 shift, float t_min, float t_max) {
+	// t = (plane - o) / d = plane * inv + shift with shift = -o * inv: one FMA per plane.
+	// (For axis-parallel rays inf - inf gives NaN, which min/max ignore: that slab
+	// then never culls, which is conservative.)
+	float x0 = fmaf(a.x, inv.x, shift.x), x1 = fmaf(a.w, inv.x, shift.x);
+	float y0 = fmaf(a.y, inv.y, shift.y), y1 = fmaf(b.x, inv.y, shift.y);
+	float z0 = fmaf(a.z, inv.z, shift.z), z1 = fmaf(b.y, inv.z, shift.z);
 	float near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
 	float far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
 	return near <= far * 1.0000004f;
@@ -77,13 +80,14 @@ VKR_DEV bool ray_box(float4 a, float4 b, f3 o, f3 inv, float t_min, float t_max)
 VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) {
 	if (!(t_max >= t_min)) return false;
 	f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+	f3 shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
 	uint32_t node = 0;
 	const uint32_t end = bvh.node_count;
 	float dist;
 	while (node < end) {
 		float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
 		uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
-		bool hit = ray_box(a, b, o, inv, t_min, t_max);
+		bool hit = ray_box(a, b, inv, shift, t_min, t_max);
 		if (hit && leaf != kNoLeaf) {
 			const float4* t = bvh.triangles + 3 * (size_t) leaf;
 			if (ray_triangle<false>(t[0], t[1], t[2], o, d, t_min, t_max, dist)) return true;
@@ -99,6 +103,7 @@ VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) 
 // primitive index or 0xFFFFFFFF.
 VKR_DEV uint32_t closest_front_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) {
 	f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+	f3 shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
 	uint32_t node = 0;
 	const uint32_t end = bvh.node_count;
 	uint32_t best = 0xFFFFFFFFu;
@@ -106,7 +111,7 @@ VKR_DEV uint32_t closest_front_hit(const bvh_view& bvh, f3 o, f3 d, float t_min,
 	while (node < end) {
 		float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
 		uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
-		bool hit = ray_box(a, b, o, inv, t_min, t_max);
+		bool hit = ray_box(a, b, inv, shift, t_min, t_max);
 		if (hit && leaf != kNoLeaf) {
 			const float4* t = bvh.triangles + 3 * (size_t) leaf;
 			float4 p0 = t[0];

@@ -50,7 +50,30 @@ struct shade_params {
 	// tile schedule (include/vkr_shading_pass.h tile_schedule_t)
 	uint32_t tile_size, rank, rank_count, tiles_x, tile_count;
 	unsigned long long* ray_counter;
+	// wavefront mode (RAYS == kRaysDeferred): per-thread streams of pending terms and
+	// the compacted shadow-ray queue, see "wavefront" below
+	uint8_t* codes;
+	float* terms_visible;
+	float* terms_hidden;
+	// kRayQueueCount independent queues, each with its own counter (one counter for the
+	// whole chip saturates at ~88 atomics / us); wave w appends to queue w % count
+	float4* ray_queue;
+	uint32_t* ray_queue_size;
+	uint32_t ray_queue_capacity;
+	uint32_t thread_count, max_terms, max_codes;
 };
+
+constexpr uint32_t kRayQueueCount = 256;
+
+// How shadow rays are traced (template parameter RAYS):
+//   kRaysNone      TRACE_SHADOW_RAYS = 0
+//   kRaysInline    every lane walks the BVH inside the shading kernel
+//   kRaysDeferred  wavefront: the shading kernel appends rays to a queue compacted
+//                  with wave ballots, a lean high-occupancy kernel traces them, a
+//                  resolve kernel replays the per-pixel sums in the original order
+enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2 };
+// codes of the per-thread term stream written in deferred mode
+enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5 };
 
 VKR_DEV float load_f(const uint8_t* base, uint32_t offset) { return *(const float*) (base + offset); }
 VKR_DEV uint32_t load_u(const uint8_t* base, uint32_t offset) { return *(const uint32_t*) (base + offset); }
@@ -398,22 +421,80 @@ VKR_DEV bool light_ray_intersection(const light_ref& light, uint32_t vmax, f3 or
 struct pixel_context {
 	const shade_params& p;
 	uint32_t rays;
+	// deferred mode: this thread's slot in the term streams and its write cursors
+	uint32_t tid, code_cursor, term_cursor;
+	bool light_has_terms;
 };
 
-// get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231
-template <bool RAYS, bool DIFFUSE, bool SPECULAR>
-VKR_DEV f3 radiance_visibility_brdf(pixel_context& ctx, float& out_lambert, bool& out_visibility, f3 dir, const shading_data& sd, const light_ref& light) {
+// get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231, without
+// the ray query: `candidate` is the visibility before tracing (n.l > 0), the return
+// value is radiance * BRDF under the assumption that the shadow ray reaches the light.
+template <bool DIFFUSE, bool SPECULAR>
+VKR_DEV f3 radiance_brdf(float& out_lambert, bool& out_candidate, f3 dir, const shading_data& sd, const light_ref& light) {
 	float lambert = dot(sd.normal, dir);
-	bool visibility = lambert > 0.0f;
-	if (RAYS && visibility) {
-		float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
-		++ctx.rays;
-		visibility = !any_hit(ctx.p.bvh, sd.position, dir, 1.0e-3f, max_t);
-	}
 	out_lambert = lambert;
-	out_visibility = visibility;
-	if (visibility) return light_radiance(light) * evaluate_brdf<DIFFUSE, SPECULAR>(sd, dir);
+	out_candidate = lambert > 0.0f;
+	if (out_candidate) return light_radiance(light) * evaluate_brdf<DIFFUSE, SPECULAR>(sd, dir);
 	return mk3(0.0f, 0.0f, 0.0f);
+}
+
+VKR_DEV bool all_zero(f3 v) { return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z)) & 0x7FFFFFFFu) == 0; }
+
+// Appends one shadow ray to the global queue.  Lanes of the wave that arrive here
+// together reserve their slots with ONE atomic: ballot -> popcount -> lane prefix.
+VKR_DEV void push_ray(const shade_params& p, f3 origin, f3 dir, float t_max, uint32_t code_index) {
+	uint64_t mask = __ballot(1);
+	uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+	uint32_t queue = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kRayQueueCount;
+	uint32_t base = 0;
+	if (prefix == 0) base = atomicAdd(p.ray_queue_size + queue, (uint32_t) __popcll(mask));
+	base = __builtin_amdgcn_readfirstlane(base);
+	size_t slot = (size_t) queue * p.ray_queue_capacity + base + prefix;
+	p.ray_queue[2 * slot] = make_float4(origin.x, origin.y, origin.z, t_max);
+	p.ray_queue[2 * slot + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(code_index));
+}
+
+// Adds one estimator term to the per-light sum.  `visible_term` is the value of the
+// term if the shadow ray reaches the light (or, without a candidate ray, simply the
+// value), `hidden_term` the value if it is blocked.
+template <int RAYS>
+VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visible_term, f3 hidden_term, f3 dir, const shading_data& sd, const light_ref& light) {
+	if constexpr (RAYS == kRaysNone) {
+		result = result + visible_term;
+	}
+	else if constexpr (RAYS == kRaysInline) {
+		bool visible = candidate;
+		if (candidate) {
+			float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
+			++ctx.rays;
+			visible = !any_hit(ctx.p.bvh, sd.position, dir, 1.0e-3f, max_t);
+		}
+		result = result + ((visible || !candidate) ? visible_term : hidden_term);
+	}
+	else {
+		// Adding +-0 never changes the running sum (it starts at +0), so such terms are
+		// dropped; everything else is written in program order.
+		const shade_params& p = ctx.p;
+		bool hidden_matters = !all_zero(hidden_term);
+		bool needs_ray = candidate && (hidden_matters || !all_zero(visible_term));
+		bool is_final = !candidate && !all_zero(visible_term);
+		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
+			size_t code_index = (size_t) ctx.code_cursor * p.thread_count + ctx.tid;
+			size_t term_index = ((size_t) ctx.term_cursor * p.thread_count + ctx.tid) * 3;
+			p.codes[code_index] = (uint8_t) (is_final ? kCodeFinal : (hidden_matters ? kCodePendingWithHidden : kCodePending));
+			p.terms_visible[term_index] = visible_term.x; p.terms_visible[term_index + 1] = visible_term.y; p.terms_visible[term_index + 2] = visible_term.z;
+			if (needs_ray && hidden_matters) {
+				p.terms_hidden[term_index] = hidden_term.x; p.terms_hidden[term_index + 1] = hidden_term.y; p.terms_hidden[term_index + 2] = hidden_term.z;
+			}
+			if (needs_ray) {
+				float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
+				push_ray(p, sd.position, dir, max_t, (uint32_t) code_index);
+			}
+			++ctx.code_cursor;
+			++ctx.term_cursor;
+			ctx.light_has_terms = true;
+		}
+	}
 }
 
 VKR_DEV float mis_weight_over_density(int heuristic, float sampled, float other) {
@@ -448,22 +529,29 @@ VKR_DEV f3 mis_estimate(int heuristic, f3 integrand, f3 sw, float sd, f3 ow, flo
 }
 
 // get_polygonal_light_mis_estimate, shading_pass.frag.glsl:305-323
-template <int STRATEGY, bool RAYS>
-VKR_DEV f3 light_mis_estimate(pixel_context& ctx, f3 dir, float density, const shading_data& sd, const light_ref& light) {
+template <int STRATEGY, int RAYS>
+VKR_DEV void add_light_mis_estimate(pixel_context& ctx, f3& result, f3 dir, float density, const shading_data& sd, const light_ref& light) {
 	float lambert;
-	bool visibility;
-	f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, dir, sd, light);
-	if (STRATEGY == kStrategyDiffuseOnly)
-		return (density > 0.0f) ? rb * divide(lambert, density) : mk3(0.0f, 0.0f, 0.0f);
-	if (STRATEGY == kStrategyDiffuseGgxMis) {
-		float ggx_density = ggx_reflected_density(sd.lambert_outgoing, sd.outgoing, dir, sd.normal, sd.roughness);
-		return (rb * lambert) * mis_weight_over_density(ctx.p.mis_heuristic, density, ggx_density);
+	bool candidate;
+	f3 rb = radiance_brdf<true, true>(lambert, candidate, dir, sd, light);
+	const f3 zero = mk3(0.0f, 0.0f, 0.0f);
+	f3 visible_term = zero, hidden_term = zero;
+	if (STRATEGY == kStrategyDiffuseOnly) {
+		float factor = divide(lambert, density);
+		visible_term = (density > 0.0f) ? rb * factor : zero;
+		hidden_term = (density > 0.0f) ? zero * factor : zero;
 	}
-	return mk3(0.0f, 0.0f, 0.0f);
+	else if (STRATEGY == kStrategyDiffuseGgxMis) {
+		float ggx_density = ggx_reflected_density(sd.lambert_outgoing, sd.outgoing, dir, sd.normal, sd.roughness);
+		float weight = mis_weight_over_density(ctx.p.mis_heuristic, density, ggx_density);
+		visible_term = (rb * lambert) * weight;
+		hidden_term = (zero * lambert) * weight;
+	}
+	accumulate<RAYS>(ctx, result, candidate, visible_term, hidden_term, dir, sd, light);
 }
 
 // evaluate_polygonal_light_shading, shading_pass.frag.glsl:329-711
-template <int STRATEGY, int TECHNIQUE, int V, bool RAYS>
+template <int STRATEGY, int TECHNIQUE, int V, int RAYS>
 VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_coefficients& ltc_in, const light_ref& light, noise_accessor& noise) {
 	const shade_params& p = ctx.p;
 	constexpr bool kBiased = TECHNIQUE == kTechniquePsaBiased;
@@ -484,7 +572,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		density_factor = rcp(pd.solid_angle);
 		for (uint32_t s = 0; s != S; ++s) {
 			f3 dir = sample_sa<V>(pd, next_noise_2(p, noise));
-			result = result + light_mis_estimate<STRATEGY, RAYS>(ctx, dir, density_factor, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueClippedSolidAngle) {
@@ -500,7 +588,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		for (uint32_t s = 0; s != S; ++s) {
 			f3 dir = sample_sa<V>(pd, next_noise_2(p, noise));
 			dir = mul_transposed(world_to_shading, dir);
-			result = result + light_mis_estimate<STRATEGY, RAYS>(ctx, dir, density_factor, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
 	else {
@@ -529,7 +617,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 				f3 dir = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
 				float density = divide(dir.z, pd.total);
 				dir = mul_transposed(world_to_shading, dir);
-				result = result + light_mis_estimate<STRATEGY, RAYS>(ctx, dir, density, sd, light);
+				add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
 			}
 			density_factor = rcp(pd.total);
 		}
@@ -562,18 +650,25 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					f3 dd = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
 					dd = mul_transposed(world_to_shading, dd);
 					float lambert;
-					bool visibility;
-					f3 rb = radiance_visibility_brdf<RAYS, true, false>(ctx, lambert, visibility, dd, sd, light);
-					result = result + rb * pd.total;
+					bool candidate;
+					f3 rb = radiance_brdf<true, false>(lambert, candidate, dd, sd, light);
+					accumulate<RAYS>(ctx, result, candidate, rb * pd.total, zero * pd.total, dd, sd, light);
 					if (ps.total > 0.0f) {
 						f3 dc = sample_psa<V, kBiased>(ps, next_noise_2(p, noise));
 						f3 ds = normalize(cosine_to_shading(ltc_in, dc));
 						float ltc_density = evaluate_ltc_density(ltc_in, ds, 1.0f);
-						f3 rb2 = radiance_visibility_brdf<RAYS, false, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
-						if (!(ds.z <= 0.0f || dc.z <= 0.0f))
-							{
+						f3 dw = mul_transposed(world_to_shading, ds);
+						f3 rb2 = radiance_brdf<false, true>(lambert, candidate, dw, sd, light);
+						if (!(ds.z <= 0.0f || dc.z <= 0.0f)) {
 							f3 t = (rb2 * ds.z) * ps.total;
-							result = result + mk3(divide(t.x, ltc_density), divide(t.y, ltc_density), divide(t.z, ltc_density));
+							f3 t0 = (zero * ds.z) * ps.total;
+							accumulate<RAYS>(ctx, result, candidate,
+								mk3(divide(t.x, ltc_density), divide(t.y, ltc_density), divide(t.z, ltc_density)),
+								mk3(divide(t0.x, ltc_density), divide(t0.y, ltc_density), divide(t0.z, ltc_density)), dw, sd, light);
+						}
+						else if (RAYS == kRaysInline && candidate) {
+							// the reference traces this ray even though the sample is discarded (:583-584)
+							accumulate<RAYS>(ctx, result, candidate, zero, zero, dw, sd, light);
 						}
 					}
 				}
@@ -605,15 +700,25 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 						float dens_d = ds.z * rcp_d;
 						float dens_s = evaluate_ltc_density(ltc_in, ds, rcp_s);
 						float lambert;
-						bool visibility;
-						f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
+						bool candidate;
+						f3 dw = mul_transposed(world_to_shading, ds);
+						f3 rb = radiance_brdf<true, true>(lambert, candidate, dw, sd, light);
 						f3 integrand = rb * ds.z;
-						if (j == 0 && ps.total <= 0.0f)
-							result = result + (visibility ? integrand * rcp(dens_d) : zero);
-						else if (j == 0)
-							result = result + mis_estimate(heuristic, integrand, diffuse_weight, dens_d, specular_weight_rgb, dens_s, visibility_estimate);
-						else
-							result = result + mis_estimate(heuristic, integrand, specular_weight_rgb, dens_s, diffuse_weight, dens_d, visibility_estimate);
+						f3 dark = zero * ds.z;
+						f3 visible_term, hidden_term;
+						if (j == 0 && ps.total <= 0.0f) {
+							visible_term = candidate ? integrand * rcp(dens_d) : zero;
+							hidden_term = zero;
+						}
+						else if (j == 0) {
+							visible_term = mis_estimate(heuristic, integrand, diffuse_weight, dens_d, specular_weight_rgb, dens_s, visibility_estimate);
+							hidden_term = mis_estimate(heuristic, dark, diffuse_weight, dens_d, specular_weight_rgb, dens_s, visibility_estimate);
+						}
+						else {
+							visible_term = mis_estimate(heuristic, integrand, specular_weight_rgb, dens_s, diffuse_weight, dens_d, visibility_estimate);
+							hidden_term = mis_estimate(heuristic, dark, specular_weight_rgb, dens_s, diffuse_weight, dens_d, visibility_estimate);
+						}
+						accumulate<RAYS>(ctx, result, candidate, visible_term, hidden_term, dw, sd, light);
 					}
 				}
 			}
@@ -633,12 +738,16 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					float dens_d = lambert * diffuse_albedo;
 					float dens_s = evaluate_ltc_density(ltc_in, ds, specular_albedo);
 					float density = divide(dens_d + dens_s, diffuse_weight + specular_weight);
-					bool visibility;
-					f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, mul_transposed(world_to_shading, ds), sd, light);
+					bool candidate;
+					f3 dw = mul_transposed(world_to_shading, ds);
+					f3 rb = radiance_brdf<true, true>(lambert, candidate, dw, sd, light);
 					if (!(ds.z <= 0.0f)) {
 						f3 t = rb * ds.z;
-						result = result + mk3(divide(t.x, density), divide(t.y, density), divide(t.z, density));
+						f3 t0 = zero * ds.z;
+						accumulate<RAYS>(ctx, result, candidate, mk3(divide(t.x, density), divide(t.y, density), divide(t.z, density)),
+							mk3(divide(t0.x, density), divide(t0.y, density), divide(t0.z, density)), dw, sd, light);
 					}
+					else if (RAYS == kRaysInline && candidate) accumulate<RAYS>(ctx, result, candidate, zero, zero, dw, sd, light);
 				}
 			}
 		}
@@ -654,11 +763,20 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			f3 dw = mul_transposed(world_to_shading, dg);
 			if (dg.z > 0.0f && light_ray_intersection(light, p.max_light_vertex_count, sd.position, dw, 0.0f)) {
 				float lambert;
-				bool visibility;
-				f3 rb = radiance_visibility_brdf<RAYS, true, true>(ctx, lambert, visibility, dw, sd, light);
+				bool candidate;
+				f3 rb = radiance_brdf<true, true>(lambert, candidate, dw, sd, light);
 				float polygon_density = kIsPsa ? (lambert * density_factor) : density_factor;
-				result = result + (rb * lambert) * mis_weight_over_density(p.mis_heuristic, ggx_density, polygon_density);
+				float weight = mis_weight_over_density(p.mis_heuristic, ggx_density, polygon_density);
+				accumulate<RAYS>(ctx, result, candidate, (rb * lambert) * weight, (zero * lambert) * weight, dw, sd, light);
 			}
+		}
+	}
+	if constexpr (RAYS == kRaysDeferred) {
+		// close this light's run of terms; the resolve kernel scales by 1 / S and adds it
+		if (ctx.light_has_terms && ctx.code_cursor + 1 < p.max_codes) {
+			p.codes[(size_t) ctx.code_cursor * p.thread_count + ctx.tid] = (uint8_t) kCodeEndOfLight;
+			++ctx.code_cursor;
+			ctx.light_has_terms = false;
 		}
 	}
 	return result * (1.0f / (float) S);
@@ -685,13 +803,20 @@ VKR_DEV bool locate_pixel(const shade_params& p, uint32_t& px, uint32_t& py, siz
 	return px < p.width && py < p.height;
 }
 
+VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color) {
+	float exposure = load_f(p.constants, 176);
+	bool broken = !(fabsf(color.x) < __builtin_inff()) || !(fabsf(color.y) < __builtin_inff()) || !(fabsf(color.z) < __builtin_inff());
+	if (broken) color = mk3(divide(1.0f, exposure), divide(0.0f, exposure), divide(0.8f, exposure));
+	p.out_radiance[out_index] = make_float4(color.x * exposure, color.y * exposure, color.z * exposure, 1.0f);
+}
+
 // main, shading_pass.frag.glsl:824-866
-template <int STRATEGY, int TECHNIQUE, int V, bool RAYS>
+template <int STRATEGY, int TECHNIQUE, int V, int RAYS>
 __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 	uint32_t px, py;
 	size_t out_index;
 	bool inside = locate_pixel(p, px, py, out_index);
-	pixel_context ctx = {p, 0};
+	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false};
 	if (inside) {
 		const uint8_t* c = p.constants;
 		uint32_t primitive = p.visibility[(size_t) py * p.width + px];
@@ -728,12 +853,16 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS>(ctx, sd, ltc, light, noise);
 			}
 		}
-		float exposure = load_f(c, 176);
-		bool broken = !(fabsf(color.x) < __builtin_inff()) || !(fabsf(color.y) < __builtin_inff()) || !(fabsf(color.z) < __builtin_inff());
-		if (broken) color = mk3(divide(1.0f, exposure), divide(0.0f, exposure), divide(0.8f, exposure));
-		p.out_radiance[out_index] = make_float4(color.x * exposure, color.y * exposure, color.z * exposure, 1.0f);
+		if constexpr (RAYS == kRaysDeferred) {
+			// hand over to trace_shadow_rays / resolve_shadow_terms: the colour so far
+			// (light display) and the terminated term stream
+			p.out_radiance[out_index] = make_float4(color.x, color.y, color.z, 0.0f);
+			p.codes[(size_t) ctx.code_cursor * p.thread_count + ctx.tid] = (uint8_t) kCodeEnd;
+		}
+		else
+			store_final_color(p, out_index, color);
 	}
-	if (RAYS && p.ray_counter) {
+	if (RAYS == kRaysInline && p.ray_counter) {
 		// one atomic per wave
 		uint32_t rays = ctx.rays;
 #pragma unroll
@@ -741,5 +870,55 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 		if ((threadIdx.x & 63) == 0 && rays) atomicAdd(p.ray_counter, (unsigned long long) rays);
 	}
 }
+
+// ---- wavefront: trace and resolve (instantiated once, in shading_pass.hip) -------------------
+#ifdef VKR_WAVEFRONT_KERNELS
+
+// One shadow ray per lane, grid-stride over the compacted queue.  Few registers,
+// no LDS, no scratch: many waves per SIMD hide the latency of the dependent node
+// fetches.  A visible ray flips its term's code to kCodeVisible.
+__global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t blocks_per_queue, uint8_t* codes) {
+	uint32_t queue = blockIdx.x / blocks_per_queue, part = blockIdx.x - queue * blocks_per_queue;
+	uint32_t count = ray_queue_size[queue];
+	const float4* rays = ray_queue + 2 * (size_t) queue * ray_queue_capacity;
+	uint32_t stride = blocks_per_queue * 256u;
+	for (uint32_t i = part * 256u + threadIdx.x; i < count; i += stride) {
+		float4 a = rays[2 * (size_t) i], b = rays[2 * (size_t) i + 1];
+		if (!any_hit(bvh, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 1.0e-3f, a.w))
+			codes[__float_as_uint(b.w)] = (uint8_t) kCodeVisible;
+	}
+}
+
+// Replays every pixel's sums in the order of the shading program: terms of one light
+// are added one after the other, the light's sum is scaled by 1 / SAMPLE_COUNT and
+// added to the colour (shading_pass.frag.glsl:710, :858), then NaN check and exposure.
+__global__ void __launch_bounds__(256) resolve_shadow_terms(const shade_params p) {
+	uint32_t px, py;
+	size_t out_index;
+	if (!locate_pixel(p, px, py, out_index)) return;
+	uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+	float4 base = p.out_radiance[out_index];
+	f3 color = mk3(base.x, base.y, base.z);
+	f3 sum = mk3(0.0f, 0.0f, 0.0f);
+	float rcp_samples = 1.0f / (float) p.sample_count;
+	uint32_t term = 0;
+	for (uint32_t k = 0; k < p.max_codes; ++k) {
+		uint32_t code = p.codes[(size_t) k * p.thread_count + tid];
+		if (code == kCodeEnd) break;
+		if (code == kCodeEndOfLight) {
+			color = color + sum * rcp_samples;
+			sum = mk3(0.0f, 0.0f, 0.0f);
+			continue;
+		}
+		size_t index = ((size_t) term * p.thread_count + tid) * 3;
+		++term;
+		if (code == kCodeVisible || code == kCodeFinal)
+			sum = sum + mk3(p.terms_visible[index], p.terms_visible[index + 1], p.terms_visible[index + 2]);
+		else if (code == kCodePendingWithHidden)
+			sum = sum + mk3(p.terms_hidden[index], p.terms_hidden[index + 1], p.terms_hidden[index + 2]);
+	}
+	store_final_color(p, out_index, color);
+}
+#endif
 
 }  // namespace vkr

@@ -2,6 +2,7 @@
 // output encoding and read-back behind the reference's entry points
 // (create_shading_pass src/main.c:598, write_constants :2114, the vkCmdDraw of
 // record_render_frame_commands :1428-1434, implement_screenshot :1719).
+#define VKR_WAVEFRONT_KERNELS 1
 #include "shading_kernel.h"
 #include "host/vkr_internal.h"
 #include <hip/hip_fp16.h>
@@ -74,9 +75,60 @@ extern "C" int create_render_targets(render_targets_t* targets, const device_t* 
 // device counter of traced shadow rays, shared by all passes of the process
 static unsigned long long* g_ray_counter = NULL;
 
+// Buffers of the wavefront ray path, sized for the worst case (every sample of every
+// light on every pixel produces a term and a ray) and owned by the pass.
+struct wavefront_buffers {
+	uint8_t* codes;
+	float* terms_visible;
+	float* terms_hidden;
+	float4* ray_queue;
+	uint32_t* ray_queue_size;
+	uint32_t thread_count, max_terms, max_codes, queue_capacity;
+};
+
+static void destroy_wavefront(shading_pass_t* pass) {
+	wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
+	if (!w) return;
+	(void) hipFree(w->codes); (void) hipFree(w->terms_visible); (void) hipFree(w->terms_hidden);
+	(void) hipFree(w->ray_queue); (void) hipFree(w->ray_queue_size);
+	free(w);
+	pass->wavefront = NULL;
+}
+
+static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
+	wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
+	uint32_t max_codes = max_terms + light_count + 2;
+	if (w && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
+	destroy_wavefront(pass);
+	w = (wavefront_buffers*) calloc(1, sizeof(wavefront_buffers));
+	pass->wavefront = w;
+	w->thread_count = thread_count; w->max_terms = max_terms; w->max_codes = max_codes;
+	size_t terms = (size_t) max_terms * thread_count;
+	if (terms >= 0xFFFFFFFFull || (size_t) max_codes * thread_count >= 0xFFFFFFFFull) {
+		printf("The wavefront ray queue would need more than 2^32 entries (%u threads x %u terms); render in tiles or use inline rays.\n", thread_count, max_terms);
+		destroy_wavefront(pass);
+		return 1;
+	}
+	// worst case per queue: every lane of every wave that feeds it emits max_terms rays
+	uint32_t waves = thread_count / 64;
+	w->queue_capacity = ((waves + kRayQueueCount - 1) / kRayQueueCount) * 64u * max_terms;
+	if (hipMalloc(&w->codes, (size_t) max_codes * thread_count) != hipSuccess
+		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
+		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
+		|| hipMalloc(&w->ray_queue, (size_t) w->queue_capacity * kRayQueueCount * 32) != hipSuccess
+		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * kRayQueueCount) != hipSuccess)
+	{
+		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", (terms * 56.0 + (double) max_codes * thread_count) / 1048576.0);
+		destroy_wavefront(pass);
+		return 1;
+	}
+	return 0;
+}
+
 extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
 	vkr_device_free(pass->constants_device, device);
 	vkr_host_free_pinned(pass->constants_host);
+	destroy_wavefront(pass);
 	if (pass->timing_ring) {
 		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
 		for (uint32_t i = 0; i != 2 * pass->timing_ring_size; ++i) if (ring[i]) (void) hipEventDestroy(ring[i]);
@@ -145,9 +197,10 @@ static int create_timing_ring(shading_pass_t* pass) {
 }
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
-	int32_t fast_math = pass->fast_math;
+	int32_t fast_math = pass->fast_math, inline_rays = pass->inline_rays;
 	memset(pass, 0, sizeof(*pass));
 	pass->fast_math = fast_math ? 1 : 0;
+	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->variant = -1;
 	const device_t* device = &app->device;
 	if (validate_settings(app)) return 1;
@@ -250,10 +303,20 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	uint32_t grid_blocks = 0;
 	fill_tile_schedule(p, app, grid_blocks);
+	int ray_mode = !pass->use_ray_tracing ? kRaysNone : (pass->inline_rays ? kRaysInline : kRaysDeferred);
 	if (pass->use_ray_tracing) {
 		if (!g_ray_counter && hip_failed(hipMalloc(&g_ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
 		if (hip_failed(hipMemsetAsync(g_ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 		p.ray_counter = g_ray_counter;
+	}
+	if (ray_mode == kRaysDeferred) {
+		if (ensure_wavefront(pass, grid_blocks * 256u, 2u * p.light_count * p.sample_count, p.light_count)) return 1;
+		wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
+		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden;
+		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
+		p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
+		p.ray_queue_capacity = w->queue_capacity;
+		if (hip_failed(hipMemsetAsync(w->ray_queue_size, 0, sizeof(uint32_t) * kRayQueueCount, stream), "clearing the ray queue")) return 1;
 	}
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
@@ -262,7 +325,14 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
 	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
 	(void) hipEventRecord(ring[2 * slot], stream);
-	int status = g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, pass->use_ray_tracing ? 1 : 0, &p, grid_blocks, stream);
+	int status = g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
+	if (status == 0 && ray_mode == kRaysDeferred) {
+		// enough resident waves to fill the chip; each lane strides over the queue
+		const uint32_t blocks_per_queue = 8;
+		trace_shadow_rays<<<kRayQueueCount * blocks_per_queue, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, blocks_per_queue, p.codes);
+		resolve_shadow_terms<<<grid_blocks, 256, 0, stream>>>(p);
+		status = hipGetLastError() != hipSuccess;
+	}
 	(void) hipEventRecord(ring[2 * slot + 1], stream);
 	++pass->timing_cursor;
 	if (status < 0) {
@@ -301,6 +371,13 @@ extern "C" float get_last_dispatch_milliseconds(application_t* app) {
 extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	unsigned long long rays = 0;
 	if (!g_ray_counter || !app->shading_pass.use_ray_tracing) return 0;
+	if (!app->shading_pass.inline_rays) {
+		const wavefront_buffers* w = (const wavefront_buffers*) app->shading_pass.wavefront;
+		uint32_t queued[kRayQueueCount];
+		if (!w || vkr_copy_to_host(queued, w->ray_queue_size, sizeof(queued), &app->device)) return 0;
+		for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += queued[q];
+		return rays;
+	}
 	if (vkr_copy_to_host(&rays, g_ray_counter, sizeof(rays), &app->device)) return 0;
 	return rays;
 }

@@ -19,14 +19,15 @@
 using namespace vkr;
 
 template <int TECHNIQUE, int V>
-static int launch_rays(bool rays, const shade_params& p, dim3 grid, hipStream_t stream) {
-	if (rays) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, true><<<grid, 256, 0, stream>>>(p);
-	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, false><<<grid, 256, 0, stream>>>(p);
+static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
+	if (rays == kRaysDeferred) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferred><<<grid, 256, 0, stream>>>(p);
+	else if (rays == kRaysInline) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysInline><<<grid, 256, 0, stream>>>(p);
+	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysNone><<<grid, 256, 0, stream>>>(p);
 	return hipGetLastError() != hipSuccess;
 }
 
 template <int TECHNIQUE>
-static int launch_capacity(int capacity, bool rays, const shade_params& p, dim3 grid, hipStream_t stream) {
+static int launch_capacity(int capacity, int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
 	switch (capacity) {
 	case 3: if constexpr (TECHNIQUE == kTechniqueSolidAngle) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
 	case 4: return launch_rays<TECHNIQUE, 4>(rays, p, grid, stream);
@@ -43,13 +44,13 @@ extern "C" int VKR_LAUNCH_NAME(int technique, int capacity, int rays, const shad
 	dim3 grid(grid_x, 1, 1);
 	hipStream_t s = (hipStream_t) stream;
 	switch (technique) {
-	case kTechniquePsa: return launch_capacity<kTechniquePsa>(capacity, rays != 0, *p, grid, s);
-	case kTechniquePsaBiased: return launch_capacity<kTechniquePsaBiased>(capacity, rays != 0, *p, grid, s);
+	case kTechniquePsa: return launch_capacity<kTechniquePsa>(capacity, rays, *p, grid, s);
+	case kTechniquePsaBiased: return launch_capacity<kTechniquePsaBiased>(capacity, rays, *p, grid, s);
 #if VKR_STRATEGY == 0 || VKR_STRATEGY == 1
 	// the solid-angle samplers only pair with these two strategies
 	// (reference shading_pass.frag.glsl:305-323 returns black otherwise)
-	case kTechniqueSolidAngle: return launch_capacity<kTechniqueSolidAngle>(capacity, rays != 0, *p, grid, s);
-	case kTechniqueClippedSolidAngle: return launch_capacity<kTechniqueClippedSolidAngle>(capacity, rays != 0, *p, grid, s);
+	case kTechniqueSolidAngle: return launch_capacity<kTechniqueSolidAngle>(capacity, rays, *p, grid, s);
+	case kTechniqueClippedSolidAngle: return launch_capacity<kTechniqueClippedSolidAngle>(capacity, rays, *p, grid, s);
 #endif
 	default: return -1;
 	}

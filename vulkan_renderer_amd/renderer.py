@@ -171,12 +171,13 @@ class HostScene:
 class Renderer(HostScene):
     """The shading pass on one MI355X."""
 
-    def __init__(self, hip_device=0, stream=None, fast_math=False):
+    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False):
         super().__init__()
         if self.lib.create_hip_device(C.byref(self.app.device), hip_device, stream):
             raise RuntimeError("no usable HIP device: the shading pass has no CPU fallback")
         self._device = True
         self.fast_math = fast_math
+        self.inline_rays = inline_rays
 
     def create_targets(self):
         if self.app.render_targets.radiance:
@@ -188,6 +189,7 @@ class Renderer(HostScene):
         if self.app.shading_pass.constants_device:
             self.lib.destroy_shading_pass(C.byref(self.app.shading_pass), self._dev())
         self.app.shading_pass.fast_math = int(self.fast_math)
+        self.app.shading_pass.inline_rays = int(self.inline_rays)
         if self.lib.create_shading_pass(C.byref(self.app.shading_pass), C.byref(self.app)):
             raise RuntimeError("create_shading_pass failed")
 
