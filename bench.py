@@ -112,7 +112,7 @@ def main():
 
         def step():
             r.render(slab.data_ptr())
-            dist.all_gather_into_tensor(gathered, slab)
+            dist.all_gather_into_tensor(gathered.view(world * slab_pixels, 4), slab)
             r.assemble(gathered.data_ptr(), frame.data_ptr())
     else:
         def step():
