@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-rays", action="store_true", help="disable shadow rays (TRACE_SHADOW_RAYS=0) for experiments")
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
 
@@ -168,6 +169,12 @@ def main():
         except Exception:
             traffic = None
     rays = r.last_ray_count()
+    traversal = None
+    if args.traversal_stats and rays and not args.inline_rays:
+        traversal = r.traversal_statistics()
+        traversal["visits_per_ray"] = round(traversal["node_visits"] / max(traversal["rays"], 1), 2)
+        traversal["tests_per_ray"] = round(traversal["triangle_tests"] / max(traversal["rays"], 1), 2)
+        traversal["lane_use"] = round(traversal["node_visits"] / max(64 * traversal["wave_steps"], 1), 3)
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                 "kernel_ms": round(kernel_avg_ms, 4), "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -237,6 +244,8 @@ def main():
             "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (kernel_avg_ms * 1e-3) / 1e6, 2) if rays else 0.0,
             "roofline": roofline,
         }
+        if traversal:
+            result["traversal"] = traversal
         if cpu_baseline:
             result["cpu_baseline"] = cpu_baseline
             result["speedup_vs_cpu"] = round(value / cpu_baseline["value"], 1)

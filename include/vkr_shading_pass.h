@@ -242,6 +242,11 @@ VKR_API uint32_t get_dispatch_milliseconds(application_t* app, float* out_millis
 	was built without counters) */
 VKR_API uint64_t get_last_ray_count(const application_t* app);
 
+/*! Diagnostics for profiling: replays the shadow rays queued by the last wavefront frame
+	and writes {rays, node visits, triangle tests, blocked rays, wave steps (sum over
+	groups of 64 rays of the longest ray's visits), longest ray's visits}.  0 on success. */
+VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]);
+
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,
 	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,
 	materials_t, acceleration_structure_t, scene_t, scene_specification_t,

@@ -95,7 +95,10 @@ void* oracle_bvh_build(const uint32_t* q, uint64_t triangle_count, const float f
 		}
 	}
 	float extent = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
-	b->pad = 1.0e-4f * extent;
+	for (int j = 0; j != 3; ++j) extent = fmaxf(extent, fmaxf(fabsf(lo[j]), fabsf(hi[j])));
+	/* sixteen times the rounding error of the slab and triangle tests (about 2^-23 of
+	 * the largest coordinate), far below t_min */
+	b->pad = 2.0e-6f * extent;
 	float* centroids = (float*) malloc(sizeof(float) * 3 * triangle_count);
 	b->order = (uint32_t*) malloc(sizeof(uint32_t) * triangle_count);
 	for (uint64_t t = 0; t != triangle_count; ++t) {
@@ -119,22 +122,25 @@ void oracle_bvh_destroy(void* handle) {
 	free(b);
 }
 
-/* The shared ray/triangle predicate.  Comparisons are written so that NaNs miss. */
+/* The shared ray/triangle predicate: Moeller-Trumbore with the division removed
+ * (barycentrics and distance are compared in their det-scaled form, mirrored for
+ * det < 0).  Comparisons are written so that NaNs miss. */
 static int ray_triangle(const float* t, const float o[3], const float d[3], float t_min, float t_max) {
 	float e1[3] = {t[3] - t[0], t[4] - t[1], t[5] - t[2]};
 	float e2[3] = {t[6] - t[0], t[7] - t[1], t[8] - t[2]};
 	float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
 	float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
 	if (!(det != 0.0f)) return 0;
-	float inv = 1.0f / det;
+	float sign = (det < 0.0f) ? -1.0f : 1.0f;
+	float adet = det * sign;
 	float s[3] = {o[0] - t[0], o[1] - t[1], o[2] - t[2]};
-	float u = ((s[0] * p[0] + s[1] * p[1]) + s[2] * p[2]) * inv;
-	if (!(u >= 0.0f && u <= 1.0f)) return 0;
+	float U = ((s[0] * p[0] + s[1] * p[1]) + s[2] * p[2]) * sign;
+	if (!(U >= 0.0f && U <= adet)) return 0;
 	float q[3] = {s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0]};
-	float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv;
-	if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
-	float dist = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv;
-	return dist >= t_min && dist <= t_max;
+	float V = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * sign;
+	if (!(V >= 0.0f && U + V <= adet)) return 0;
+	float T = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * sign;
+	return T >= t_min * adet && T <= t_max * adet;
 }
 
 static int ray_box(const bvh_node_t* n, const float o[3], const float inv[3], float t_min, float t_max) {
@@ -187,16 +193,16 @@ static int ray_triangle_front(const float* t, const float o[3], const float d[3]
 	float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
 	float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
 	if (!(det > 0.0f)) return 0;
-	float inv = 1.0f / det;
 	float s[3] = {o[0] - t[0], o[1] - t[1], o[2] - t[2]};
-	float u = ((s[0] * p[0] + s[1] * p[1]) + s[2] * p[2]) * inv;
-	if (!(u >= 0.0f && u <= 1.0f)) return 0;
+	float U = ((s[0] * p[0] + s[1] * p[1]) + s[2] * p[2]) * 1.0f;
+	if (!(U >= 0.0f && U <= det)) return 0;
 	float q[3] = {s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0]};
-	float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv;
-	if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
-	float dist = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv;
-	*out_dist = dist;
-	return dist >= t_min && dist <= t_max;
+	float V = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * 1.0f;
+	if (!(V >= 0.0f && U + V <= det)) return 0;
+	float T = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * 1.0f;
+	if (!(T >= t_min * det && T <= t_max * det)) return 0;
+	*out_dist = T / det;
+	return 1;
 }
 
 uint32_t oracle_bvh_closest_front_hit(const void* handle, const float o[3], const float d[3], float t_min, float t_max) {

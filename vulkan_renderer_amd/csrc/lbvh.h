@@ -40,9 +40,12 @@ struct bvh_view {
 	uint32_t node_count;      // 2 * triangle_count - 1
 };
 
-// Moeller-Trumbore, fp32, same operation order as oracle/oracle_bvh.c ray_triangle.
-// CULL_BACK additionally rejects triangles whose normal (v1-v0)x(v2-v0) points
-// along the ray (det <= 0).  Returns the distance through `dist`.
+// Moeller-Trumbore without the division, fp32, same operation order as
+// oracle/oracle_bvh.c ray_triangle: with det = e1 . (d x e2) the barycentrics u, v and
+// the distance t are compared in their det-scaled form (U = u det, V = v det, T = t det)
+// and all comparisons are mirrored for det < 0.  No face culling unless CULL_BACK
+// (then triangles whose normal (v1-v0)x(v2-v0) points along the ray are rejected).
+// `dist` (only needed by the closest-hit query) is T / det.
 template <bool CULL_BACK>
 VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_min, float t_max, float& dist) {
 	f3 e1 = mk3(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
@@ -50,15 +53,18 @@ VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_m
 	f3 p = cross(d, e2);
 	float det = dot(e1, p);
 	if (CULL_BACK ? !(det > 0.0f) : !(det != 0.0f)) return false;
-	float inv = rcp(det);
+	float sign = (det < 0.0f) ? -1.0f : 1.0f;
+	float adet = det * sign;
 	f3 s = mk3(o.x - p0.x, o.y - p0.y, o.z - p0.z);
-	float u = dot(s, p) * inv;
-	if (!(u >= 0.0f && u <= 1.0f)) return false;
+	float U = dot(s, p) * sign;
+	if (!(U >= 0.0f && U <= adet)) return false;
 	f3 q = cross(s, e1);
-	float v = dot(d, q) * inv;
-	if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-	dist = dot(e2, q) * inv;
-	return dist >= t_min && dist <= t_max;
+	float V = dot(d, q) * sign;
+	if (!(V >= 0.0f && U + V <= adet)) return false;
+	float T = dot(e2, q) * sign;
+	if (!(T >= t_min * adet && T <= t_max * adet)) return false;
+	if (CULL_BACK) dist = T / adet;
+	return true;
 }
 
 // Conservative slab test; boxes are padded at build time, so approximate

@@ -193,11 +193,17 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	for (int j = 0; j != 3; ++j) {
 		p.factor[j] = mesh->dequantization_factor[j];
 		p.summand[j] = mesh->dequantization_summand[j];
+		// largest coordinate magnitude and extent of the quantisation grid
 		extent = fmaxf(extent, 2097152.0f * fabsf(mesh->dequantization_factor[j]));
+		extent = fmaxf(extent, fmaxf(fabsf(mesh->dequantization_summand[j]), fabsf(mesh->dequantization_summand[j] + 2097152.0f * mesh->dequantization_factor[j])));
 	}
-	// conservative padding: the triangle test may accept hits a few ulps outside
-	// the exact bounds
-	p.pad = 1.0e-4f * extent;
+	// Conservative padding.  The slab test evaluates plane * (1/d) - o * (1/d) with a
+	// 1-ulp reciprocal and two roundings, i.e. it misplaces a plane by about
+	// |o| 2^-23; the triangle test may accept hits about as far outside the triangle.
+	// 2e-6 of the largest coordinate is sixteen times that.  (The padding must stay
+	// far below t_min = 1e-3: a ray leaving a flat floor would otherwise start inside
+	// the padded boxes of the floor and walk down to its own triangle.)
+	p.pad = 2.0e-6f * extent;
 	uint32_t inner_count = n > 1 ? n - 1 : 1;
 	uint32_t total_nodes = 2 * n - 1;
 	bvh_build_node* build_nodes = NULL;

@@ -56,14 +56,19 @@ struct shade_params {
 	float* terms_visible;
 	float* terms_hidden;
 	// kRayQueueCount independent queues, each with its own counter (one counter for the
-	// whole chip saturates at ~88 atomics / us); wave w appends to queue w % count
+	// whole chip saturates at ~88 atomics / us).  Each XCD owns 64 of them: they are filled
+	// by the shading workgroups and drained by the tracing workgroups of that XCD only.
 	float4* ray_queue;
 	uint32_t* ray_queue_size;
 	uint32_t ray_queue_capacity;
 	uint32_t thread_count, max_terms, max_codes;
+	// tuning knobs (host: environment, see shading_pass.hip)
+	uint32_t refill_threshold;
 };
 
-constexpr uint32_t kRayQueueCount = 256;
+constexpr uint32_t kRayQueueCount = 512;  // 8 XCDs x 64 (one queue per lane when scanning sizes)
+constexpr uint32_t kCursorStride = 32;    // one 128-byte line per XCD work cursor
+constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic in trace_shadow_rays
 
 // How shadow rays are traced (template parameter RAYS):
 //   kRaysNone      TRACE_SHADOW_RAYS = 0
@@ -424,6 +429,7 @@ struct pixel_context {
 	// deferred mode: this thread's slot in the term streams and its write cursors
 	uint32_t tid, code_cursor, term_cursor;
 	bool light_has_terms;
+	uint32_t queue;
 };
 
 // get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231, without
@@ -442,10 +448,9 @@ VKR_DEV bool all_zero(f3 v) { return ((__float_as_uint(v.x) | __float_as_uint(v.
 
 // Appends one shadow ray to the global queue.  Lanes of the wave that arrive here
 // together reserve their slots with ONE atomic: ballot -> popcount -> lane prefix.
-VKR_DEV void push_ray(const shade_params& p, f3 origin, f3 dir, float t_max, uint32_t code_index) {
+VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 origin, f3 dir, float t_max, uint32_t code_index) {
 	uint64_t mask = __ballot(1);
 	uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-	uint32_t queue = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kRayQueueCount;
 	uint32_t base = 0;
 	if (prefix == 0) base = atomicAdd(p.ray_queue_size + queue, (uint32_t) __popcll(mask));
 	base = __builtin_amdgcn_readfirstlane(base);
@@ -488,7 +493,7 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 			}
 			if (needs_ray) {
 				float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
-				push_ray(p, sd.position, dir, max_t, (uint32_t) code_index);
+				push_ray(p, ctx.queue, sd.position, dir, max_t, (uint32_t) code_index);
 			}
 			++ctx.code_cursor;
 			++ctx.term_cursor;
@@ -816,7 +821,10 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 	uint32_t px, py;
 	size_t out_index;
 	bool inside = locate_pixel(p, px, py, out_index);
-	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false};
+	// ray queue of this wave: workgroup b runs on XCD b % 8 and uses one of the 64 queues
+	// of that XCD, so a queue counter's cache line is only ever touched from one L2
+	uint32_t queue = (blockIdx.x & 7u) * 64u + (((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)) & 63u);
+	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false, queue};
 	if (inside) {
 		const uint8_t* c = p.constants;
 		uint32_t primitive = p.visibility[(size_t) py * p.width + px];
@@ -874,18 +882,109 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 // ---- wavefront: trace and resolve (instantiated once, in shading_pass.hip) -------------------
 #ifdef VKR_WAVEFRONT_KERNELS
 
-// One shadow ray per lane, grid-stride over the compacted queue.  Few registers,
-// no LDS, no scratch: many waves per SIMD hide the latency of the dependent node
-// fetches.  A visible ray flips its term's code to kCodeVisible.
-__global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t blocks_per_queue, uint8_t* codes) {
-	uint32_t queue = blockIdx.x / blocks_per_queue, part = blockIdx.x - queue * blocks_per_queue;
-	uint32_t count = ray_queue_size[queue];
-	const float4* rays = ray_queue + 2 * (size_t) queue * ray_queue_capacity;
-	uint32_t stride = blocks_per_queue * 256u;
-	for (uint32_t i = part * 256u + threadIdx.x; i < count; i += stride) {
-		float4 a = rays[2 * (size_t) i], b = rays[2 * (size_t) i + 1];
-		if (!any_hit(bvh, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 1.0e-3f, a.w))
-			codes[__float_as_uint(b.w)] = (uint8_t) kCodeVisible;
+// Persistent waves trace the queued shadow rays.  Few registers, no LDS, no scratch:
+// 8 waves per SIMD hide the latency of the dependent node fetches.
+//  - Queues 64 x ... 64 x + 63 are served only by workgroups that run on XCD x
+//    (workgroup b is placed on XCD b % 8; used for cache affinity only, never for
+//    correctness), so counters and cursors never bounce between the eight L2s.
+//  - A wave claims kRayChunk rays with one atomic on its XCD's cursor and locates
+//    the chunk with a wave-wide prefix sum over the 64 queue sizes of that XCD.
+//  - Lanes whose ray has finished are refilled from the chunk while the others keep
+//    walking (shadow rays differ a lot in length), so lanes stay busy.
+// A ray that reaches the light flips its term's code to kCodeVisible.
+__global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t refill_threshold) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t xcd = blockIdx.x & 7u;
+	// exclusive prefix sum of the chunk counts of this XCD's 64 queues, one queue per lane
+	const uint32_t my_queue = xcd * 64u + lane;
+	const uint32_t my_size = ray_queue_size[my_queue];
+	// chunk size: large enough to keep the atomics rare, small enough that every resident
+	// wave of this XCD gets about two chunks (few rays: config 2 queues 0.9 M, config 3 29 M)
+	uint32_t xcd_rays = my_size;
+#pragma unroll
+	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
+	const uint32_t xcd_waves = (gridDim.x / 8u) * 4u;
+	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
+	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
+	uint32_t inclusive = my_chunks;
+#pragma unroll
+	for (int offset = 1; offset < 64; offset <<= 1) {
+		uint32_t other = __shfl_up(inclusive, offset);
+		if (lane >= (uint32_t) offset) inclusive += other;
+	}
+	const uint32_t exclusive = inclusive - my_chunks;
+	const uint32_t total_chunks = __shfl(inclusive, 63);
+	const uint32_t end = bvh.node_count;
+	// wave-uniform description of the claimed chunk
+	const float4* chunk_rays = ray_queue;
+	uint32_t chunk_count = 0, chunk_next = 0;
+	bool chunks_left = true;
+	// per-lane ray
+	bool active = false;
+	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, inv = o, shift = o;
+	float t_max = 0.0f;
+	uint32_t node = 0, code_index = 0;
+	while (true) {
+		// ---- hand new rays to idle lanes ------------------------------------------------
+		uint64_t idle = __ballot(!active);
+		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
+			if (chunk_next >= chunk_count) {
+				uint32_t chunk = 0;
+				if (lane == 0) chunk = atomicAdd(work_cursors + xcd * kCursorStride, 1u);
+				chunk = __builtin_amdgcn_readfirstlane(chunk);
+				if (chunk >= total_chunks) { chunks_left = false; break; }
+				uint64_t owner = __ballot(my_chunks != 0 && exclusive <= chunk && chunk < inclusive);
+				int owner_lane = __ffsll((unsigned long long) owner) - 1;
+				uint32_t queue = xcd * 64u + (uint32_t) owner_lane;
+				uint32_t first = (chunk - __shfl(exclusive, owner_lane)) * chunk_size;
+				uint32_t size = __shfl(my_size, owner_lane);
+				chunk_rays = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + first);
+				chunk_count = min(chunk_size, size - first);
+				chunk_next = 0;
+			}
+			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+			uint32_t index = chunk_next + rank;
+			if (!active && index < chunk_count) {
+				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
+				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
+				code_index = __float_as_uint(b.w);
+				inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+				shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+				node = 0;
+				active = true;
+				if (!(t_max >= 1.0e-3f)) {
+					// empty interval: nothing can block the ray (same rule as any_hit)
+					codes[code_index] = (uint8_t) kCodeVisible;
+					active = false;
+				}
+			}
+			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
+			idle = __ballot(!active);
+		}
+		uint64_t busy = __ballot(active);
+		if (busy == 0) break;
+		// ---- walk until too many lanes have run dry (then refill) -------------------------
+		bool may_refill = chunk_next < chunk_count || chunks_left;
+		do {
+			if (active) {
+				float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
+				uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
+				bool hit = ray_box(a, b, inv, shift, 1.0e-3f, t_max);
+				bool blocked = false;
+				if (hit && leaf != kNoLeaf) {
+					const float4* t = bvh.triangles + 3 * (size_t) leaf;
+					float dist;
+					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
+				}
+				node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
+				if (blocked) active = false;
+				else if (node >= end) {
+					codes[code_index] = (uint8_t) kCodeVisible;
+					active = false;
+				}
+			}
+			busy = __ballot(active);
+		} while (busy != 0 && (!may_refill || __popcll((unsigned long long) busy) > refill_threshold));
 	}
 }
 

@@ -82,7 +82,7 @@ struct wavefront_buffers {
 	float* terms_visible;
 	float* terms_hidden;
 	float4* ray_queue;
-	uint32_t* ray_queue_size;
+	uint32_t* ray_queue_size;  // kRayQueueCount sizes followed by 8 per-XCD work cursors
 	uint32_t thread_count, max_terms, max_codes, queue_capacity;
 };
 
@@ -95,9 +95,10 @@ static void destroy_wavefront(shading_pass_t* pass) {
 	pass->wavefront = NULL;
 }
 
-static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
+static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_t max_terms, uint32_t light_count, uint32_t width, uint32_t height) {
 	wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
 	uint32_t max_codes = max_terms + light_count + 2;
+	(void) width; (void) height;
 	if (w && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
 	destroy_wavefront(pass);
 	w = (wavefront_buffers*) calloc(1, sizeof(wavefront_buffers));
@@ -109,14 +110,14 @@ static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_
 		destroy_wavefront(pass);
 		return 1;
 	}
-	// worst case per queue: every lane of every wave that feeds it emits max_terms rays
-	uint32_t waves = thread_count / 64;
-	w->queue_capacity = ((waves + kRayQueueCount - 1) / kRayQueueCount) * 64u * max_terms;
+	// a queue sees every 512th wave (8 XCDs x 64 queues, waves dealt round-robin), every
+	// lane of which may emit max_terms rays
+	w->queue_capacity = ((thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * 64u * max_terms;
 	if (hipMalloc(&w->codes, (size_t) max_codes * thread_count) != hipSuccess
 		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
 		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
 		|| hipMalloc(&w->ray_queue, (size_t) w->queue_capacity * kRayQueueCount * 32) != hipSuccess
-		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * kRayQueueCount) != hipSuccess)
+		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * (kRayQueueCount + 8 * kCursorStride)) != hipSuccess)
 	{
 		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", (terms * 56.0 + (double) max_codes * thread_count) / 1048576.0);
 		destroy_wavefront(pass);
@@ -310,13 +311,15 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		p.ray_counter = g_ray_counter;
 	}
 	if (ray_mode == kRaysDeferred) {
-		if (ensure_wavefront(pass, grid_blocks * 256u, 2u * p.light_count * p.sample_count, p.light_count)) return 1;
+		if (ensure_wavefront(pass, grid_blocks * 256u, 2u * p.light_count * p.sample_count, p.light_count, p.width, p.height)) return 1;
 		wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
 		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden;
 		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
 		p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
 		p.ray_queue_capacity = w->queue_capacity;
-		if (hip_failed(hipMemsetAsync(w->ray_queue_size, 0, sizeof(uint32_t) * kRayQueueCount, stream), "clearing the ray queue")) return 1;
+		const char* knob = getenv("VKR_REFILL_THRESHOLD");
+		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
+		if (hip_failed(hipMemsetAsync(w->ray_queue_size, 0, sizeof(uint32_t) * (kRayQueueCount + 8 * kCursorStride), stream), "clearing the ray queue")) return 1;
 	}
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
@@ -328,8 +331,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	int status = g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
 	if (status == 0 && ray_mode == kRaysDeferred) {
 		// enough resident waves to fill the chip; each lane strides over the queue
-		const uint32_t blocks_per_queue = 8;
-		trace_shadow_rays<<<kRayQueueCount * blocks_per_queue, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, blocks_per_queue, p.codes);
+		// persistent: 8 waves per SIMD on every CU
+		uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
+		trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
 		resolve_shadow_terms<<<grid_blocks, 256, 0, stream>>>(p);
 		status = hipGetLastError() != hipSuccess;
 	}
@@ -366,6 +370,70 @@ extern "C" float get_last_dispatch_milliseconds(application_t* app) {
 	if (get_dispatch_milliseconds(app, &ms, 1) != 1) return 0.0f;
 	app->shading_pass.last_dispatch_ms = ms;
 	return ms;
+}
+
+// Diagnostics: replays the rays that the last frame queued and counts the work of the
+// traversal (profiles/ cites these numbers; not part of the frame).
+__global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, const float4* ray_queue, const uint32_t* ray_queue_size, uint32_t ray_queue_capacity, unsigned long long* out) {
+	uint32_t queue = blockIdx.y;
+	uint32_t size = ray_queue_size[queue];
+	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ((size + 63u) & ~63u); i += gridDim.x * 256u) {
+		uint32_t my_visits = 0;
+		if (i < size) {
+			const float4* r = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + i);
+			float4 a = r[0], b = r[1];
+			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
+			float t_max = a.w;
+			f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+			f3 shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+			uint32_t node = 0;
+			bool blocked = false;
+			++rays;
+			while (t_max >= 1.0e-3f && node < bvh.node_count && !blocked) {
+				float4 na = bvh.nodes[2 * (size_t) node], nb = bvh.nodes[2 * (size_t) node + 1];
+				uint32_t skip = __float_as_uint(nb.z), leaf = __float_as_uint(nb.w);
+				bool hit = ray_box(na, nb, inv, shift, 1.0e-3f, t_max);
+				++my_visits;
+				if (hit && leaf != kNoLeaf) {
+					const float4* t = bvh.triangles + 3 * (size_t) leaf;
+					float dist;
+					++tests;
+					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
+				}
+				node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
+			}
+			blocked_rays += blocked ? 1 : 0;
+		}
+		visits += my_visits;
+		// steps the wave needs for these 64 rays = longest ray
+		uint32_t longest = my_visits;
+		for (int offset = 32; offset > 0; offset >>= 1) longest = max(longest, (uint32_t) __shfl_xor((int) longest, offset));
+		if ((threadIdx.x & 63u) == 0) wave_steps += longest;
+		atomicMax(out + 5, (unsigned long long) my_visits);
+	}
+	atomicAdd(out + 0, rays); atomicAdd(out + 1, visits); atomicAdd(out + 2, tests);
+	atomicAdd(out + 3, blocked_rays); atomicAdd(out + 4, wave_steps);
+}
+
+extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]) {
+	const wavefront_buffers* w = (const wavefront_buffers*) app->shading_pass.wavefront;
+	if (!w || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays) {
+		printf("get_traversal_statistics() needs a frame rendered with wavefront shadow rays.\n");
+		return 1;
+	}
+	unsigned long long* counters = NULL;
+	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 6), "allocating traversal counters")) return 1;
+	hipStream_t stream = (hipStream_t) app->device.stream;
+	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 6, stream);
+	bvh_view bvh;
+	bvh.nodes = (const float4*) app->scene.acceleration_structure.nodes;
+	bvh.triangles = (const float4*) app->scene.acceleration_structure.triangle_vertices;
+	bvh.node_count = app->scene.acceleration_structure.node_count;
+	k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size, w->queue_capacity, counters);
+	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 6, &app->device);
+	(void) hipFree(counters);
+	return failed;
 }
 
 extern "C" uint64_t get_last_ray_count(const application_t* app) {

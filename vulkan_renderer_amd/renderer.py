@@ -221,6 +221,14 @@ class Renderer(HostScene):
     def last_ray_count(self):
         return int(self.lib.get_last_ray_count(C.byref(self.app)))
 
+    def traversal_statistics(self):
+        """Work of the BVH traversal for the rays of the last wavefront frame (diagnostics)."""
+        out = (C.c_uint64 * 6)()
+        if self.lib.get_traversal_statistics(C.byref(self.app), out):
+            raise RuntimeError("get_traversal_statistics failed")
+        keys = ("rays", "node_visits", "triangle_tests", "blocked_rays", "wave_steps", "longest_ray_visits")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def sync(self):
         self.lib.wait_for_device(C.byref(self.app.device))
 
