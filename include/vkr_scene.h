@@ -65,7 +65,10 @@ VKR_API const char* get_material_texture_suffix(material_texture_type_t type);
 /*! reference scene.h:181 / scene.c:409-559.  texture_path/<material>_<suffix>.vkt
 	files are read when present (uncompressed float / half formats only; the
 	smallest mip level supplies the constant), otherwise defaults apply: base
-	colour 0.8, specular (1, 0.5, 0), flat normal. */
+	colour 0.8, specular (1, 0.5, 0), flat normal.
+	request_acceleration_structure: VK_FALSE none, VK_TRUE the fast-trace build (SAH on
+	the host, the counterpart of PREFER_FAST_TRACE at scene.c:254-262), 2 the fast-build
+	variant (Morton-code LBVH on the device). */
 VKR_API int load_scene(scene_t* scene, const device_t* device, const char* file_path, const char* texture_path, VkBool32 request_acceleration_structure);
 /*! reference scene.h:184 */
 VKR_API void destroy_scene(scene_t* scene, const device_t* device);

@@ -198,7 +198,7 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 			return 1;
 		}
 		if (request_acceleration_structure && device->ray_tracing_supported) {
-			if (vkr_build_acceleration_structure(&scene->acceleration_structure, device, mesh)) {
+			if (vkr_build_acceleration_structure(&scene->acceleration_structure, device, mesh, (int) request_acceleration_structure)) {
 				printf("Failed to construct an acceleration structure for the scene file at path %s.\n", file_path);
 				destroy_scene(scene, device);
 				return 1;

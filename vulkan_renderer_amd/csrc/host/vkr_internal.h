@@ -34,8 +34,13 @@ void vkr_matrix_inverse(float inverse[4][4], const float matrix[4][4]);
 /*! reference math_utilities.h:50-57 */
 uint32_t vkr_wang_random_number(uint32_t seed);
 
-/*! LBVH construction and kernels live on the HIP side (the .hip files in csrc) */
-int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh);
+/*! Builds the threaded BVH (csrc/lbvh.h) over the mesh.  builder 1: surface-area
+	heuristic on the host (sah_bvh.c; best traversal), builder 2: Morton-code LBVH on the
+	device (lbvh_build.hip; build time about a millisecond).  The environment variable
+	VKR_BVH_BUILDER=sah|lbvh overrides the argument. */
+int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh, int builder);
+/*! sah_bvh.c: malloc'ed nodes (8 floats each, depth-first) and triangles (12 floats per leaf slot) */
+int vkr_build_sah_bvh_host(const mesh_t* mesh, float pad, float** out_nodes, float** out_triangles, uint32_t* out_node_count);
 void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, const device_t* device);
 
 #ifdef __cplusplus

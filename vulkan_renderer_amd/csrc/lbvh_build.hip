@@ -178,8 +178,11 @@ extern "C" void vkr_destroy_acceleration_structure(acceleration_structure_t* str
 	memset(structure, 0, sizeof(*structure));
 }
 
-extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh) {
+extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh, int builder) {
 	memset(structure, 0, sizeof(*structure));
+	const char* requested = getenv("VKR_BVH_BUILDER");
+	if (requested && strcmp(requested, "lbvh") == 0) builder = 2;
+	if (requested && strcmp(requested, "sah") == 0) builder = 1;
 	if (mesh->triangle_count > 0x7FFFFFFFull) {
 		printf("The LBVH supports at most 2^31 triangles.\n");
 		return 1;
@@ -204,6 +207,26 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	// far below t_min = 1e-3: a ray leaving a flat floor would otherwise start inside
 	// the padded boxes of the floor and walk down to its own triangle.)
 	p.pad = 2.0e-6f * extent;
+	if (builder != 2) {
+		// surface-area heuristic on the host, then one upload
+		float *host_nodes = NULL, *host_triangles = NULL;
+		uint32_t node_count = 0;
+		if (vkr_build_sah_bvh_host(mesh, p.pad, &host_nodes, &host_triangles, &node_count)) {
+			printf("Building the SAH BVH over %u triangles failed (out of memory or no host copy of the positions).\n", n);
+			return 1;
+		}
+		int upload_failed = vkr_device_upload(&structure->nodes, device, host_nodes, sizeof(float) * 8 * (size_t) node_count, "BVH nodes")
+			|| vkr_device_upload(&structure->triangle_vertices, device, host_triangles, sizeof(float) * 12 * (size_t) n, "BVH triangles");
+		free(host_nodes);
+		free(host_triangles);
+		if (upload_failed) {
+			vkr_destroy_acceleration_structure(structure, device);
+			return 1;
+		}
+		structure->node_count = node_count;
+		structure->root = 0;
+		return 0;
+	}
 	uint32_t inner_count = n > 1 ? n - 1 : 1;
 	uint32_t total_nodes = 2 * n - 1;
 	bvh_build_node* build_nodes = NULL;
