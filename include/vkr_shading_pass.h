@@ -140,10 +140,13 @@ typedef struct shading_pass_s {
 	int32_t variant;
 	/*! MAX_POLYGON_VERTEX_COUNT of the selected variant (main.c:194-216) */
 	uint32_t max_polygon_vertex_count;
-	/*! device + pinned host staging copy of the constant buffer */
+	/*! device + pinned host staging copy of the constant buffer of the most recent
+		frame (one slot of constants_ring) */
 	void* constants_device;
 	void* constants_host;
 	size_t constants_size;
+	/*! ring of constant buffers, one per set of constants in flight */
+	void* constants_ring;
 	/*! arithmetic mode: 0 = exact (IEEE division/sqrt, no contraction; bit-comparable
 		with the CPU oracle), 1 = fast (approximate reciprocals, contraction) */
 	int32_t fast_math;

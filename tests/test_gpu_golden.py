@@ -137,3 +137,30 @@ def test_missing_variant_and_bad_settings_fail_loudly(golden_dataset):
     r.app.render_settings.sampling_strategies = 0  # changing the variant without recreating the pass
     assert r.lib.render_shading_pass(C.byref(r.app), None) == 1
     r.close()
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_keep_their_own_constants(golden_dataset):
+    """The host records frames without waiting for the device; every frame must see the
+    constants that write_constants produced for it (ring of constant buffers), and a
+    frame with unchanged constants must reuse them (no stale or future data)."""
+    case = golden_cases.FRAME_CASES[3]
+    r, _ = render_case(case, golden_dataset, False, 200, 120)
+    exposures = [0.5, 0.5, 2.0, 3.0, 3.0, 4.0, 5.0, 6.0, 6.0, 7.0]
+    expected = []
+    for e in sorted(set(exposures)):
+        r.app.render_settings.exposure_factor = e
+        r.render()
+        r.sync()
+        expected.append((e, r.read_radiance()))
+    expected = dict(expected)
+    buffers = [DeviceBuffer(120 * 200 * 16) for _ in exposures]
+    for e, b in zip(exposures, buffers):  # no synchronisation between these launches
+        r.app.render_settings.exposure_factor = e
+        r.render(b.ptr.value)
+    r.sync()
+    for e, b in zip(exposures, buffers):
+        got = b.download((120, 200, 4), np.float32)
+        assert np.array_equal(got.view(np.uint32), expected[e].view(np.uint32)), e
+        b.free()
+    r.close()

@@ -68,6 +68,7 @@ struct shade_params {
 
 constexpr uint32_t kRayQueueCount = 512;  // 8 XCDs x 64 (one queue per lane when scanning sizes)
 constexpr uint32_t kCursorStride = 32;    // one 128-byte line per XCD work cursor
+constexpr uint32_t kRayCounterCount = kRayQueueCount + 8 * kCursorStride;  // queue sizes, then cursors
 constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic in trace_shadow_rays
 
 // How shadow rays are traced (template parameter RAYS):
@@ -991,7 +992,7 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 // Replays every pixel's sums in the order of the shading program: terms of one light
 // are added one after the other, the light's sum is scaled by 1 / SAMPLE_COUNT and
 // added to the colour (shading_pass.frag.glsl:710, :858), then NaN check and exposure.
-__global__ void __launch_bounds__(256) resolve_shadow_terms(const shade_params p) {
+VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 	uint32_t px, py;
 	size_t out_index;
 	if (!locate_pixel(p, px, py, out_index)) return;
@@ -1017,6 +1018,19 @@ __global__ void __launch_bounds__(256) resolve_shadow_terms(const shade_params p
 			sum = sum + mk3(p.terms_hidden[index], p.terms_hidden[index + 1], p.terms_hidden[index + 2]);
 	}
 	store_final_color(p, out_index, color);
+}
+
+// Leaves the ray queues empty for the next frame (saves two fill launches per frame) and
+// keeps a copy of the counters for get_last_ray_count() / get_traversal_statistics().
+__global__ void __launch_bounds__(256) resolve_shadow_terms_and_reset(const shade_params p) {
+	resolve_shadow_terms_body(p);
+	if (blockIdx.x == 0) {
+		uint32_t* counters = const_cast<uint32_t*>(p.ray_queue_size);
+		for (uint32_t i = threadIdx.x; i < kRayCounterCount; i += 256u) {
+			counters[kRayCounterCount + i] = counters[i];
+			counters[i] = 0;
+		}
+	}
 }
 #endif
 

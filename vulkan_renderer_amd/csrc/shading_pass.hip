@@ -82,7 +82,7 @@ struct wavefront_buffers {
 	float* terms_visible;
 	float* terms_hidden;
 	float4* ray_queue;
-	uint32_t* ray_queue_size;  // kRayQueueCount sizes followed by 8 per-XCD work cursors
+	uint32_t* ray_queue_size;  // kRayCounterCount live counters (queue sizes, per-XCD work cursors), then last frame's copy
 	uint32_t thread_count, max_terms, max_codes, queue_capacity;
 };
 
@@ -117,7 +117,8 @@ static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_
 		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
 		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
 		|| hipMalloc(&w->ray_queue, (size_t) w->queue_capacity * kRayQueueCount * 32) != hipSuccess
-		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * (kRayQueueCount + 8 * kCursorStride)) != hipSuccess)
+		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess
+		|| hipMemset(w->ray_queue_size, 0, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess)
 	{
 		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", (terms * 56.0 + (double) max_codes * thread_count) / 1048576.0);
 		destroy_wavefront(pass);
@@ -126,9 +127,78 @@ static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_
 	return 0;
 }
 
+// The constant buffer is a small ring: the host may record several frames ahead, so
+// every set of constants in flight needs its own staging and device copy (the reference
+// keeps one uniform buffer per swapchain image for the same reason, main.c:330-360).
+// A frame whose constants are byte-identical to the previous frame's reuses the slot
+// that is already on the device (static camera and lights: no upload at all, like the
+// reference's host-coherent uniform buffer, which costs no GPU time either).
+constexpr uint32_t kConstantSlots = 4;
+struct constants_ring {
+	void* host[kConstantSlots];
+	void* device[kConstantSlots];
+	hipEvent_t consumed[kConstantSlots];
+	bool in_flight[kConstantSlots];
+	void* scratch;    // write_constants target before it is known whether anything changed
+	uint32_t current; // slot whose device copy the next launch reads
+	bool valid;       // false until the first upload
+};
+
+static void destroy_constants_ring(shading_pass_t* pass, const device_t* device) {
+	constants_ring* ring = (constants_ring*) pass->constants_ring;
+	if (!ring) return;
+	for (uint32_t i = 0; i != kConstantSlots; ++i) {
+		vkr_device_free(ring->device[i], device);
+		vkr_host_free_pinned(ring->host[i]);
+		if (ring->consumed[i]) (void) hipEventDestroy(ring->consumed[i]);
+	}
+	free(ring->scratch);
+	free(ring);
+	pass->constants_ring = NULL;
+	pass->constants_device = pass->constants_host = NULL;
+}
+
+static int create_constants_ring(shading_pass_t* pass, const device_t* device) {
+	constants_ring* ring = (constants_ring*) calloc(1, sizeof(constants_ring));
+	pass->constants_ring = ring;
+	if (!ring) return 1;
+	ring->scratch = calloc(1, pass->constants_size);
+	if (!ring->scratch) return 1;
+	for (uint32_t i = 0; i != kConstantSlots; ++i) {
+		if (vkr_device_alloc(&ring->device[i], device, pass->constants_size, "the constant buffer")
+			|| vkr_host_alloc_pinned(&ring->host[i], pass->constants_size)
+			|| hip_failed(hipEventCreateWithFlags(&ring->consumed[i], hipEventDisableTiming), "creating upload events"))
+			return 1;
+		memset(ring->host[i], 0, pass->constants_size);
+	}
+	pass->constants_device = ring->device[0];
+	pass->constants_host = ring->host[0];
+	return 0;
+}
+
+// write_constants and, if the bytes changed, upload them into the next free slot
+static int upload_constants(application_t* app, hipStream_t stream) {
+	shading_pass_t* pass = &app->shading_pass;
+	constants_ring* ring = (constants_ring*) pass->constants_ring;
+	write_constants(ring->scratch, app);
+	if (ring->valid && memcmp(ring->scratch, ring->host[ring->current], pass->constants_size) == 0) return 0;
+	uint32_t slot = ring->valid ? (ring->current + 1) % kConstantSlots : 0;
+	// everything launched so far may read the old slot: it is free again once the stream
+	// has passed this point
+	if (ring->valid) ring->in_flight[ring->current] = hipEventRecord(ring->consumed[ring->current], stream) == hipSuccess;
+	if (ring->in_flight[slot] && hip_failed(hipEventSynchronize(ring->consumed[slot]), "waiting for a free constant buffer")) return 1;
+	ring->in_flight[slot] = false;
+	memcpy(ring->host[slot], ring->scratch, pass->constants_size);
+	if (hip_failed(hipMemcpyAsync(ring->device[slot], ring->host[slot], pass->constants_size, hipMemcpyHostToDevice, stream), "uploading the constants")) return 1;
+	ring->current = slot;
+	ring->valid = true;
+	pass->constants_device = ring->device[slot];
+	pass->constants_host = ring->host[slot];
+	return 0;
+}
+
 extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
-	vkr_device_free(pass->constants_device, device);
-	vkr_host_free_pinned(pass->constants_host);
+	destroy_constants_ring(pass, device);
 	destroy_wavefront(pass);
 	if (pass->timing_ring) {
 		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
@@ -211,15 +281,12 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	pass->max_polygon_vertex_count = get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings);
 	pass->variant = (int32_t) app->render_settings.sampling_strategies * 4 + technique_index(app->render_settings.polygon_sampling_technique);
 	pass->constants_size = get_constant_buffer_size(app);
-	if (vkr_device_alloc(&pass->constants_device, device, pass->constants_size, "the constant buffer")
-		|| vkr_host_alloc_pinned(&pass->constants_host, pass->constants_size)
-		|| create_timing_ring(pass))
+	if (create_constants_ring(pass, device) || create_timing_ring(pass))
 	{
 		printf("Failed to create the shading pass.\n");
 		destroy_shading_pass(pass, device);
 		return 1;
 	}
-	memset(pass->constants_host, 0, pass->constants_size);
 	return 0;
 }
 
@@ -266,8 +333,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		return 1;
 	}
 	hipStream_t stream = (hipStream_t) device->stream;
-	write_constants(pass->constants_host, app);
-	if (vkr_copy_to_device_async(pass->constants_device, pass->constants_host, pass->constants_size, device)) return 1;
+	if (upload_constants(app, stream)) return 1;
 	shade_params p;
 	memset(&p, 0, sizeof(p));
 	p.constants = (const uint8_t*) pass->constants_device;
@@ -307,7 +373,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	int ray_mode = !pass->use_ray_tracing ? kRaysNone : (pass->inline_rays ? kRaysInline : kRaysDeferred);
 	if (pass->use_ray_tracing) {
 		if (!g_ray_counter && hip_failed(hipMalloc(&g_ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
-		if (hip_failed(hipMemsetAsync(g_ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
+		if (pass->inline_rays && hip_failed(hipMemsetAsync(g_ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 		p.ray_counter = g_ray_counter;
 	}
 	if (ray_mode == kRaysDeferred) {
@@ -319,7 +385,6 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		p.ray_queue_capacity = w->queue_capacity;
 		const char* knob = getenv("VKR_REFILL_THRESHOLD");
 		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
-		if (hip_failed(hipMemsetAsync(w->ray_queue_size, 0, sizeof(uint32_t) * (kRayQueueCount + 8 * kCursorStride), stream), "clearing the ray queue")) return 1;
 	}
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
@@ -334,7 +399,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		// persistent: 8 waves per SIMD on every CU
 		uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
 		trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
-		resolve_shadow_terms<<<grid_blocks, 256, 0, stream>>>(p);
+		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
 		status = hipGetLastError() != hipSuccess;
 	}
 	(void) hipEventRecord(ring[2 * slot + 1], stream);
@@ -344,6 +409,8 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		return 1;
 	}
 	if (status > 0) {
+		// the resolve kernel did not run, so the ray queues may not be empty
+		if (pass->wavefront) (void) hipMemsetAsync(((wavefront_buffers*) pass->wavefront)->ray_queue_size, 0, sizeof(uint32_t) * kRayCounterCount, stream);
 		printf("Launching the shading kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
 		return 1;
 	}
@@ -430,7 +497,7 @@ extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statist
 	bvh.nodes = (const float4*) app->scene.acceleration_structure.nodes;
 	bvh.triangles = (const float4*) app->scene.acceleration_structure.triangle_vertices;
 	bvh.node_count = app->scene.acceleration_structure.node_count;
-	k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size, w->queue_capacity, counters);
+	k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
 	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 6, &app->device);
 	(void) hipFree(counters);
 	return failed;
@@ -442,7 +509,7 @@ extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	if (!app->shading_pass.inline_rays) {
 		const wavefront_buffers* w = (const wavefront_buffers*) app->shading_pass.wavefront;
 		uint32_t queued[kRayQueueCount];
-		if (!w || vkr_copy_to_host(queued, w->ray_queue_size, sizeof(queued), &app->device)) return 0;
+		if (!w || vkr_copy_to_host(queued, w->ray_queue_size + kRayCounterCount, sizeof(queued), &app->device)) return 0;
 		for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += queued[q];
 		return rays;
 	}
@@ -552,8 +619,7 @@ extern "C" int render_visibility_pass(application_t* app) {
 		printf("The visibility pass needs an acceleration structure and a shading pass.\n");
 		return 1;
 	}
-	write_constants(pass->constants_host, app);
-	if (vkr_copy_to_device_async(pass->constants_device, pass->constants_host, pass->constants_size, &app->device)) return 1;
+	if (upload_constants(app, (hipStream_t) app->device.stream)) return 1;
 	bvh_view bvh;
 	bvh.nodes = (const float4*) as->nodes;
 	bvh.triangles = (const float4*) as->triangle_vertices;
