@@ -254,7 +254,8 @@ VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics
 	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,
 	materials_t, acceleration_structure_t, scene_t, scene_specification_t,
 	render_settings_t, per_frame_constants_t, swapchain_t, render_targets_t,
-	screenshot_t, tile_schedule_t, shading_pass_t, application_t) so that bindings can
+	screenshot_t, tile_schedule_t, shading_pass_t, application_t, experiment_t,
+	experiment_list_t) so that bindings can
 	check their mirrors.  Returns the number of structs. */
 VKR_API uint32_t get_abi_struct_sizes(uint64_t* sizes, uint32_t capacity);
 

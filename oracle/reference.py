@@ -125,3 +125,55 @@ def host():
         _host.ref_half_to_float.restype = C.c_float
         _host.ref_half_to_float.argtypes = [C.c_uint16]
     return _host
+
+
+# ---- experiment table and screenshot writers of the reference ------------------------
+class _ExperimentView(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("scene_index", C.c_uint32), ("use_hdr", C.c_uint32),
+                ("quick_save_path", C.c_char_p), ("screenshot_path", C.c_char_p),
+                ("exposure_factor", C.c_float), ("roughness_factor", C.c_float),
+                ("sample_count", C.c_uint32), ("sampling_strategies", C.c_uint32), ("mis_heuristic", C.c_uint32),
+                ("mis_visibility_estimate", C.c_float), ("polygon_sampling_technique", C.c_uint32),
+                ("error_display", C.c_uint32), ("error_min_exponent", C.c_float), ("noise_type", C.c_uint32),
+                ("animate_noise", C.c_uint32), ("trace_shadow_rays", C.c_uint32), ("show_polygonal_lights", C.c_uint32),
+                ("show_gui", C.c_uint32), ("v_sync", C.c_uint32)]
+
+
+def experiments():
+    """The reference's create_experiment_list() (src/experiment_list.c) as a list of dicts."""
+    lib = host()
+    lib.ref_experiment_count.restype = C.c_uint32
+    lib.ref_experiment_get.argtypes = [C.c_uint32, C.POINTER(_ExperimentView)]
+    out = []
+    for i in range(lib.ref_experiment_count()):
+        view = _ExperimentView()
+        assert lib.ref_experiment_get(i, C.byref(view)) == 0
+        entry = {}
+        for name, _ in _ExperimentView._fields_:
+            value = getattr(view, name)
+            entry[name] = value.decode() if isinstance(value, bytes) else value
+        out.append(entry)
+    return out
+
+
+def write_png(path, rgb8):
+    """stbi_write_png as called at src/main.c:1731"""
+    import numpy as np
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    lib = host()
+    lib.ref_write_png_rgb8.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    assert lib.ref_write_png_rgb8(path.encode(), a.shape[1], a.shape[0], a.ctypes.data) == 0
+
+
+def write_hdr(path, rgb32f):
+    """stbi_write_hdr as called at src/main.c:1752"""
+    import numpy as np
+    a = np.ascontiguousarray(rgb32f, np.float32)
+    lib = host()
+    lib.ref_write_hdr_rgb32f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    assert lib.ref_write_hdr_rgb32f(path.encode(), a.shape[1], a.shape[0], a.ctypes.data) == 0
+
+
+def half_to_float_bits(half):
+    import numpy as np
+    return int(np.float32(host().ref_half_to_float(half)).view(np.uint32))

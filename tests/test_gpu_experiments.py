@@ -1,0 +1,61 @@
+"""SURVEY.md 8(f) rank 2 on the GPU: screenshots of a rendered frame and one full
+experiment (table entry -> scene, settings, timing, screenshot file)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases
+from test_experiments import decode_hdr, decode_png
+from test_gpu_golden import render_case
+from vulkan_renderer_amd import experiments, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden_dataset(tmp_path_factory):
+    return synthetic.write_dataset(str(tmp_path_factory.mktemp("dataset")), **golden_cases.DATASET)
+
+
+def test_screenshots_hold_the_encoded_frame(golden_dataset, tmp_path):
+    case = golden_cases.FRAME_CASES[3]
+    r, radiance = render_case(case, golden_dataset, False, 200, 120)
+    png, hdr = str(tmp_path / "shot.png"), str(tmp_path / "shot.hdr")
+    assert r.lib.take_screenshot(C.byref(r.app), png.encode(), hdr.encode()) == 0
+    # the PNG holds the sRGB-encoded frame without alpha (reference main.c:1664-1674)
+    assert np.array_equal(decode_png(open(png, "rb").read()), r.read_encoded(False, 0)[..., :3])
+    # the HDR file holds the colour rounded to half precision (two frames with frame_bits 1 and 2
+    # in the reference, main.c:1700-1711), stored as RGBE
+    half = radiance[..., :3].astype(np.float16).astype(np.float32)
+    rgbe = decode_hdr(open(hdr, "rb").read())
+    largest = half.max(axis=-1)
+    mantissa, exponent = np.frexp(largest)
+    scale = np.where(largest >= 1e-32, mantissa * 256.0 / np.where(largest > 0, largest, 1.0), 0.0).astype(np.float32)
+    expected = np.zeros_like(rgbe)
+    expected[..., :3] = (half * scale[..., None]).astype(np.uint8)
+    expected[..., 3] = np.where(largest >= 1e-32, exponent + 128, 0)
+    expected[largest < 1e-32] = 0
+    assert np.array_equal(rgbe, expected)
+    assert r.app.screenshot.frame_bits == 0
+    r.close()
+
+
+def test_experiment_from_the_table_runs_end_to_end(tmp_path):
+    """mis_plane with the clamped optimal heuristic (entry 34), on a generated stand-in data root"""
+    root = str(tmp_path / "root")
+    made = experiments.write_synthetic_data_root(root, grid=64, box_count=16)
+    table = experiments.experiment_table()
+    index = next(i for i in range(table.count) if table.experiments[i].screenshot_path == b"data/experiments/mis_plane_clamped_optimal_ours_2spp_%.3f.png")
+    result = experiments.run_experiment(index, root, frames=6, warmup=2, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
+    assert (result["width"], result["height"]) == (1024, 1024) and result["rays"]
+    files = glob.glob(os.path.join(root, "data", "experiments", "mis_plane_clamped_optimal_ours_2spp_*.png"))
+    assert files == [result["screenshot"]]
+    assert os.path.basename(files[0]) == "mis_plane_clamped_optimal_ours_2spp_%.3f.png" % result["frame_ms"]
+    image = decode_png(open(files[0], "rb").read())
+    assert image.shape == (1024, 1024, 3) and image.max() > 0
+    # an experiment that needs a related-work sampler is refused with the library's message
+    with pytest.raises(RuntimeError):
+        experiments.run_experiment(index + 8, root, frames=1, warmup=0, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)

@@ -136,9 +136,20 @@ class Application(C.Structure):
                 ("shading_pass", ShadingPass), ("tile_schedule", TileSchedule)]
 
 
+class Experiment(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("scene_index", C.c_int32), ("quick_save_path", C.c_char_p),
+                ("use_hdr", C.c_uint32), ("screenshot_path", C.c_char_p), ("render_settings", RenderSettings)]
+
+
+class ExperimentList(C.Structure):
+    _fields_ = [("experiments", C.POINTER(Experiment)), ("experiment", C.POINTER(Experiment)), ("count", C.c_uint32),
+                ("next", C.c_uint32), ("next_setup_time", C.c_double), ("next_setup_frame", C.c_uint32),
+                ("frame_index", C.c_uint32), ("state", C.c_int32)]
+
+
 ABI_STRUCTS = [Device, PolygonalLight, Camera, LtcConstants, LtcTable, NoiseTable, Mesh, Materials,
                AccelerationStructure, Scene, SceneSpecification, RenderSettings, PerFrameConstants, Swapchain,
-               RenderTargets, Screenshot, TileSchedule, ShadingPass, Application]
+               RenderTargets, Screenshot, TileSchedule, ShadingPass, Application, Experiment, ExperimentList]
 
 # every symbol include/*.h declares, with (restype, argtypes)
 P = C.POINTER
@@ -190,6 +201,14 @@ SIGNATURES = {
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_slab_pixel_coordinates": (C.c_uint64, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
     "get_abi_struct_sizes": (C.c_uint32, [P(C.c_uint64), C.c_uint32]),
+    "create_experiment_list": (None, [P(ExperimentList)]),
+    "destroy_experiment_list": (None, [P(ExperimentList)]),
+    "apply_experiment": (C.c_int, [P(Application), P(Experiment), C.c_char_p]),
+    "half_to_float": (C.c_float, [C.c_uint16]),
+    "format_screenshot_path": (C.c_void_p, [C.c_char_p, C.c_float]),
+    "write_png_rgb8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "write_hdr_rgb32f": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "take_screenshot": (C.c_int, [P(Application), C.c_char_p, C.c_char_p]),
 }
 
 _lib = None
