@@ -43,6 +43,7 @@ class Frame(C.Structure):
         ("sampling_strategies", C.c_int32), ("mis_heuristic", C.c_int32), ("polygon_technique", C.c_int32),
         ("sample_count", C.c_uint32), ("trace_shadow_rays", C.c_int32), ("show_polygonal_lights", C.c_int32),
         ("bvh", C.c_void_p), ("brute_force_rays", C.c_int32),
+        ("error_display", C.c_int32), ("error_index", C.c_int32),
     ]
 
 
@@ -206,6 +207,10 @@ def make_frame(inputs, settings, bvh=None):
     f.show_polygonal_lights = int(bool(settings.get("show_polygonal_lights", False)))
     f.bvh = bvh.handle if bvh is not None else None
     f.brute_force_rays = int(bool(settings.get("brute_force_rays", False)))
+    # error_display_t of the reference (main.h:93-118): 1..3 diffuse, 4..6 specular
+    display = int(settings.get("error_display", 0))
+    f.error_display = 0 if display == 0 else (1 if display <= 3 else 2)
+    f.error_index = (display - 1) % 3 if display else 0
     f._keep = keep
     f._bvh = bvh
     return f

@@ -62,6 +62,10 @@ typedef struct oracle_frame_s {
 	/* opaque BVH handle from oracle_bvh_build (NULL: brute force over all triangles) */
 	const void* bvh;
 	int32_t brute_force_rays;
+	/* ERROR_DISPLAY_DIFFUSE / _SPECULAR / ERROR_INDEX of the reference (main.c:728-750):
+	 * error_display 0 none, 1 diffuse, 2 specular; error_index 0 backward, 1 backward
+	 * times projected solid angle, 2 forward */
+	int32_t error_display, error_index;
 } oracle_frame_t;
 
 /* Shades rows [y0, y1) of the frame into out_rgba (width*height*4 floats,

@@ -160,6 +160,25 @@ static inline void vkr_sincosf(float x, float* out_sin, float* out_cos) {
 	*out_cos = c_out;
 }
 
+/* log2 for positive normal x: exponent + odd series of the mantissa in [sqrt(1/2), sqrt(2)]
+ * (s = (m - 1) / (m + 1), log2(m) = 2 / ln 2 (s + s^3/3 + ...)), < 1 ulp off at the sizes
+ * the error display feeds it.  Mirrored by log2_poly in csrc/device_math.h. */
+static inline float vkr_log2f(float x) {
+	uint32_t bits = f2u(x);
+	int e = (int) (bits >> 23) - 127;
+	float m = u2f((bits & 0x007FFFFFu) | 0x3F800000u);
+	if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+	float s = (m - 1.0f) / (m + 1.0f);
+	float z = s * s;
+	float r = 2.22222222e-01f;
+	r = fmaf(r, z, 2.85714298e-01f);
+	r = fmaf(r, z, 4.00000006e-01f);
+	r = fmaf(r, z, 6.66666687e-01f);
+	r = fmaf(r, z, 2.0f);
+	return fmaf(s * r, 1.44269502f, (float) e);
+}
+
+static inline float o_log2(float x) { return g_oracle_math_mode ? vkr_log2f(x) : log2f(x); }
 static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : atanf(t); }
 static inline float o_acos_unit(float x) { return g_oracle_math_mode ? vkr_acosf_unit(x) : acosf(x); }
 static inline void o_sincos(float x, float* s, float* c) {

@@ -37,7 +37,7 @@ typedef struct {
 	v3 dequant_factor, dequant_summand;
 	float pixel_to_ray[3][4];
 	v3 camera_position;
-	float mis_visibility_estimate, exposure_factor, roughness_factor;
+	float mis_visibility_estimate, exposure_factor, roughness_factor, error_factor;
 	uint32_t noise_resolution_mask[2], noise_texture_index_mask, frame_bits;
 	uint32_t noise_random_numbers[4];
 	float ltc_fresnel_factor, ltc_fresnel_summand, ltc_roughness_factor, ltc_roughness_summand, ltc_inclination_factor, ltc_inclination_summand;
@@ -65,6 +65,7 @@ static frame_constants_t read_frame_constants(const uint8_t* c) {
 			k.pixel_to_ray[i][j] = rd_f(c, 96 + 16 * i + 4 * j);
 	k.camera_position = mk3(rd_f(c, 144), rd_f(c, 148), rd_f(c, 152));
 	k.mis_visibility_estimate = rd_f(c, 156);
+	k.error_factor = rd_f(c, 28);
 	k.exposure_factor = rd_f(c, 176);
 	k.roughness_factor = rd_f(c, 180);
 	k.noise_resolution_mask[0] = rd_u(c, 184);
@@ -989,6 +990,37 @@ static int light_ray_intersection(const light_view_t* light, uint32_t vmax, v3 o
 	return result;
 }
 
+/* error_to_color, shading_pass.frag.glsl:80-114: tab20b colours, five decades */
+static v3 error_to_color(const frame_constants_t* k, float error) {
+	static const float colors[20][3] = {
+		{0.04092f, 0.04374f, 0.19120f}, {0.08438f, 0.08866f, 0.36625f}, {0.14703f, 0.15593f, 0.62396f}, {0.33245f, 0.34191f, 0.73046f},
+		{0.12477f, 0.19120f, 0.04092f}, {0.26225f, 0.36131f, 0.08438f}, {0.46208f, 0.62396f, 0.14703f}, {0.61721f, 0.70838f, 0.33245f},
+		{0.26225f, 0.15293f, 0.03071f}, {0.50888f, 0.34191f, 0.04092f}, {0.79910f, 0.49102f, 0.08438f}, {0.79910f, 0.59720f, 0.29614f},
+		{0.23074f, 0.04519f, 0.04092f}, {0.41789f, 0.06663f, 0.06848f}, {0.67244f, 0.11954f, 0.14703f}, {0.79910f, 0.30499f, 0.33245f},
+		{0.19807f, 0.05286f, 0.17144f}, {0.37626f, 0.08228f, 0.29614f}, {0.61721f, 0.15293f, 0.50888f}, {0.73046f, 0.34191f, 0.67244f}};
+	const float min_exponent = 0.0f, max_exponent = 5.0f, color_count = 20.0f;
+	const float min_error = powf(10.0f, min_exponent);
+	const float max_error = powf(10.0f, max_exponent - 0.01f);
+	error = g_min(g_max(fabsf(k->error_factor * error), min_error), max_error);
+	/* A NaN error (degenerate sample) passes through the clamp; in the reference the
+	 * colour index is then int(NaN), which is undefined.  Defined here: first colour. */
+	error = (error == error) ? error : min_error;
+	float color_index = fmaf(o_log2(error), color_count / ((max_exponent - min_exponent) * log2f(10.0f)), color_count * -min_exponent / (max_exponent - min_exponent));
+	int index = (int) color_index;
+	return mk3(colors[index][0], colors[index][1], colors[index][2]);
+}
+
+/* the ERROR_DISPLAY_* branches, shading_pass.frag.glsl:489-494, :549-563 */
+static v3 display_sampling_error(pixel_ctx_t* ctx, const psa_polygon_t* polygon, uint32_t cap, noise_accessor_t* noise, int biased) {
+	const oracle_frame_t* f = ctx->f;
+	v2 u = next_noise_2(f, ctx->k, noise);
+	v3 dir = sample_psa(polygon, cap, u, biased);
+	v3 e = psa_sampling_error(polygon, cap, u, dir);
+	float error = (f->error_index == 0) ? e.x : ((f->error_index == 1) ? e.y : e.z);
+	v3 color = error_to_color(ctx->k, error);
+	return mk3(color.x / ctx->k->exposure_factor, color.y / ctx->k->exposure_factor, color.z / ctx->k->exposure_factor);
+}
+
 /* evaluate_polygonal_light_shading, shading_pass.frag.glsl:329-711 */
 static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t* ltc_in, const light_view_t* light, noise_accessor_t* noise) {
 	const oracle_frame_t* f = ctx->f;
@@ -1047,6 +1079,7 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 			if (clipped == 0) return zero;
 			psa_polygon_t pd = prepare_psa(clipped, cap, vs, biased);
 			if (pd.psa <= 0.0f) return zero;
+			if (f->error_display == 1) return display_sampling_error(ctx, &pd, cap, noise, biased);
 			for (uint32_t s = 0; s != S; ++s) {
 				v3 dir = sample_psa(&pd, cap, next_noise_2(f, k, noise), biased);
 				float density = dir.z / pd.psa;
@@ -1074,6 +1107,8 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 			if (pd.psa == 0.0f) return zero;
 			float specular_albedo = ltc.albedo;
 			float specular_weight = specular_albedo * ps.psa;
+			if (f->error_display == 1) return display_sampling_error(ctx, &pd, cap, noise, biased);
+			if (f->error_display == 2) return (ps.psa > 0.0f) ? display_sampling_error(ctx, &ps, cap, noise, biased) : zero;
 			if (strategy == O_STRATEGY_DIFFUSE_SPECULAR_SEPARATELY) {
 				/* :565-586 */
 				for (uint32_t s = 0; s != S; ++s) {

@@ -93,7 +93,9 @@ def variant_defines(v):
         "MAX_POLYGON_VERTEX_COUNT": vmax + (1 if clipped else 0),
         "SAMPLE_COUNT": v["samples"], "SAMPLE_COUNT_CLAMPED": min(v["samples"], 33),
         "TRACE_SHADOW_RAYS": int(v.get("rays", False)), "SHOW_POLYGONAL_LIGHTS": int(v.get("show_lights", False)),
-        "ERROR_DISPLAY_DIFFUSE": 0, "ERROR_DISPLAY_SPECULAR": 0, "ERROR_INDEX": 0,
+        # error_display_t of the reference (main.h:93-118, main.c:728-750): 1..3 diffuse, 4..6 specular
+        "ERROR_DISPLAY_DIFFUSE": int(1 <= v.get("error_display", 0) <= 3), "ERROR_DISPLAY_SPECULAR": int(v.get("error_display", 0) >= 4),
+        "ERROR_INDEX": (v.get("error_display", 0) - 1) % 3 if v.get("error_display", 0) else 0,
         "OUTPUT_LINEAR_RGB": int(v.get("output_linear_rgb", True)),
     }
     for i, s in enumerate(strategies):
@@ -108,10 +110,11 @@ def variant_defines(v):
 
 
 def variant_name(v):
-    return "s%d_h%d_%s_L%d_V%d-%d_S%d_r%d_l%d_o%d" % (
+    name = "s%d_h%d_%s_L%d_V%d-%d_S%d_r%d_l%d_o%d" % (
         v["strategy"], v.get("heuristic", 0), v.get("technique", "projected_solid_angle"), v["lights"],
         v.get("min_light_vertices", v["max_light_vertices"]), v["max_light_vertices"], v["samples"],
         int(v.get("rays", False)), int(v.get("show_lights", False)), int(v.get("output_linear_rgb", True)))
+    return name + ("_e%d" % v["error_display"] if v.get("error_display", 0) else "")
 
 
 # Variants that the golden fixtures and the oracle-vs-reference tests use.
@@ -137,6 +140,10 @@ VARIANTS = [
     dict(strategy=0, technique="projected_solid_angle_biased", lights=1, max_light_vertices=4, samples=1),
     dict(strategy=0, technique="solid_angle", lights=1, max_light_vertices=4, samples=1),
     dict(strategy=1, heuristic=0, technique="clipped_solid_angle", lights=1, max_light_vertices=4, samples=1),
+    # error display: backward (diffuse-only path), backward times PSA and forward (combined path)
+    dict(strategy=0, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=1),
+    dict(strategy=3, heuristic=3, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=2),
+    dict(strategy=3, heuristic=3, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=6),
     # encoded output (sRGB transfer in the shader)
     dict(strategy=0, lights=1, max_light_vertices=3, samples=1, output_linear_rgb=False),
 ]

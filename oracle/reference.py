@@ -18,10 +18,11 @@ def available():
 
 
 def variant_name(strategy=0, heuristic=0, technique="projected_solid_angle", lights=1, min_light_vertices=None,
-                 max_light_vertices=3, samples=1, rays=False, show_lights=False, output_linear_rgb=True):
+                 max_light_vertices=3, samples=1, rays=False, show_lights=False, output_linear_rgb=True, error_display=0):
     lo = max_light_vertices if min_light_vertices is None else min_light_vertices
-    return "s%d_h%d_%s_L%d_V%d-%d_S%d_r%d_l%d_o%d" % (strategy, heuristic, technique, lights, lo, max_light_vertices,
+    name = "s%d_h%d_%s_L%d_V%d-%d_S%d_r%d_l%d_o%d" % (strategy, heuristic, technique, lights, lo, max_light_vertices,
                                                       samples, int(rays), int(show_lights), int(output_linear_rgb))
+    return name + ("_e%d" % error_display if error_display else "")
 
 
 def variants():

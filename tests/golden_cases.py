@@ -41,6 +41,9 @@ FRAME_CASES = [
     dict(key="biased_psa", lights=QUAD, strategy=0, heuristic=0, samples=1, technique="projected_solid_angle_biased"),
     dict(key="solid_angle", lights=QUAD, strategy=0, heuristic=0, samples=1, technique="solid_angle"),
     dict(key="clipped_solid_angle_ggx", lights=QUAD, strategy=1, heuristic=0, samples=1, technique="clipped_solid_angle"),
+    dict(key="error_backward_diffuse_only", lights=MIXED, strategy=0, heuristic=0, samples=1, error_display=1),
+    dict(key="error_backward_scaled_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=2),
+    dict(key="error_forward_specular_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=6),
     dict(key="cfg1_srgb_encoded", lights=TRIANGLE, strategy=0, heuristic=0, samples=1, output_linear_rgb=False),
 ]
 
@@ -56,7 +59,8 @@ def apply_case(scene, case, dataset, width=WIDTH, height=HEIGHT):
     scene.set_lights(case["lights"])
     scene.set_settings(width=width, height=height, sample_count=case["samples"], sampling_strategies=case["strategy"],
                        mis_heuristic=case["heuristic"], polygon_technique=case.get("technique", "projected_solid_angle"),
-                       trace_shadow_rays=rays, show_polygonal_lights=bool(case.get("show_lights", False)))
+                       trace_shadow_rays=rays, show_polygonal_lights=bool(case.get("show_lights", False)),
+                       error_display=case.get("error_display", 0), error_min_exponent=-7.0)
 
 
 def reference_variant(case):
@@ -65,7 +69,7 @@ def reference_variant(case):
                                   technique=case.get("technique", "projected_solid_angle"), lights=len(counts),
                                   min_light_vertices=min(counts), max_light_vertices=max(counts), samples=case["samples"],
                                   rays=case.get("rays", False), show_lights=case.get("show_lights", False),
-                                  output_linear_rgb=case.get("output_linear_rgb", True))
+                                  output_linear_rgb=case.get("output_linear_rgb", True), error_display=case.get("error_display", 0))
 
 
 def build_frame(case, dataset, width=WIDTH, height=HEIGHT):

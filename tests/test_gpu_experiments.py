@@ -56,6 +56,12 @@ def test_experiment_from_the_table_runs_end_to_end(tmp_path):
     assert os.path.basename(files[0]) == "mis_plane_clamped_optimal_ours_2spp_%.3f.png" % result["frame_ms"]
     image = decode_png(open(files[0], "rb").read())
     assert image.shape == (1024, 1024, 3) and image.max() > 0
+    # the sampling-error figure of the paper (entry 5): error display, and the out-of-range
+    # sampling strategy that the reference's table carries (experiment_list.c:107)
+    result = experiments.run_experiment(5, root, frames=2, warmup=1, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
+    assert os.path.basename(result["screenshot"]).startswith("error_attic_backward_") and not result["rays"]
+    colors = np.unique(decode_png(open(result["screenshot"], "rb").read()).reshape(-1, 3), axis=0)
+    assert 2 <= len(colors) <= 22  # background + a subset of the 20 colour bins
     # an experiment that needs a related-work sampler is refused with the library's message
     with pytest.raises(RuntimeError):
         experiments.run_experiment(index + 8, root, frames=1, warmup=0, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)

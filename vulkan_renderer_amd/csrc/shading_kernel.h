@@ -64,6 +64,10 @@ struct shade_params {
 	uint32_t thread_count, max_terms, max_codes;
 	// tuning knobs (host: environment, see shading_pass.hip)
 	uint32_t refill_threshold;
+	// error display (ERROR_INDEX of the reference; the two constants of error_to_color
+	// that the GLSL compiler folds: 10^4.99 and 20 / (5 log2 10), computed on the host)
+	uint32_t error_index;
+	float error_max, error_scale;
 };
 
 constexpr uint32_t kRayQueueCount = 512;  // 8 XCDs x 64 (one queue per lane when scanning sizes)
@@ -556,8 +560,41 @@ VKR_DEV void add_light_mis_estimate(pixel_context& ctx, f3& result, f3 dir, floa
 	accumulate<RAYS>(ctx, result, candidate, visible_term, hidden_term, dir, sd, light);
 }
 
+enum { kErrorNone = 0, kErrorDiffuse = 1, kErrorSpecular = 2 };
+
+// error_to_color, shading_pass.frag.glsl:80-114: tab20b colours (linear Rec. 709), four
+// shades per decade over five decades
+__device__ const float k_tab20b[20][3] = {
+	{0.04092f, 0.04374f, 0.19120f}, {0.08438f, 0.08866f, 0.36625f}, {0.14703f, 0.15593f, 0.62396f}, {0.33245f, 0.34191f, 0.73046f},
+	{0.12477f, 0.19120f, 0.04092f}, {0.26225f, 0.36131f, 0.08438f}, {0.46208f, 0.62396f, 0.14703f}, {0.61721f, 0.70838f, 0.33245f},
+	{0.26225f, 0.15293f, 0.03071f}, {0.50888f, 0.34191f, 0.04092f}, {0.79910f, 0.49102f, 0.08438f}, {0.79910f, 0.59720f, 0.29614f},
+	{0.23074f, 0.04519f, 0.04092f}, {0.41789f, 0.06663f, 0.06848f}, {0.67244f, 0.11954f, 0.14703f}, {0.79910f, 0.30499f, 0.33245f},
+	{0.19807f, 0.05286f, 0.17144f}, {0.37626f, 0.08228f, 0.29614f}, {0.61721f, 0.15293f, 0.50888f}, {0.73046f, 0.34191f, 0.67244f}};
+
+VKR_DEV f3 error_to_color(const shade_params& p, float error) {
+	float error_factor = load_f(p.constants, 28);
+	error = gmin(gmax(fabsf(error_factor * error), 1.0f), p.error_max);
+	// NaN (degenerate sample) is undefined in the reference (int(NaN)); defined as the first colour
+	error = (error == error) ? error : 1.0f;
+	float color_index = fmaf(log2_poly(error), p.error_scale, -0.0f);
+	int index = (int) color_index;
+	return mk3(k_tab20b[index][0], k_tab20b[index][1], k_tab20b[index][2]);
+}
+
+// the ERROR_DISPLAY_* branches, shading_pass.frag.glsl:489-494, :549-563
+template <int V, bool BIASED>
+VKR_DEV f3 display_sampling_error(const shade_params& p, const psa_polygon<V>& polygon, noise_accessor& noise) {
+	f2 u = next_noise_2(p, noise);
+	f3 dir = sample_psa<V, BIASED>(polygon, u);
+	f3 e = psa_sampling_error<V>(polygon, u, dir);
+	float error = (p.error_index == 0) ? e.x : ((p.error_index == 1) ? e.y : e.z);
+	f3 color = error_to_color(p, error);
+	float exposure = load_f(p.constants, 176);
+	return mk3(divide(color.x, exposure), divide(color.y, exposure), divide(color.z, exposure));
+}
+
 // evaluate_polygonal_light_shading, shading_pass.frag.glsl:329-711
-template <int STRATEGY, int TECHNIQUE, int V, int RAYS>
+template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
 VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_coefficients& ltc_in, const light_ref& light, noise_accessor& noise) {
 	const shade_params& p = ctx.p;
 	constexpr bool kBiased = TECHNIQUE == kTechniquePsaBiased;
@@ -619,6 +656,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			psa_polygon<V> pd;
 			prepare_psa<V, kBiased>(pd, clipped, vs);
 			if (pd.total <= 0.0f) return zero;
+			if constexpr (ERROR == kErrorDiffuse) return display_sampling_error<V, kBiased>(p, pd, noise);
 			for (uint32_t s = 0; s != S; ++s) {
 				f3 dir = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
 				float density = divide(dir.z, pd.total);
@@ -651,6 +689,11 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			if (pd.total == 0.0f) return zero;
 			float specular_albedo = ltc_in.albedo;
 			float specular_weight = specular_albedo * ps.total;
+			if constexpr (ERROR == kErrorDiffuse) return display_sampling_error<V, kBiased>(p, pd, noise);
+			if constexpr (ERROR == kErrorSpecular) {
+				if (ps.total > 0.0f) return display_sampling_error<V, kBiased>(p, ps, noise);
+				return zero;
+			}
 			if constexpr (STRATEGY == kStrategySeparately) {
 				for (uint32_t s = 0; s != S; ++s) {
 					f3 dd = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
@@ -817,7 +860,7 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 }
 
 // main, shading_pass.frag.glsl:824-866
-template <int STRATEGY, int TECHNIQUE, int V, int RAYS>
+template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
 __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 	uint32_t px, py;
 	size_t out_index;
@@ -859,7 +902,7 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 			noise.available = 0; noise.px = px; noise.py = py; noise.sample_index = 0;
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
-				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS>(ctx, sd, ltc, light, noise);
+				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);
 			}
 		}
 		if constexpr (RAYS == kRaysDeferred) {

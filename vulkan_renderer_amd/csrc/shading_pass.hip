@@ -13,6 +13,8 @@ using namespace vkr;
 VKR_DECLARE_LAUNCH(exact, 0) VKR_DECLARE_LAUNCH(exact, 1) VKR_DECLARE_LAUNCH(exact, 2) VKR_DECLARE_LAUNCH(exact, 3) VKR_DECLARE_LAUNCH(exact, 4)
 VKR_DECLARE_LAUNCH(fast, 0) VKR_DECLARE_LAUNCH(fast, 1) VKR_DECLARE_LAUNCH(fast, 2) VKR_DECLARE_LAUNCH(fast, 3) VKR_DECLARE_LAUNCH(fast, 4)
 
+extern "C" int vkr_launch_error_display_exact(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
+extern "C" int vkr_launch_error_display_fast(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
 typedef int (*launch_function_t)(int, int, int, const shade_params*, unsigned int, void*);
 static const launch_function_t g_launchers[2][5] = {
 	{vkr_launch_shade_exact_0, vkr_launch_shade_exact_1, vkr_launch_shade_exact_2, vkr_launch_shade_exact_3, vkr_launch_shade_exact_4},
@@ -219,7 +221,12 @@ static int validate_settings(const application_t* app) {
 		return 1;
 	}
 	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased;
-	if (s->sampling_strategies >= sampling_strategies_count || s->mis_heuristic >= mis_heuristic_count) {
+	// An out-of-range strategy selects none of the strategy defines of the reference, i.e.
+	// the combined diffuse + specular preparation with no estimator behind it.  That is
+	// only meaningful with an error display (the reference's own experiment table does it,
+	// experiment_list.c:107); everything else is refused.
+	bool strategy_in_range = s->sampling_strategies < sampling_strategies_count;
+	if ((!strategy_in_range && !(s->error_display != error_display_none && is_psa)) || s->mis_heuristic >= mis_heuristic_count) {
 		printf("Invalid sampling strategy or MIS heuristic.\n");
 		return 1;
 	}
@@ -236,8 +243,8 @@ static int validate_settings(const application_t* app) {
 		printf("The weighted and optimal MIS heuristics are only defined for the diffuse+specular MIS strategy.\n");
 		return 1;
 	}
-	if (s->error_display != error_display_none) {
-		printf("Error display modes are not implemented in the kernels.\n");
+	if (s->error_display >= error_display_count) {
+		printf("Invalid error display mode.\n");
 		return 1;
 	}
 	if (s->sample_count == 0) {
@@ -371,6 +378,28 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	uint32_t grid_blocks = 0;
 	fill_tile_schedule(p, app, grid_blocks);
 	int ray_mode = !pass->use_ray_tracing ? kRaysNone : (pass->inline_rays ? kRaysInline : kRaysDeferred);
+	// Error display (ERROR_DISPLAY_DIFFUSE / _SPECULAR / ERROR_INDEX, main.c:728-750): only
+	// the projected solid angle paths look at these flags, and the specular display
+	// exists only where the specular technique is prepared.  The program returns
+	// before it samples, so no ray is ever traced.
+	int error_mode = kErrorNone;
+	{
+		int display = (int) app->render_settings.error_display;
+		int technique_now = technique_index(app->render_settings.polygon_sampling_technique);
+		bool combined = app->render_settings.sampling_strategies >= sampling_strategies_diffuse_specular_separately;
+		if (display != error_display_none && (technique_now == kTechniquePsa || technique_now == kTechniquePsaBiased)) {
+			bool specular = display == error_display_specular_backward || display == error_display_specular_backward_scaled || display == error_display_specular_forward;
+			error_mode = specular ? (combined ? kErrorSpecular : kErrorNone) : kErrorDiffuse;
+		}
+		if (error_mode != kErrorNone) {
+			ray_mode = kRaysNone;
+			p.error_index = (display == error_display_diffuse_backward || display == error_display_specular_backward) ? 0u
+				: ((display == error_display_diffuse_backward_scaled || display == error_display_specular_backward_scaled) ? 1u : 2u);
+			// the constants that the GLSL compiler folds in error_to_color (shading_pass.frag.glsl:81-89)
+			p.error_max = powf(10.0f, 5.0f - 0.01f);
+			p.error_scale = 20.0f / ((5.0f - 0.0f) * log2f(10.0f));
+		}
+	}
 	if (pass->use_ray_tracing) {
 		if (!g_ray_counter && hip_failed(hipMalloc(&g_ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
 		if (pass->inline_rays && hip_failed(hipMemsetAsync(g_ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
@@ -393,7 +422,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
 	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
 	(void) hipEventRecord(ring[2 * slot], stream);
-	int status = g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
+	int status = error_mode != kErrorNone
+		? (pass->fast_math ? vkr_launch_error_display_fast : vkr_launch_error_display_exact)(strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
+		: g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
 	if (status == 0 && ray_mode == kRaysDeferred) {
 		// enough resident waves to fill the chip; each lane strides over the queue
 		// persistent: 8 waves per SIMD on every CU

@@ -149,7 +149,8 @@ class HostScene:
         s = self.app.render_settings
         return {"sampling_strategies": s.sampling_strategies, "mis_heuristic": s.mis_heuristic,
                 "polygon_technique": s.polygon_sampling_technique, "sample_count": s.sample_count,
-                "trace_shadow_rays": bool(s.trace_shadow_rays), "show_polygonal_lights": bool(s.show_polygonal_lights)}
+                "trace_shadow_rays": bool(s.trace_shadow_rays), "show_polygonal_lights": bool(s.show_polygonal_lights),
+                "error_display": int(s.error_display)}
 
     def close(self):
         app = self.app
