@@ -39,18 +39,20 @@ typedef struct materials_s {
 	void* constants;
 } materials_t;
 
-/*! Replaces reference scene.h:161-175: a binary LBVH over the de-quantised
+/*! Replaces reference scene.h:161-175: a binary BVH over the de-quantised
 	triangle soup (same de-quantisation as scene.c:176-187). */
 typedef struct acceleration_structure_s {
-	/*! float4 per vertex, 3 per triangle, in LBVH leaf order */
+	/*! float4 per vertex, 3 per triangle, in leaf order */
 	void* triangle_vertices;
-	/*! original triangle index per leaf slot */
+	/*! unused (the original triangle index travels in w of the first vertex) */
 	void* triangle_indices;
-	/*! (2 * triangle_count - 1) nodes of 32 bytes in depth-first order, see
-		vulkan_renderer_amd/csrc/lbvh.h */
+	/*! (2 * triangle_count - 1) nodes of 16 bytes in depth-first order with boxes
+		quantised to a 16-bit grid, see vulkan_renderer_amd/csrc/lbvh.h */
 	void* nodes;
 	uint32_t node_count;
 	uint32_t root;
+	/*! the grid of the quantised boxes: world = grid_origin + q / grid_inverse_cell */
+	float grid_origin[3], grid_inverse_cell[3];
 } acceleration_structure_t;
 
 /*! reference scene.h:161-166 */

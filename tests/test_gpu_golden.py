@@ -60,11 +60,14 @@ def test_golden_frames_of_the_reference_shader(case, fast_math, golden_dataset, 
         palette = np.unique(theirs, axis=0)
         assert {tuple(c) for c in np.unique(mine, axis=0)} <= {tuple(c) for c in palette} | {(0.0, 0.0, 0.0)} or len(palette) > 64
         same = (mine == theirs).all(axis=-1).mean()
-        assert same >= 0.6, same
+        # fast arithmetic changes the rounding errors that are being displayed even more
+        assert same >= (0.3 if fast_math else 0.6), same
         assert abs(float(mine.mean()) - float(theirs.mean())) <= 0.02 * max(float(theirs.mean()), 1e-6)
         return
     assert stats["rmse"] <= RMSE_TOLERANCE, stats
-    assert stats["max_abs"] <= 2.0e-3, stats
+    # single-pixel bound: a sample that lands next to a discontinuity of the estimator
+    # (sector boundary, clipping) moves further under approximate reciprocals
+    assert stats["max_abs"] <= (1.0e-2 if fast_math else 2.0e-3), stats
 
 
 @pytest.mark.parametrize("case", LINEAR_CASES, ids=[c["key"] for c in LINEAR_CASES])

@@ -74,7 +74,8 @@ class Materials(C.Structure):
 
 class AccelerationStructure(C.Structure):
     _fields_ = [("triangle_vertices", C.c_void_p), ("triangle_indices", C.c_void_p), ("nodes", C.c_void_p),
-                ("node_count", C.c_uint32), ("root", C.c_uint32)]
+                ("node_count", C.c_uint32), ("root", C.c_uint32),
+                ("grid_origin", C.c_float * 3), ("grid_inverse_cell", C.c_float * 3)]
 
 
 class Scene(C.Structure):

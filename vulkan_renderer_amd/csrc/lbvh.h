@@ -6,17 +6,20 @@
 // ray-query semantics: opaque geometry, first hit terminates, no face culling,
 // t in [t_min, t_max], triangle soup de-quantised like scene.c:176-187.
 //
-// Layout in HBM ("threaded" BVH): all 2n-1 nodes of the binary radix tree, inner
-// nodes and leaves alike, stored in depth-first order as 32 bytes each:
-//     float4 a = (lo.x, lo.y, lo.z, hi.x)
-//     float4 b = (hi.y, hi.z, bits(skip), bits(leaf))
-// The left child of an inner node is the next node; `skip` is the index of the
-// node that follows the whole subtree; `leaf` is the triangle slot or 0xFFFFFFFF.
-// A ray walks the array with a single cursor: hit -> next node (testing the
-// triangle first if it is a leaf), miss -> skip.  No stack, hence no scratch
-// memory and no LDS: the only per-ray state is the cursor.  Triangles are three
-// float4 per slot in the same (Morton) order, w of vertex 0 carries the original
-// primitive index.
+// Layout in HBM ("threaded" BVH): all 2n-1 nodes of the binary tree, inner nodes and
+// leaves alike, stored in depth-first order as 16 bytes each:
+//     uint4 = (lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16, link)
+// Box coordinates are 16-bit positions on a uniform grid over the (padded) scene box,
+// rounded outwards, so the quantised box contains the fp32 box.  The left child of an
+// inner node is the next node; for an inner node `link` is the index of the node that
+// follows its whole subtree, for a leaf it is 0x80000000 | triangle slot (the node after
+// a leaf is always the next one).  A ray walks the array with a single cursor: hit ->
+// next node (testing the triangle first if it is a leaf), miss -> link.  No stack, hence
+// no scratch memory and no LDS: the only per-ray state is the cursor.  One 16-byte load
+// per visit matters: the traversal is bound by the L1/TA data path (profiles/).
+// The ray is moved into grid space once ((o - origin) * inverse_cell, d * inverse_cell),
+// which leaves the ray parameter t unchanged.  Triangles are three float4 per slot in
+// leaf order, w of vertex 0 carries the original primitive index.
 #pragma once
 #include "device_math.h"
 
@@ -33,11 +36,15 @@ struct alignas(16) bvh_build_node {
 
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
+// outward rounding margin of the quantised boxes in cells: covers the rounding of the
+// grid transform of the ray and of the slab arithmetic (a few 1e-3 cells each)
+constexpr float kGridMargin = 0.05f;
 
 struct bvh_view {
-	const float4* nodes;      // 2 float4 per node, depth-first order
+	const uint4* nodes;       // 16 bytes per node, depth-first order
 	const float4* triangles;  // 3 float4 per leaf slot
 	uint32_t node_count;      // 2 * triangle_count - 1
+	f3 grid_origin, grid_inverse_cell;
 };
 
 // Moeller-Trumbore without the division, fp32, same operation order as
@@ -67,15 +74,27 @@ VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_m
 	return true;
 }
 
-// Conservative slab test; boxes are padded at build time, so approximate
-// reciprocals are fine here in every arithmetic mode.
-VKR_DEV bool ray_box(float4 a, float4 b, f3 inv, f3 shift, float t_min, float t_max) {
-	// t = (plane - o) / d = plane * inv + shift with shift = -o * inv: one FMA per plane.
-	// (For axis-parallel rays inf - inf gives NaN, which min/max ignore: that slab
-	// then never culls, which is conservative.)
-	float x0 = fmaf(a.x, inv.x, shift.x), x1 = fmaf(a.w, inv.x, shift.x);
-	float y0 = fmaf(a.y, inv.y, shift.y), y1 = fmaf(b.x, inv.y, shift.y);
-	float z0 = fmaf(a.z, inv.z, shift.z), z1 = fmaf(b.y, inv.z, shift.z);
+// A ray in the grid space of the quantised boxes: t = plane * inv + shift
+struct grid_ray {
+	f3 inv, shift;
+};
+
+VKR_DEV grid_ray make_grid_ray(const bvh_view& bvh, f3 o, f3 d) {
+	f3 og = mk3((o.x - bvh.grid_origin.x) * bvh.grid_inverse_cell.x, (o.y - bvh.grid_origin.y) * bvh.grid_inverse_cell.y, (o.z - bvh.grid_origin.z) * bvh.grid_inverse_cell.z);
+	f3 dg = mk3(d.x * bvh.grid_inverse_cell.x, d.y * bvh.grid_inverse_cell.y, d.z * bvh.grid_inverse_cell.z);
+	grid_ray r;
+	// approximate reciprocals are fine: the boxes are rounded outwards by kGridMargin
+	r.inv = mk3(__builtin_amdgcn_rcpf(dg.x), __builtin_amdgcn_rcpf(dg.y), __builtin_amdgcn_rcpf(dg.z));
+	r.shift = mk3(-og.x * r.inv.x, -og.y * r.inv.y, -og.z * r.inv.z);
+	return r;
+}
+
+// Conservative slab test against a quantised node.  (For axis-parallel rays inf - inf
+// gives NaN, which min/max ignore: that slab then never culls, which is conservative.)
+VKR_DEV bool ray_box(uint4 n, const grid_ray& r, float t_min, float t_max) {
+	float x0 = fmaf((float) (n.x & 0xFFFFu), r.inv.x, r.shift.x), x1 = fmaf((float) (n.x >> 16), r.inv.x, r.shift.x);
+	float y0 = fmaf((float) (n.y & 0xFFFFu), r.inv.y, r.shift.y), y1 = fmaf((float) (n.y >> 16), r.inv.y, r.shift.y);
+	float z0 = fmaf((float) (n.z & 0xFFFFu), r.inv.z, r.shift.z), z1 = fmaf((float) (n.z >> 16), r.inv.z, r.shift.z);
 	float near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
 	float far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
 	return near <= far * 1.0000004f;
@@ -85,22 +104,21 @@ VKR_DEV bool ray_box(float4 a, float4 b, f3 inv, f3 shift, float t_min, float t_
 // ray within [t_min, t_max].
 VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) {
 	if (!(t_max >= t_min)) return false;
-	f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-	f3 shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+	grid_ray r = make_grid_ray(bvh, o, d);
 	uint32_t node = 0;
 	const uint32_t end = bvh.node_count;
 	float dist;
 	while (node < end) {
-		float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
-		uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
-		bool hit = ray_box(a, b, inv, shift, t_min, t_max);
-		if (hit && leaf != kNoLeaf) {
-			const float4* t = bvh.triangles + 3 * (size_t) leaf;
+		uint4 n = bvh.nodes[node];
+		bool is_leaf = (n.w & kLeafBit) != 0;
+		bool hit = ray_box(n, r, t_min, t_max);
+		if (hit && is_leaf) {
+			const float4* t = bvh.triangles + 3 * (size_t) (n.w & ~kLeafBit);
 			if (ray_triangle<false>(t[0], t[1], t[2], o, d, t_min, t_max, dist)) return true;
 		}
-		// inner node that was hit: descend (the left child is the next node);
-		// everything else: leave the subtree
-		node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
+		// inner node that was hit: descend (the left child is the next node); a leaf is
+		// followed by the next node as well; otherwise leave the subtree
+		node = (hit || is_leaf) ? node + 1 : n.w;
 	}
 	return false;
 }
@@ -108,18 +126,17 @@ VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) 
 // Closest hit with back-face culling (primary visibility).  Returns the original
 // primitive index or 0xFFFFFFFF.
 VKR_DEV uint32_t closest_front_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) {
-	f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-	f3 shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+	grid_ray r = make_grid_ray(bvh, o, d);
 	uint32_t node = 0;
 	const uint32_t end = bvh.node_count;
 	uint32_t best = 0xFFFFFFFFu;
 	float dist;
 	while (node < end) {
-		float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
-		uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
-		bool hit = ray_box(a, b, inv, shift, t_min, t_max);
-		if (hit && leaf != kNoLeaf) {
-			const float4* t = bvh.triangles + 3 * (size_t) leaf;
+		uint4 n = bvh.nodes[node];
+		bool is_leaf = (n.w & kLeafBit) != 0;
+		bool hit = ray_box(n, r, t_min, t_max);
+		if (hit && is_leaf) {
+			const float4* t = bvh.triangles + 3 * (size_t) (n.w & ~kLeafBit);
 			float4 p0 = t[0];
 			if (ray_triangle<true>(p0, t[1], t[2], o, d, t_min, t_max, dist)) {
 				uint32_t primitive = __float_as_uint(p0.w);
@@ -127,7 +144,7 @@ VKR_DEV uint32_t closest_front_hit(const bvh_view& bvh, f3 o, f3 d, float t_min,
 				if (dist < t_max || primitive < best) { t_max = dist; best = primitive; }
 			}
 		}
-		node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
+		node = (hit || is_leaf) ? node + 1 : n.w;
 	}
 	return best;
 }

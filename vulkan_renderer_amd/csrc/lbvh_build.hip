@@ -169,7 +169,51 @@ __global__ void __launch_bounds__(256) k_thread_nodes(int leaf_count, const bvh_
 	threaded[2 * (size_t) position + 1] = make_float4(hi[3 * (size_t) id + 1], hi[3 * (size_t) id + 2], __uint_as_float(skip), __uint_as_float(is_leaf ? slot : kNoLeaf));
 }
 
+// fp32 threaded nodes (32 bytes: lo.xyz, hi.x | hi.yz, skip, leaf) -> 16-byte nodes with
+// boxes rounded outwards on the 16-bit grid (layout: lbvh.h)
+__global__ void __launch_bounds__(256) k_quantize_nodes(uint32_t node_count, const float4* nodes, f3 origin, f3 inverse_cell, uint4* quantized) {
+	uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= node_count) return;
+	float4 a = nodes[2 * (size_t) id], b = nodes[2 * (size_t) id + 1];
+	float lo[3] = {a.x, a.y, a.z}, hi[3] = {a.w, b.x, b.y};
+	float g0[3] = {origin.x, origin.y, origin.z}, scale[3] = {inverse_cell.x, inverse_cell.y, inverse_cell.z};
+	uint32_t packed[3];
+	for (int j = 0; j != 3; ++j) {
+		float q0 = floorf((lo[j] - g0[j]) * scale[j] - kGridMargin);
+		float q1 = ceilf((hi[j] - g0[j]) * scale[j] + kGridMargin);
+		q0 = fminf(fmaxf(q0, 0.0f), 65535.0f);
+		q1 = fminf(fmaxf(q1, 0.0f), 65535.0f);
+		packed[j] = (uint32_t) q0 | ((uint32_t) q1 << 16);
+	}
+	uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
+	quantized[id] = make_uint4(packed[0], packed[1], packed[2], leaf != kNoLeaf ? (kLeafBit | leaf) : skip);
+}
+
 }  // namespace
+
+// Replaces structure->nodes (fp32 threaded nodes on the device) by the quantised nodes
+static int quantize_nodes(acceleration_structure_t* structure, const device_t* device) {
+	hipStream_t stream = (hipStream_t) device->stream;
+	float root[8];
+	if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(root, structure->nodes, sizeof(root), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+	const float lo[3] = {root[0], root[1], root[2]}, hi[3] = {root[3], root[4], root[5]};
+	for (int j = 0; j != 3; ++j) {
+		// one spare cell on either side keeps every box strictly inside [0, 65535]
+		float extent = fmaxf(hi[j] - lo[j], 1.0e-20f);
+		float cell = extent / 65533.0f;
+		structure->grid_origin[j] = lo[j] - cell;
+		structure->grid_inverse_cell[j] = 1.0f / cell;
+	}
+	void* quantized = NULL;
+	if (hipMalloc(&quantized, sizeof(uint4) * (size_t) structure->node_count) != hipSuccess) return 1;
+	k_quantize_nodes<<<(structure->node_count + 255) / 256, 256, 0, stream>>>(structure->node_count, (const float4*) structure->nodes,
+		f3{structure->grid_origin[0], structure->grid_origin[1], structure->grid_origin[2]},
+		f3{structure->grid_inverse_cell[0], structure->grid_inverse_cell[1], structure->grid_inverse_cell[2]}, (uint4*) quantized);
+	if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) { (void) hipFree(quantized); return 1; }
+	(void) hipFree(structure->nodes);
+	structure->nodes = quantized;
+	return 0;
+}
 
 extern "C" void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, const device_t* device) {
 	(void) device;
@@ -225,6 +269,11 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 		}
 		structure->node_count = node_count;
 		structure->root = 0;
+		if (quantize_nodes(structure, device)) {
+			printf("Quantising the BVH nodes failed.\n");
+			vkr_destroy_acceleration_structure(structure, device);
+			return 1;
+		}
 		return 0;
 	}
 	uint32_t inner_count = n > 1 ? n - 1 : 1;
@@ -260,7 +309,7 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 		if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) break;
 		structure->node_count = total_nodes;
 		structure->triangle_indices = NULL;
-		failed = 0;
+		failed = quantize_nodes(structure, device);
 	} while (0);
 	(void) hipFree(keys); (void) hipFree(sorted_keys); (void) hipFree(lo); (void) hipFree(hi);
 	(void) hipFree(leaf_parents); (void) hipFree(arrivals); (void) hipFree(sort_storage); (void) hipFree(build_nodes);

@@ -860,6 +860,15 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 }
 
 // main, shading_pass.frag.glsl:824-866
+// The kernel lives in a namespace per arithmetic mode: the exact and the fast translation
+// units instantiate the same template arguments, and without distinct names their host
+// stubs would be merged by the linker (one mode would silently run for both).
+#if VKR_FAST_MATH
+#define VKR_MODE_NAMESPACE fast_math
+#else
+#define VKR_MODE_NAMESPACE exact_math
+#endif
+inline namespace VKR_MODE_NAMESPACE {
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
 __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 	uint32_t px, py;
@@ -923,6 +932,8 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 	}
 }
 
+}  // inline namespace VKR_MODE_NAMESPACE
+
 // ---- wavefront: trace and resolve (instantiated once, in shading_pass.hip) -------------------
 #ifdef VKR_WAVEFRONT_KERNELS
 
@@ -965,7 +976,8 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 	bool chunks_left = true;
 	// per-lane ray
 	bool active = false;
-	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, inv = o, shift = o;
+	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
+	grid_ray ray = {o, o};
 	float t_max = 0.0f;
 	uint32_t node = 0, code_index = 0;
 	while (true) {
@@ -992,8 +1004,7 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
 				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
 				code_index = __float_as_uint(b.w);
-				inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-				shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+				ray = make_grid_ray(bvh, o, d);
 				node = 0;
 				active = true;
 				if (!(t_max >= 1.0e-3f)) {
@@ -1011,16 +1022,16 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 		bool may_refill = chunk_next < chunk_count || chunks_left;
 		do {
 			if (active) {
-				float4 a = bvh.nodes[2 * (size_t) node], b = bvh.nodes[2 * (size_t) node + 1];
-				uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
-				bool hit = ray_box(a, b, inv, shift, 1.0e-3f, t_max);
+				uint4 n = bvh.nodes[node];
+				bool is_leaf = (n.w & kLeafBit) != 0;
+				bool hit = ray_box(n, ray, 1.0e-3f, t_max);
 				bool blocked = false;
-				if (hit && leaf != kNoLeaf) {
-					const float4* t = bvh.triangles + 3 * (size_t) leaf;
+				if (hit && is_leaf) {
+					const float4* t = bvh.triangles + 3 * (size_t) (n.w & ~kLeafBit);
 					float dist;
 					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
 				}
-				node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
+				node = (hit || is_leaf) ? node + 1 : n.w;
 				if (blocked) active = false;
 				else if (node >= end) {
 					codes[code_index] = (uint8_t) kCodeVisible;

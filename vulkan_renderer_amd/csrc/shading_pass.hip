@@ -27,6 +27,16 @@ static int hip_failed(hipError_t error, const char* what) {
 	return 1;
 }
 
+static bvh_view make_bvh_view(const acceleration_structure_t* structure) {
+	bvh_view view;
+	view.nodes = (const uint4*) structure->nodes;
+	view.triangles = (const float4*) structure->triangle_vertices;
+	view.node_count = structure->node_count;
+	view.grid_origin = f3{structure->grid_origin[0], structure->grid_origin[1], structure->grid_origin[2]};
+	view.grid_inverse_cell = f3{structure->grid_inverse_cell[0], structure->grid_inverse_cell[1], structure->grid_inverse_cell[2]};
+	return view;
+}
+
 static int technique_index(sample_polygon_technique_t technique) {
 	switch (technique) {
 	case sample_polygon_projected_solid_angle: return kTechniquePsa;
@@ -364,9 +374,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	p.noise = (const uint2*) app->noise_table.device_data;
 	p.noise_width = app->noise_table.resolution.width;
 	p.noise_height = app->noise_table.resolution.height;
-	p.bvh.nodes = (const float4*) app->scene.acceleration_structure.nodes;
-	p.bvh.triangles = (const float4*) app->scene.acceleration_structure.triangle_vertices;
-	p.bvh.node_count = app->scene.acceleration_structure.node_count;
+	p.bvh = make_bvh_view(&app->scene.acceleration_structure);
 	if (!p.positions || !p.visibility || !p.out_radiance || !p.ltc_rgba || !p.noise || !p.material_constants) {
 		printf("render_shading_pass() needs a loaded scene, LTC table, noise table and render targets on the device.\n");
 		return 1;
@@ -483,23 +491,22 @@ __global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, cons
 			float4 a = r[0], b = r[1];
 			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
 			float t_max = a.w;
-			f3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-			f3 shift = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+			grid_ray ray = make_grid_ray(bvh, o, d);
 			uint32_t node = 0;
 			bool blocked = false;
 			++rays;
 			while (t_max >= 1.0e-3f && node < bvh.node_count && !blocked) {
-				float4 na = bvh.nodes[2 * (size_t) node], nb = bvh.nodes[2 * (size_t) node + 1];
-				uint32_t skip = __float_as_uint(nb.z), leaf = __float_as_uint(nb.w);
-				bool hit = ray_box(na, nb, inv, shift, 1.0e-3f, t_max);
+				uint4 n = bvh.nodes[node];
+				bool is_leaf = (n.w & kLeafBit) != 0;
+				bool hit = ray_box(n, ray, 1.0e-3f, t_max);
 				++my_visits;
-				if (hit && leaf != kNoLeaf) {
-					const float4* t = bvh.triangles + 3 * (size_t) leaf;
+				if (hit && is_leaf) {
+					const float4* t = bvh.triangles + 3 * (size_t) (n.w & ~kLeafBit);
 					float dist;
 					++tests;
 					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
 				}
-				node = (hit && leaf == kNoLeaf) ? node + 1 : skip;
+				node = (hit || is_leaf) ? node + 1 : n.w;
 			}
 			blocked_rays += blocked ? 1 : 0;
 		}
@@ -524,10 +531,7 @@ extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statist
 	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 6), "allocating traversal counters")) return 1;
 	hipStream_t stream = (hipStream_t) app->device.stream;
 	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 6, stream);
-	bvh_view bvh;
-	bvh.nodes = (const float4*) app->scene.acceleration_structure.nodes;
-	bvh.triangles = (const float4*) app->scene.acceleration_structure.triangle_vertices;
-	bvh.node_count = app->scene.acceleration_structure.node_count;
+	bvh_view bvh = make_bvh_view(&app->scene.acceleration_structure);
 	k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
 	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 6, &app->device);
 	(void) hipFree(counters);
@@ -651,10 +655,7 @@ extern "C" int render_visibility_pass(application_t* app) {
 		return 1;
 	}
 	if (upload_constants(app, (hipStream_t) app->device.stream)) return 1;
-	bvh_view bvh;
-	bvh.nodes = (const float4*) as->nodes;
-	bvh.triangles = (const float4*) as->triangle_vertices;
-	bvh.node_count = as->node_count;
+	bvh_view bvh = make_bvh_view(as);
 	uint32_t width = app->swapchain.extent.width, height = app->swapchain.extent.height;
 	dim3 grid((width + 15) / 16, (height + 15) / 16);
 	k_primary_visibility<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const uint8_t*) pass->constants_device, bvh, (uint32_t*) app->render_targets.visibility_buffer,
