@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
+    ap.add_argument("--exchange", choices=("rgba8", "rgba32f"), default="rgba8", help="what the ranks all-gather: the encoded frame (default) or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
 
@@ -106,20 +107,56 @@ def main():
     techniques = 1 if settings["sampling_strategies"] == "diffuse_only" else 2
 
     if distributed:
+        # Every rank shades its tiles into a dense slab.  What is exchanged is the pass's
+        # real output, the encoded RGBA8 frame (reference: the swapchain image), a quarter of
+        # the bytes of the float radiance.  The all-gather of frame k runs on RCCL's stream
+        # while frame k + 1 is shaded (two sets of buffers); a frame counts as done when it
+        # has been reassembled, and the timed region ends only after the last one has.
         slab_pixels = r.slab_pixel_count(0)
         slab = torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world, slab_pixels, 4), dtype=torch.float32, device="cuda")
-        frame = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+        if args.exchange == "rgba8":
+            send = [torch.zeros(slab_pixels, dtype=torch.int32, device="cuda") for _ in range(2)]
+            gathered = [torch.zeros(world * slab_pixels, dtype=torch.int32, device="cuda") for _ in range(2)]
+            frame = torch.zeros((height, width), dtype=torch.int32, device="cuda")
+        else:
+            send = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            gathered = [torch.zeros((world * slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            frame = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+        pending = [None, None]
+        frame_counter = [0]
+
+        def finish(b):
+            if pending[b] is not None:
+                pending[b].wait()  # the compute stream waits for the collective, not the host
+                if args.exchange == "rgba8":
+                    r.assemble_encoded(gathered[b].data_ptr(), frame.data_ptr())
+                else:
+                    r.assemble(gathered[b].data_ptr(), frame.data_ptr())
+                pending[b] = None
 
         def step():
-            r.render(slab.data_ptr())
-            dist.all_gather_into_tensor(gathered.view(world * slab_pixels, 4), slab)
-            r.assemble(gathered.data_ptr(), frame.data_ptr())
+            b = frame_counter[0] & 1
+            frame_counter[0] += 1
+            finish(b)  # frame k - 2 is complete, its buffers are free again
+            if args.exchange == "rgba8":
+                r.render(slab.data_ptr())
+                r.encode_slab(slab.data_ptr(), send[b].data_ptr(), slab_pixels)
+            else:
+                r.render(send[b].data_ptr())
+            pending[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
+
+        def drain():
+            finish(frame_counter[0] & 1)
+            finish((frame_counter[0] + 1) & 1)
     else:
         def step():
             r.render()
 
+        def drain():
+            pass
+
     def fence():
+        drain()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -239,7 +276,7 @@ def main():
                                    % (config, width, height, sample_count, light_count, settings["sampling_strategies"],
                                       settings["polygon_technique"], "LBVH shadow rays" if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
                        "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
-                       "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, " + RCCL all-gather" if distributed else ""),
+                       "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, " + RCCL all-gather of %s slabs overlapped with the next frame" % args.exchange if distributed else ""),
                        "scene_triangles": int(r.app.scene.mesh.triangle_count)},
             "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (kernel_avg_ms * 1e-3) / 1e6, 2) if rays else 0.0,
             "roofline": roofline,

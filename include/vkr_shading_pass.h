@@ -227,6 +227,12 @@ VKR_API uint64_t get_slab_pixel_coordinates(const application_t* app, uint32_t r
 /*! Scatters the all-gathered slabs (rank-major, each padded to
 	get_slab_pixel_count(app, 0) pixels) back into a row-major frame */
 VKR_API int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance);
+/*! The same for slabs of the encoded frame (RGBA8, 4 bytes per pixel): what the
+	reference's pass actually outputs, and a quarter of the bytes to exchange */
+VKR_API int assemble_encoded_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded);
+/*! Output encoding (as encode_output) of `pixel_count` pixels of a slab or any other
+	RGBA32F device buffer into an RGBA8 device buffer */
+VKR_API int encode_slab(application_t* app, const void* slab_radiance, void* slab_encoded, uint64_t pixel_count, VkBool32 output_linear_rgb);
 /*! Output encoding of shading_pass.frag.glsl:871-892 into render_targets.encoded */
 VKR_API int encode_output(application_t* app, VkBool32 output_linear_rgb);
 /*! Synchronous copies to host memory (implement_screenshot, main.c:1601-1631) */

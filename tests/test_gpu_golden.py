@@ -132,7 +132,24 @@ def test_tiles_of_virtual_ranks_reassemble_bit_exactly(golden_dataset):
         r.assemble(all_slabs.ptr.value, frame.ptr.value)
         r.sync()
         assert np.array_equal(frame.download((120, 200, 4), np.float32).view(np.uint32), full.view(np.uint32)), (tile_size, ranks)
-        for b in (dev, all_slabs, frame):
+        # the same exchange in the pass's output format (RGBA8): encode every slab, gather, scatter
+        encoded_full = r.read_encoded(False, 0)
+        gathered8 = np.zeros((ranks, slab_pixels), np.uint32)
+        slab8 = DeviceBuffer(slab_pixels * 4)
+        for rank in range(ranks):
+            r.set_tiles(tile_size, rank, ranks)
+            dev.upload(gathered[rank])
+            r.encode_slab(dev.ptr.value, slab8.ptr.value, slab_pixels)
+            r.sync()
+            gathered8[rank] = slab8.download((slab_pixels,), np.uint32)
+        all_slabs8 = DeviceBuffer(gathered8.nbytes)
+        all_slabs8.upload(gathered8)
+        frame8 = DeviceBuffer(120 * 200 * 4)
+        r.set_tiles(tile_size, 0, ranks)
+        r.assemble_encoded(all_slabs8.ptr.value, frame8.ptr.value)
+        r.sync()
+        assert np.array_equal(frame8.download((120, 200, 4), np.uint8), encoded_full), (tile_size, ranks)
+        for b in (dev, all_slabs, frame, slab8, all_slabs8, frame8):
             b.free()
     r.set_tiles(16, 0, 1)
     r.close()

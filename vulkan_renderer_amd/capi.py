@@ -198,6 +198,8 @@ SIGNATURES = {
     "upload_visibility": (C.c_int, [P(Application), C.c_void_p]),
     "get_last_dispatch_milliseconds": (C.c_float, [P(Application)]),
     "get_last_ray_count": (C.c_uint64, [P(Application)]),
+    "assemble_encoded_frame_from_slabs": (C.c_int, [P(Application), C.c_void_p, C.c_void_p]),
+    "encode_slab": (C.c_int, [P(Application), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "get_traversal_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_slab_pixel_coordinates": (C.c_uint64, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),

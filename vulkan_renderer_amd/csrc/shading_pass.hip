@@ -554,7 +554,8 @@ extern "C" uint64_t get_last_ray_count(const application_t* app) {
 
 // ---- slabs -> frame ----------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_assemble_frame(const float4* slabs, float4* frame, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tiles_x, uint32_t rank_count, uint64_t slab_stride) {
+template <typename PIXEL>
+__global__ void __launch_bounds__(256) k_assemble_frame(const PIXEL* slabs, PIXEL* frame, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tiles_x, uint32_t rank_count, uint64_t slab_stride) {
 	uint32_t px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
 	if (px >= width || py >= height) return;
 	uint32_t tx = px / tile_size, ty = py / tile_size;
@@ -564,7 +565,8 @@ __global__ void __launch_bounds__(256) k_assemble_frame(const float4* slabs, flo
 	frame[(size_t) py * width + px] = slabs[rank * slab_stride + (size_t) local_tile * tile_size * tile_size + (size_t) iy * tile_size + ix];
 }
 
-extern "C" int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance) {
+template <typename PIXEL>
+static int assemble_slabs(application_t* app, const void* gathered_slabs, void* out_frame) {
 	shade_params p;
 	memset(&p, 0, sizeof(p));
 	p.width = app->swapchain.extent.width;
@@ -575,9 +577,17 @@ extern "C" int assemble_frame_from_slabs(application_t* app, const void* gathere
 	fill_tile_schedule(p, &first, grid_blocks);
 	uint64_t slab_stride = (uint64_t) grid_blocks * 256;
 	dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
-	k_assemble_frame<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const float4*) gathered_slabs, (float4*) (out_radiance ? out_radiance : app->render_targets.radiance),
+	k_assemble_frame<PIXEL><<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const PIXEL*) gathered_slabs, (PIXEL*) out_frame,
 		p.width, p.height, p.tile_size, p.tiles_x, p.rank_count, slab_stride);
 	return hip_failed(hipGetLastError(), "assembling the frame");
+}
+
+extern "C" int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance) {
+	return assemble_slabs<float4>(app, gathered_slabs, out_radiance ? out_radiance : app->render_targets.radiance);
+}
+
+extern "C" int assemble_encoded_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded) {
+	return assemble_slabs<uint32_t>(app, gathered_slabs, out_encoded ? out_encoded : app->render_targets.encoded);
 }
 
 // ---- output encoding (shading_pass.frag.glsl:871-892, srgb_utility.glsl) --------------
@@ -627,6 +637,13 @@ extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 	k_encode_output<<<(uint32_t) ((pixels + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) app->render_targets.radiance, (uint32_t*) app->render_targets.encoded,
 		pixels, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
 	return hip_failed(hipGetLastError(), "encoding the output");
+}
+
+extern "C" int encode_slab(application_t* app, const void* slab_radiance, void* slab_encoded, uint64_t pixel_count, VkBool32 output_linear_rgb) {
+	if (!slab_radiance || !slab_encoded) return 1;
+	k_encode_output<<<(uint32_t) ((pixel_count + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_encoded,
+		pixel_count, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
+	return hip_failed(hipGetLastError(), "encoding the slab");
 }
 
 // ---- primary visibility ------------------------------------------------------------

@@ -261,6 +261,14 @@ class Renderer(HostScene):
     def slab_pixel_count(self, rank=0):
         return int(self.lib.get_slab_pixel_count(C.byref(self.app), rank))
 
+    def encode_slab(self, slab_pointer, encoded_pointer, pixel_count, output_linear_rgb=False):
+        if self.lib.encode_slab(C.byref(self.app), slab_pointer, encoded_pointer, pixel_count, int(output_linear_rgb)):
+            raise RuntimeError("encode_slab failed")
+
+    def assemble_encoded(self, gathered_pointer, out_pointer=None):
+        if self.lib.assemble_encoded_frame_from_slabs(C.byref(self.app), gathered_pointer, out_pointer):
+            raise RuntimeError("assemble_encoded_frame_from_slabs failed")
+
     def assemble(self, gathered_pointer, out_pointer=None):
         if self.lib.assemble_frame_from_slabs(C.byref(self.app), gathered_pointer, out_pointer):
             raise RuntimeError("assemble_frame_from_slabs failed")
