@@ -56,7 +56,23 @@ static inline v3 cross3(v3 a, v3 b) {
 /* fma(vec3(s), a, b) */
 static inline v3 fma3s(float s, v3 a, v3 b) { return mk3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
 static inline v2 fma2s(float s, v2 a, v2 b) { return mk2(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y)); }
-static inline float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
+/* GLSL inversesqrt.  Math mode 0: 1 / sqrt (two correctly rounded operations).  Math
+ * mode 1 (the form shared with the GPU, where 1 / sqrt costs 28 instructions): integer
+ * seed, two Newton steps and a third one in residual form; at most 0.85 ulp off over
+ * the whole positive range (oracle/tools/fit_math.py checks that), deterministic because
+ * every step is a single IEEE operation.  Zero gives a large finite number, not inf. */
+extern int g_oracle_math_mode;
+static inline float vkr_rsqrtf(float x) {
+	float hx = 0.5f * x;
+	float y = u2f(0x5F3759DFu - (f2u(x) >> 1));
+	float t = y * y;
+	y = y * fmaf(-hx, t, 1.5f);
+	t = y * y;
+	y = y * fmaf(-hx, t, 1.5f);
+	t = y * y;
+	return fmaf(y, fmaf(-hx, t, 0.5f), y);
+}
+static inline float rsqrt_f(float x) { return g_oracle_math_mode ? vkr_rsqrtf(x) : 1.0f / sqrtf(x); }
 static inline v3 normalize3(v3 a) { return scale3(a, rsqrt_f(dot3(a, a))); }
 static inline v2 normalize2(v2 a) { return scale2(a, rsqrt_f(dot2(a, a))); }
 static inline float clamp_f(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
