@@ -58,9 +58,12 @@ def main():
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
+    ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame with HIP events for the kernel time (roofline)")
     ap.add_argument("--exchange", choices=("rgba8", "rgba32f"), default="rgba8", help="what the ranks all-gather: the encoded frame (default) or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
+    if args.steps < 4 * args.timing_stride:
+        args.timing_stride = 1  # short runs: time every frame
 
     import torch
     import torch.distributed as dist
@@ -95,7 +98,8 @@ def main():
     tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % rank)
     dataset = synthetic.write_dataset(tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51)
     stream = torch.cuda.current_stream()
-    r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays)
+    r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays,
+                          timing_stride=args.timing_stride)
     renderer.setup_config(r, config, dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=True,
                           trace_shadow_rays=settings["trace_shadow_rays"])
     r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1)
@@ -179,7 +183,7 @@ def main():
     value = total_pixels * sample_count / (elapsed / args.steps) / 1e6
 
     # ---- roofline of the shading kernel, from HIP events recorded inside the timed region --------
-    kernel_ms = r.dispatch_ms(min(args.steps, 256))
+    kernel_ms = r.dispatch_ms(max(1, min(args.steps // max(args.timing_stride, 1), 256)))
     kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     visibility = r.read_visibility()
     own_pixels = r.slab_pixel_count(rank) if distributed else total_pixels

@@ -158,9 +158,12 @@ typedef struct shading_pass_s {
 	void* wavefront;
 	/*! timing of the last dispatch in milliseconds (HIP events on device->stream) */
 	float last_dispatch_ms;
-	/*! ring of HIP event pairs, one pair per render_shading_pass call */
+	/*! ring of HIP event pairs, one pair per timed render_shading_pass call */
 	void* timing_ring;
 	uint32_t timing_ring_size, timing_cursor;
+	/*! time every timing_stride-th frame only (0 or 1: every frame; set before
+		create_shading_pass like fast_math); frames rendered so far */
+	uint32_t timing_stride, frame_counter;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
@@ -244,8 +247,8 @@ VKR_API int upload_visibility(application_t* app, const uint32_t* host_primitive
 /*! GPU time of the last render_shading_pass launch in milliseconds, measured with
 	HIP events on the device's stream (blocks until the launch has finished) */
 VKR_API float get_last_dispatch_milliseconds(application_t* app);
-/*! Durations of the most recent `count` launches (oldest first, at most 256 are
-	kept).  Returns how many were written. */
+/*! Durations of the most recent `count` timed launches (oldest first, at most 256 are
+	kept; see timing_stride).  Returns how many were written. */
 VKR_API uint32_t get_dispatch_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
 /*! Number of shadow rays the last render_shading_pass traced (0 when the variant
 	was built without counters) */

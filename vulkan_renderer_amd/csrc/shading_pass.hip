@@ -286,7 +286,9 @@ static int create_timing_ring(shading_pass_t* pass) {
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	int32_t fast_math = pass->fast_math, inline_rays = pass->inline_rays;
+	uint32_t timing_stride = pass->timing_stride;
 	memset(pass, 0, sizeof(*pass));
+	pass->timing_stride = timing_stride;
 	pass->fast_math = fast_math ? 1 : 0;
 	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->variant = -1;
@@ -427,9 +429,13 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
 	bool is_clipped = technique != kTechniqueSolidAngle;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
+	// every timing_stride-th frame is bracketed by a pair of events (an event record costs
+	// about 5 us of idle time on the stream, a tenth of a config-2 frame for the pair)
 	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
 	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
-	(void) hipEventRecord(ring[2 * slot], stream);
+	bool timed = pass->timing_stride <= 1 || pass->frame_counter % pass->timing_stride == 0;
+	++pass->frame_counter;
+	if (timed) (void) hipEventRecord(ring[2 * slot], stream);
 	int status = error_mode != kErrorNone
 		? (pass->fast_math ? vkr_launch_error_display_fast : vkr_launch_error_display_exact)(strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
 		: g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
@@ -441,8 +447,10 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
 		status = hipGetLastError() != hipSuccess;
 	}
-	(void) hipEventRecord(ring[2 * slot + 1], stream);
-	++pass->timing_cursor;
+	if (timed) {
+		(void) hipEventRecord(ring[2 * slot + 1], stream);
+		++pass->timing_cursor;
+	}
 	if (status < 0) {
 		printf("No kernel variant was built for strategy %d, technique %d, vertex capacity %d.\n", strategy, technique, capacity);
 		return 1;

@@ -172,8 +172,9 @@ class HostScene:
 class Renderer(HostScene):
     """The shading pass on one MI355X."""
 
-    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False):
+    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1):
         super().__init__()
+        self.timing_stride = timing_stride
         if self.lib.create_hip_device(C.byref(self.app.device), hip_device, stream):
             raise RuntimeError("no usable HIP device: the shading pass has no CPU fallback")
         self._device = True
@@ -191,6 +192,7 @@ class Renderer(HostScene):
             self.lib.destroy_shading_pass(C.byref(self.app.shading_pass), self._dev())
         self.app.shading_pass.fast_math = int(self.fast_math)
         self.app.shading_pass.inline_rays = int(self.inline_rays)
+        self.app.shading_pass.timing_stride = int(self.timing_stride)
         if self.lib.create_shading_pass(C.byref(self.app.shading_pass), C.byref(self.app)):
             raise RuntimeError("create_shading_pass failed")
 
