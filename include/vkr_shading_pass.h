@@ -156,6 +156,8 @@ typedef struct shading_pass_s {
 	int32_t inline_rays;
 	/*! buffers of the wavefront ray path (ray queue, term streams) */
 	void* wavefront;
+	/*! device counter of the rays traced inside the shading kernel (inline_rays) */
+	void* ray_counter;
 	/*! timing of the last dispatch in milliseconds (HIP events on device->stream) */
 	float last_dispatch_ms;
 	/*! ring of HIP event pairs, one pair per timed render_shading_pass call */

@@ -85,7 +85,6 @@ extern "C" int create_render_targets(render_targets_t* targets, const device_t* 
 // ---- shading pass ----------------------------------------------------------------
 
 // device counter of traced shadow rays, shared by all passes of the process
-static unsigned long long* g_ray_counter = NULL;
 
 // Buffers of the wavefront ray path, sized for the worst case (every sample of every
 // light on every pixel produces a term and a ray) and owned by the pass.
@@ -211,6 +210,7 @@ static int upload_constants(application_t* app, hipStream_t stream) {
 
 extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
 	destroy_constants_ring(pass, device);
+	if (pass->ray_counter) (void) hipFree(pass->ray_counter);
 	destroy_wavefront(pass);
 	if (pass->timing_ring) {
 		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
@@ -411,9 +411,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		}
 	}
 	if (pass->use_ray_tracing) {
-		if (!g_ray_counter && hip_failed(hipMalloc(&g_ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
-		if (pass->inline_rays && hip_failed(hipMemsetAsync(g_ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
-		p.ray_counter = g_ray_counter;
+		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
+		if (pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
+		p.ray_counter = (unsigned long long*) pass->ray_counter;
 	}
 	if (ray_mode == kRaysDeferred) {
 		if (ensure_wavefront(pass, grid_blocks * 256u, 2u * p.light_count * p.sample_count, p.light_count, p.width, p.height)) return 1;
@@ -548,7 +548,7 @@ extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statist
 
 extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	unsigned long long rays = 0;
-	if (!g_ray_counter || !app->shading_pass.use_ray_tracing) return 0;
+	if (!app->shading_pass.ray_counter || !app->shading_pass.use_ray_tracing) return 0;
 	if (!app->shading_pass.inline_rays) {
 		const wavefront_buffers* w = (const wavefront_buffers*) app->shading_pass.wavefront;
 		uint32_t queued[kRayQueueCount];
@@ -556,7 +556,7 @@ extern "C" uint64_t get_last_ray_count(const application_t* app) {
 		for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += queued[q];
 		return rays;
 	}
-	if (vkr_copy_to_host(&rays, g_ray_counter, sizeof(rays), &app->device)) return 0;
+	if (vkr_copy_to_host(&rays, app->shading_pass.ray_counter, sizeof(rays), &app->device)) return 0;
 	return rays;
 }
 
