@@ -50,6 +50,9 @@ typedef struct {
 	uint32_t vertex_count, texturing_technique;
 	v3 rotation_columns[3];
 	v3 vertices_world[O_CAP];
+	/* world-space area; per fan triangle (area of the triangle, area of the fan so far) */
+	float area;
+	v2 fan_areas[O_CAP];
 } light_view_t;
 
 static float rd_f(const uint8_t* p, size_t off) { float f; memcpy(&f, p + off, 4); return f; }
@@ -103,6 +106,10 @@ static light_view_t read_light(const uint8_t* constants, uint32_t index, uint32_
 	const uint8_t* world = p + 160 + 16 * (size_t) vmax;
 	for (uint32_t i = 0; i != vmax && i != O_CAP; ++i)
 		l.vertices_world[i] = mk3(rd_f(world, 16 * i), rd_f(world, 16 * i + 4), rd_f(world, 16 * i + 8));
+	l.area = rd_f(p, 144);
+	const uint8_t* fans = p + 160 + 32 * (size_t) vmax;
+	for (uint32_t i = 0; i + 2 < vmax && i != O_CAP; ++i)
+		l.fan_areas[i] = mk2(rd_f(fans, 16 * i), rd_f(fans, 16 * i + 4));
 	return l;
 }
 
@@ -1021,6 +1028,35 @@ static v3 display_sampling_error(pixel_ctx_t* ctx, const psa_polygon_t* polygon,
 	return mk3(color.x / ctx->k->exposure_factor, color.y / ctx->k->exposure_factor, color.z / ctx->k->exposure_factor);
 }
 
+/* sample_area_polygon_turk, polygon_sampling_related_work.glsl:38-64 (cap = MAX_POLYGON_VERTEX_COUNT) */
+static v3 sample_area_turk(uint32_t vertex_count, uint32_t cap, const v3* vertices, const v2* fan_areas, v2 u) {
+	float target_area = fan_areas[cap - 3].y * u.x;
+	float subtriangle_area = target_area;
+	float triangle_area = fan_areas[0].x;
+	v3 t0 = vertices[1], t1 = vertices[0], t2 = vertices[2];
+	for (uint32_t i = 0; i + 3 != cap; ++i) {
+		if (i + 3 >= vertex_count || fan_areas[i].y >= target_area) break;
+		subtriangle_area = target_area - fan_areas[i].y;
+		triangle_area = fan_areas[i + 1].x;
+		t0 = vertices[i + 2];
+		t2 = vertices[i + 3];
+	}
+	u.x = subtriangle_area / triangle_area;
+	float sqrt_u = sqrtf(u.x);
+	float b0 = 1.0f - sqrt_u, b1 = sqrt_u * u.y, b2 = fmaf(-sqrt_u, u.y, sqrt_u);
+	return add3(add3(scale3(t0, b0), scale3(t1, b1)), scale3(t2, b2));
+}
+
+/* get_area_sample_density, polygon_sampling_related_work.glsl:78-85 */
+static float area_sample_density(v3* out_dir, v3 light_sample, v3 shading_position, v3 light_normal, float light_area) {
+	v3 d = sub3(light_sample, shading_position);
+	float distance_squared = dot3(d, d);
+	float normalization = rsqrt_f(distance_squared);
+	*out_dir = scale3(d, normalization);
+	float projected_area = fabsf(dot3(light_normal, *out_dir)) * light_area;
+	return distance_squared / projected_area;
+}
+
 /* evaluate_polygonal_light_shading, shading_pass.frag.glsl:329-711 */
 static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t* ltc_in, const light_view_t* light, noise_accessor_t* noise) {
 	const oracle_frame_t* f = ctx->f;
@@ -1036,7 +1072,25 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 	ltc_t ltc = *ltc_in;
 	float density_factor = 0.0f;
 
-	if (technique == O_TECHNIQUE_SOLID_ANGLE) {
+	if (technique == O_TECHNIQUE_BASELINE) {
+		/* :332-342: "broken" on purpose, the run time baseline of the paper */
+		v3 corner_offset = sub3(light->translation, sd->position);
+		for (uint32_t s = 0; s != S; ++s) {
+			v2 u = next_noise_2(f, k, noise);
+			v3 dir = normalize3(add3(add3(corner_offset, scale3(light->rotation_columns[0], u.x)), scale3(light->rotation_columns[1], u.y)));
+			result = add3(result, light_mis_estimate(ctx, dir, 1.0f, sd, light));
+		}
+	}
+	else if (technique == O_TECHNIQUE_AREA_TURK) {
+		/* :344-350 */
+		for (uint32_t s = 0; s != S; ++s) {
+			v3 light_sample = sample_area_turk(light->vertex_count, vmax, light->vertices_world, light->fan_areas, next_noise_2(f, k, noise));
+			v3 dir;
+			float density = area_sample_density(&dir, light_sample, sd->position, mk3(light->plane.x, light->plane.y, light->plane.z), light->area);
+			result = add3(result, light_mis_estimate(ctx, dir, density, sd, light));
+		}
+	}
+	else if (technique == O_TECHNIQUE_SOLID_ANGLE) {
 		/* :375-384 */
 		sa_polygon_t pd = prepare_sa(light->vertex_count, vmax, light->vertices_world, sd->position);
 		for (uint32_t s = 0; s != S; ++s) {

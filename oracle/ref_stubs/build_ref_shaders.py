@@ -21,20 +21,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 SHADER_FILES = ["shading_pass.frag.glsl", "polygon_sampling.glsl", "polygon_clipping.glsl", "ltc_utility.glsl",
                 "brdfs.glsl", "noise_utility.glsl", "mesh_quantization.glsl", "polygonal_light_utility.glsl",
-                "shared_constants.glsl", "srgb_utility.glsl", "math_constants.glsl", "unrolling.glsl"]
+                "shared_constants.glsl", "srgb_utility.glsl", "math_constants.glsl", "unrolling.glsl",
+                "polygon_sampling_related_work.glsl"]
 
 
 def translate(name, text):
     """GLSL -> C++ at the token level.  Every rule is syntactic; no arithmetic is touched."""
     out = []
     in_uniform_block = False
+    if name == "polygon_sampling_related_work.glsl":
+        # Only the first two functions of the related-work file are in scope (uniform area
+        # sampling by Turk and its solid-angle density); the Urena / Arvo / Hart samplers
+        # that follow are cut off, together with the cubic solver they include.
+        text = text[:text.index("/*! Holds intermediate values for sampling the solid angle of rectangles")]
+        text = text.replace('#include "cubic_solver.glsl"', "")
     for line in text.split("\n"):
         s = line.strip()
         # directives that mean nothing to a C++ compiler
         if s.startswith("#version") or s.startswith("#extension"):
             continue
-        # the related-work samplers are out of scope; their file only forwards this include
-        line = line.replace('#include "polygon_sampling_related_work.glsl"', '#include "polygon_sampling.glsl"')
         # uniform block -> plain globals
         if re.match(r"layout\s*\(std140.*\)\s*uniform\s+per_frame_constants\s*\{", s):
             in_uniform_block = True
@@ -140,6 +145,9 @@ VARIANTS = [
     dict(strategy=0, technique="projected_solid_angle_biased", lights=1, max_light_vertices=4, samples=1),
     dict(strategy=0, technique="solid_angle", lights=1, max_light_vertices=4, samples=1),
     dict(strategy=1, heuristic=0, technique="clipped_solid_angle", lights=1, max_light_vertices=4, samples=1),
+    # the two simplest related-work techniques (run time baseline, Turk's area sampling)
+    dict(strategy=0, technique="baseline", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
+    dict(strategy=0, technique="area_turk", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
     # error display: backward (diffuse-only path), backward times PSA and forward (combined path)
     dict(strategy=0, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=1),
     dict(strategy=3, heuristic=3, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=2),

@@ -41,6 +41,8 @@ FRAME_CASES = [
     dict(key="biased_psa", lights=QUAD, strategy=0, heuristic=0, samples=1, technique="projected_solid_angle_biased"),
     dict(key="solid_angle", lights=QUAD, strategy=0, heuristic=0, samples=1, technique="solid_angle"),
     dict(key="clipped_solid_angle_ggx", lights=QUAD, strategy=1, heuristic=0, samples=1, technique="clipped_solid_angle"),
+    dict(key="baseline_technique", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="baseline"),
+    dict(key="area_turk_rays", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="area_turk", rays=True),
     dict(key="error_backward_diffuse_only", lights=MIXED, strategy=0, heuristic=0, samples=1, error_display=1),
     dict(key="error_backward_scaled_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=2),
     dict(key="error_forward_specular_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=6),

@@ -41,7 +41,9 @@ def random_light(rng, n):
 def random_case(seed):
     rng = np.random.default_rng(1000 + seed)
     strategy = int(rng.integers(0, 5))
-    if strategy <= 1:
+    if strategy == 0 and rng.random() < 0.2:
+        technique = ["baseline", "area_turk"][int(rng.integers(0, 2))]
+    elif strategy <= 1:
         technique = ["projected_solid_angle", "projected_solid_angle_biased", "solid_angle", "clipped_solid_angle"][int(rng.integers(0, 4))]
     else:
         technique = ["projected_solid_angle", "projected_solid_angle_biased"][int(rng.integers(0, 2))]

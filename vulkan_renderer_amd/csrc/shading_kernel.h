@@ -22,7 +22,7 @@
 namespace vkr {
 
 enum { kStrategyDiffuseOnly = 0, kStrategyDiffuseGgxMis = 1, kStrategySeparately = 2, kStrategyMis = 3, kStrategyRandom = 4 };
-enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3 };
+enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3, kTechniqueBaseline = 4, kTechniqueAreaTurk = 5, kTechniqueCount = 6 };
 enum { kMisBalance = 0, kMisPower = 1, kMisWeighted = 2, kMisOptimalClamped = 3, kMisOptimal = 4 };
 
 struct shade_params {
@@ -407,6 +407,12 @@ VKR_DEV float plane_distance(const light_ref& l, f3 p) {
 	return ((p.x * load_f(l.base, 64) + p.y * load_f(l.base, 68)) + p.z * load_f(l.base, 72)) + 1.0f * load_f(l.base, 76);
 }
 VKR_DEV f3 plane_normal(const light_ref& l) { return load_f3(l.base, 64); }
+VKR_DEV f3 light_translation(const light_ref& l) { return load_f3(l.base, 16); }
+// column k of the plane-to-world rotation (the uniform block is row_major)
+VKR_DEV f3 light_rotation_column(const light_ref& l, uint32_t k) { return mk3(load_f(l.base, 96 + 4 * k), load_f(l.base, 112 + 4 * k), load_f(l.base, 128 + 4 * k)); }
+VKR_DEV float light_area(const light_ref& l) { return load_f(l.base, 144); }
+// (area of fan triangle i, area of the fan up to triangle i); the last entry holds the total
+VKR_DEV f2 light_fan_area(const light_ref& l, uint32_t vmax, uint32_t i) { return mk2(load_f(l.world, 16 * vmax + 16 * i), load_f(l.world, 16 * vmax + 16 * i + 4)); }
 
 // polygonal_light_ray_intersection, polygonal_light_utility.glsl:93-112
 VKR_DEV bool light_ray_intersection(const light_ref& light, uint32_t vmax, f3 origin, f3 end_xyz, float end_w) {
@@ -606,7 +612,47 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 	float density_factor = 0.0f;
 	m43 world_to_shading = ltc_in.world_to_shading;
 
-	if constexpr (TECHNIQUE == kTechniqueSolidAngle) {
+	if constexpr (TECHNIQUE == kTechniqueBaseline) {
+		// shading_pass.frag.glsl:332-342: not a sampler, the run time baseline of the paper
+		f3 corner_offset = light_translation(light) - sd.position;
+		f3 r0 = light_rotation_column(light, 0), r1 = light_rotation_column(light, 1);
+		for (uint32_t s = 0; s != S; ++s) {
+			f2 u = next_noise_2(p, noise);
+			f3 dir = normalize((corner_offset + r0 * u.x) + r1 * u.y);
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, 1.0f, sd, light);
+		}
+	}
+	else if constexpr (TECHNIQUE == kTechniqueAreaTurk) {
+		// uniform area sampling (Turk), polygon_sampling_related_work.glsl:38-85
+		const uint32_t vmax = p.max_light_vertex_count;
+		for (uint32_t s = 0; s != S; ++s) {
+			f2 u = next_noise_2(p, noise);
+			float target_area = light_fan_area(light, vmax, vmax - 3).y * u.x;
+			float subtriangle_area = target_area;
+			float triangle_area = light_fan_area(light, vmax, 0).x;
+			f3 t0 = light_vertex(light, 1), t1 = light_vertex(light, 0), t2 = light_vertex(light, 2);
+			bool done = false;
+			for (uint32_t i = 0; i + 3 < vmax; ++i) {
+				f2 fan = light_fan_area(light, vmax, i);
+				done = done || i + 3 >= count || fan.y >= target_area;
+				if (!done) {
+					subtriangle_area = target_area - fan.y;
+					triangle_area = light_fan_area(light, vmax, i + 1).x;
+					t0 = light_vertex(light, i + 2);
+					t2 = light_vertex(light, i + 3);
+				}
+			}
+			float sqrt_u = square_root(divide(subtriangle_area, triangle_area));
+			float b0 = 1.0f - sqrt_u, b1 = sqrt_u * u.y, b2 = fmaf(-sqrt_u, u.y, sqrt_u);
+			f3 light_sample = (t0 * b0 + t1 * b1) + t2 * b2;
+			f3 d = light_sample - sd.position;
+			float distance_squared = dot(d, d);
+			f3 dir = d * rsqrt(distance_squared);
+			float projected_area = fabsf(dot(plane_normal(light), dir)) * light_area(light);
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, divide(distance_squared, projected_area), sd, light);
+		}
+	}
+	else if constexpr (TECHNIQUE == kTechniqueSolidAngle) {
 		f3 vw[V];
 #pragma unroll
 		for (int i = 0; i < V; ++i) vw[i] = light_vertex(light, min((uint32_t) i, p.max_light_vertex_count - 1));

@@ -43,6 +43,8 @@ static int technique_index(sample_polygon_technique_t technique) {
 	case sample_polygon_projected_solid_angle_biased: return kTechniquePsaBiased;
 	case sample_polygon_solid_angle: return kTechniqueSolidAngle;
 	case sample_polygon_clipped_solid_angle: return kTechniqueClippedSolidAngle;
+	case sample_polygon_baseline: return kTechniqueBaseline;
+	case sample_polygon_area_turk: return kTechniqueAreaTurk;
 	default: return -1;
 	}
 }
@@ -227,7 +229,7 @@ static int validate_settings(const application_t* app) {
 	const scene_specification_t* spec = &app->scene_specification;
 	int technique = technique_index(s->polygon_sampling_technique);
 	if (technique < 0) {
-		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Use solid angle, clipped solid angle or (biased) projected solid angle sampling.\n", (int) s->polygon_sampling_technique);
+		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Use baseline, area (Turk), solid angle, clipped solid angle or (biased) projected solid angle sampling.\n", (int) s->polygon_sampling_technique);
 		return 1;
 	}
 	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased;
@@ -243,6 +245,10 @@ static int validate_settings(const application_t* app) {
 	bool needs_specular = s->sampling_strategies == sampling_strategies_diffuse_specular_separately
 		|| s->sampling_strategies == sampling_strategies_diffuse_specular_mis
 		|| s->sampling_strategies == sampling_strategies_diffuse_specular_random;
+	if ((technique == kTechniqueBaseline || technique == kTechniqueAreaTurk) && s->sampling_strategies != sampling_strategies_diffuse_only) {
+		printf("The baseline and area sampling techniques only exist for the diffuse-only sampling strategy (as in the reference shader).\n");
+		return 1;
+	}
 	if (needs_specular && !is_psa) {
 		printf("Sampling strategies with LTC importance sampling require projected solid angle sampling.\n");
 		return 1;
@@ -298,7 +304,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	if (app->render_settings.trace_shadow_rays && !pass->use_ray_tracing)
 		printf("Shadow rays were requested but the scene has no acceleration structure; rendering without shadows.\n");
 	pass->max_polygon_vertex_count = get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings);
-	pass->variant = (int32_t) app->render_settings.sampling_strategies * 4 + technique_index(app->render_settings.polygon_sampling_technique);
+	pass->variant = (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(app->render_settings.polygon_sampling_technique);
 	pass->constants_size = get_constant_buffer_size(app);
 	if (create_constants_ring(pass, device) || create_timing_ring(pass))
 	{
@@ -346,7 +352,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	if (get_constant_buffer_size(app) != pass->constants_size
 		|| get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings) != pass->max_polygon_vertex_count
-		|| (int32_t) app->render_settings.sampling_strategies * 4 + technique_index(app->render_settings.polygon_sampling_technique) != pass->variant)
+		|| (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(app->render_settings.polygon_sampling_technique) != pass->variant)
 	{
 		printf("Lights or render settings changed in a way that needs a different kernel variant. Recreate the shading pass (the reference recompiles its shader in this situation, main.c:1833-1881).\n");
 		return 1;
@@ -427,7 +433,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
-	bool is_clipped = technique != kTechniqueSolidAngle;
+	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
 	// every timing_stride-th frame is bracketed by a pair of events (an event record costs
 	// about 5 us of idle time on the stream, a tenth of a config-2 frame for the pair)

@@ -29,12 +29,12 @@ static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t s
 template <int TECHNIQUE>
 static int launch_capacity(int capacity, int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
 	switch (capacity) {
-	case 3: if constexpr (TECHNIQUE == kTechniqueSolidAngle) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
+	case 3: if constexpr (TECHNIQUE == kTechniqueSolidAngle || TECHNIQUE == kTechniqueBaseline || TECHNIQUE == kTechniqueAreaTurk) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
 	case 4: return launch_rays<TECHNIQUE, 4>(rays, p, grid, stream);
 	case 5: return launch_rays<TECHNIQUE, 5>(rays, p, grid, stream);
 	case 6: return launch_rays<TECHNIQUE, 6>(rays, p, grid, stream);
 	case 7: return launch_rays<TECHNIQUE, 7>(rays, p, grid, stream);
-	case 8: if constexpr (TECHNIQUE != kTechniqueSolidAngle) return launch_rays<TECHNIQUE, 8>(rays, p, grid, stream); else return -1;
+	case 8: if constexpr (TECHNIQUE != kTechniqueSolidAngle && TECHNIQUE != kTechniqueBaseline && TECHNIQUE != kTechniqueAreaTurk) return launch_rays<TECHNIQUE, 8>(rays, p, grid, stream); else return -1;
 	default: return -1;
 	}
 }
@@ -51,6 +51,12 @@ extern "C" int VKR_LAUNCH_NAME(int technique, int capacity, int rays, const shad
 	// (reference shading_pass.frag.glsl:305-323 returns black otherwise)
 	case kTechniqueSolidAngle: return launch_capacity<kTechniqueSolidAngle>(capacity, rays, *p, grid, s);
 	case kTechniqueClippedSolidAngle: return launch_capacity<kTechniqueClippedSolidAngle>(capacity, rays, *p, grid, s);
+#endif
+#if VKR_STRATEGY == 0
+	// the two simplest related-work techniques of the reference's comparison set; their shader
+	// branches only exist for the diffuse-only strategy (shading_pass.frag.glsl:332-350, :676-686)
+	case kTechniqueBaseline: return launch_capacity<kTechniqueBaseline>(capacity, rays, *p, grid, s);
+	case kTechniqueAreaTurk: return launch_capacity<kTechniqueAreaTurk>(capacity, rays, *p, grid, s);
 #endif
 	default: return -1;
 	}
