@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2), help="2: consecutive frames overlap on the device's two frame streams (like the reference's frame queue)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame with HIP events for the kernel time (roofline)")
     ap.add_argument("--exchange", choices=("rgba8", "rgba32f"), default="rgba8", help="what the ranks all-gather: the encoded frame (default) or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
@@ -99,7 +100,7 @@ def main():
     dataset = synthetic.write_dataset(tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51)
     stream = torch.cuda.current_stream()
     r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays,
-                          timing_stride=args.timing_stride)
+                          timing_stride=args.timing_stride, frames_in_flight=args.frames_in_flight)
     renderer.setup_config(r, config, dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=True,
                           trace_shadow_rays=settings["trace_shadow_rays"])
     r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1)
@@ -183,7 +184,13 @@ def main():
     value = total_pixels * sample_count / (elapsed / args.steps) / 1e6
 
     # ---- roofline of the shading kernel, from HIP events recorded inside the timed region --------
-    kernel_ms = r.dispatch_ms(max(1, min(args.steps // max(args.timing_stride, 1), 256)))
+    timed_frames = max(1, min(args.steps // max(args.timing_stride, 1), 256))
+    launch_ms = r.dispatch_ms(timed_frames)
+    period_ms = r.frame_period_ms(max(1, timed_frames - 1))
+    # one launch of the pass = shade + trace + resolve of one frame.  With frames in flight two
+    # launches share the GPU, so the duration that counts is the period between completions.
+    pipelined = args.frames_in_flight >= 2 and bool(settings["trace_shadow_rays"]) and not args.inline_rays and not distributed
+    kernel_ms = period_ms if (pipelined and period_ms) else launch_ms
     kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     visibility = r.read_visibility()
     own_pixels = r.slab_pixel_count(rank) if distributed else total_pixels
@@ -218,7 +225,8 @@ def main():
         traversal["lane_use"] = round(traversal["node_visits"] / max(64 * traversal["wave_steps"], 1), 3)
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                "kernel_ms": round(kernel_avg_ms, 4), "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel_ms": round(kernel_avg_ms, 4), "launch_latency_ms": round(float(np.mean(launch_ms)), 4) if launch_ms else None,
+                "frames_in_flight": 2 if pipelined else 1, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count,
                                                                    int(r.app.shading_pass.use_ray_tracing), args.mode),
                 "note": "compute-bound pass: FP32 VALU + transcendental issue and BVH latency limit it, not HBM (SURVEY.md 8d)"}

@@ -41,6 +41,11 @@ typedef struct device_s {
 	/*! Compute units and architecture name reported by HIP, for logs */
 	int32_t compute_unit_count;
 	char architecture[64];
+	/*! Two internal hipStream_t on which consecutive frames of a shading pass with
+		frames_in_flight = 2 run, so that the ray tracing of one frame overlaps the
+		shading of the next (the analogue of the reference's frame queue,
+		main.h:380-403).  Owned by the device. */
+	void* frame_streams[2];
 } device_t;
 
 /*! Replaces create_vulkan_device (reference src/vulkan_basics.h:270): selects
@@ -49,7 +54,8 @@ typedef struct device_s {
 VKR_API int create_hip_device(device_t* device, int32_t hip_device, void* existing_stream);
 /*! Replaces destroy_vulkan_device (src/vulkan_basics.h:281) */
 VKR_API void destroy_hip_device(device_t* device);
-/*! Blocks until all work on device->stream is done (vkDeviceWaitIdle analogue) */
+/*! Blocks until all work on device->stream and on the frame streams is done
+	(vkDeviceWaitIdle analogue) */
 VKR_API int wait_for_device(const device_t* device);
 
 #endif

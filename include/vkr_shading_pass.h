@@ -154,7 +154,15 @@ typedef struct shading_pass_s {
 		ordered resolve; default), 1 = every lane walks the BVH inside the shading
 		kernel.  Both give identical results. */
 	int32_t inline_rays;
-	/*! buffers of the wavefront ray path (ray queue, term streams) */
+	/*! 0 or 1: render_shading_pass orders everything on device->stream.  2: frames with
+		wavefront shadow rays alternate between the device's two frame streams and overlap
+		(trace of frame k with shading of frame k + 1); their output is complete for work
+		on device->stream only after finish_frames() or one of the entry points that read
+		or post-process the targets (read_back_*, encode_*, assemble_*, take_screenshot,
+		render_visibility_pass, wait_for_device).  Set before create_shading_pass. */
+	uint32_t frames_in_flight;
+	/*! per frame in flight: buffers of the wavefront ray path (ray queues, term
+		streams, base colour), completion events */
 	void* wavefront;
 	/*! device counter of the rays traced inside the shading kernel (inline_rays) */
 	void* ray_counter;
@@ -223,6 +231,9 @@ VKR_API int render_visibility_pass(application_t* app);
 	`out_radiance` NULL writes app->render_targets.radiance (full frame layout when
 	rank_count == 1, slab layout otherwise). */
 VKR_API int render_shading_pass(application_t* app, void* out_radiance);
+/*! Makes device->stream wait (on the device, the host does not block) for the frames
+	that are still in flight; a no-op without frames_in_flight = 2 */
+VKR_API int finish_frames(application_t* app);
 /*! Number of pixels / floats of one rank's slab for the current schedule */
 VKR_API uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank);
 /*! Pixel (x, y) of every slot of rank `rank`'s slab (0xFFFFFFFF for padding), so a
@@ -252,6 +263,12 @@ VKR_API float get_last_dispatch_milliseconds(application_t* app);
 /*! Durations of the most recent `count` timed launches (oldest first, at most 256 are
 	kept; see timing_stride).  Returns how many were written. */
 VKR_API uint32_t get_dispatch_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
+/*! Time from the end of one timed launch to the end of the next, divided by the number of
+	frames in between (timing_stride): the frame period when frames are submitted back to
+	back, which is what matters with frames in flight, where a launch's own duration
+	(get_dispatch_milliseconds) includes the time it shares the GPU with its neighbour.
+	Most recent `count` intervals, oldest first; returns how many were written. */
+VKR_API uint32_t get_frame_period_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
 /*! Number of shadow rays the last render_shading_pass traced (0 when the variant
 	was built without counters) */
 VKR_API uint64_t get_last_ray_count(const application_t* app);

@@ -27,8 +27,8 @@ def frames():
     return np.load(os.path.join(GOLDEN, "frames.npz"))
 
 
-def render_case(case, dataset, fast_math, width=golden_cases.WIDTH, height=golden_cases.HEIGHT):
-    r = renderer.Renderer(fast_math=fast_math)
+def render_case(case, dataset, fast_math, width=golden_cases.WIDTH, height=golden_cases.HEIGHT, frames_in_flight=1):
+    r = renderer.Renderer(fast_math=fast_math, frames_in_flight=frames_in_flight)
     golden_cases.apply_case(r, case, dataset, width, height)
     r.create_targets()
     r.create_pass()
@@ -174,12 +174,13 @@ def test_missing_variant_and_bad_settings_fail_loudly(golden_dataset):
 
 
 @pytest.mark.gpu
-def test_frames_in_flight_keep_their_own_constants(golden_dataset):
+@pytest.mark.parametrize("frames_in_flight", [1, 2])
+def test_frames_in_flight_keep_their_own_constants(golden_dataset, frames_in_flight):
     """The host records frames without waiting for the device; every frame must see the
     constants that write_constants produced for it (ring of constant buffers), and a
     frame with unchanged constants must reuse them (no stale or future data)."""
     case = golden_cases.FRAME_CASES[3]
-    r, _ = render_case(case, golden_dataset, False, 200, 120)
+    r, _ = render_case(case, golden_dataset, False, 200, 120, frames_in_flight)
     exposures = [0.5, 0.5, 2.0, 3.0, 3.0, 4.0, 5.0, 6.0, 6.0, 7.0]
     expected = []
     for e in sorted(set(exposures)):
@@ -192,7 +193,15 @@ def test_frames_in_flight_keep_their_own_constants(golden_dataset):
     for e, b in zip(exposures, buffers):  # no synchronisation between these launches
         r.app.render_settings.exposure_factor = e
         r.render(b.ptr.value)
-    r.sync()
+    r.sync()  # wait_for_device covers the frame streams
+    # frames that share one target arrive in order: the last one wins
+    for e in (1.0, 9.0, 2.5):
+        r.app.render_settings.exposure_factor = e
+        r.render()
+    last = r.read_radiance()
+    r.app.render_settings.exposure_factor = 2.5
+    r.render()
+    assert np.array_equal(last.view(np.uint32), r.read_radiance().view(np.uint32))
     for e, b in zip(exposures, buffers):
         got = b.download((120, 200, 4), np.float32)
         assert np.array_equal(got.view(np.uint32), expected[e].view(np.uint32)), e

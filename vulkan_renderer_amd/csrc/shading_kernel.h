@@ -55,6 +55,9 @@ struct shade_params {
 	uint8_t* codes;
 	float* terms_visible;
 	float* terms_hidden;
+	// colour of a pixel before its shadowed terms (light display), one per thread; kept apart
+	// from out_radiance so that two frames in flight may share the output target
+	float4* base_color;
 	// kRayQueueCount independent queues, each with its own counter (one counter for the
 	// whole chip saturates at ~88 atomics / us).  Each XCD owns 64 of them: they are filled
 	// by the shading workgroups and drained by the tracing workgroups of that XCD only.
@@ -963,7 +966,7 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 		if constexpr (RAYS == kRaysDeferred) {
 			// hand over to trace_shadow_rays / resolve_shadow_terms: the colour so far
 			// (light display) and the terminated term stream
-			p.out_radiance[out_index] = make_float4(color.x, color.y, color.z, 0.0f);
+			p.base_color[ctx.tid] = make_float4(color.x, color.y, color.z, 0.0f);
 			p.codes[(size_t) ctx.code_cursor * p.thread_count + ctx.tid] = (uint8_t) kCodeEnd;
 		}
 		else
@@ -1097,7 +1100,7 @@ VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 	size_t out_index;
 	if (!locate_pixel(p, px, py, out_index)) return;
 	uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-	float4 base = p.out_radiance[out_index];
+	float4 base = p.base_color[tid];
 	f3 color = mk3(base.x, base.y, base.z);
 	f3 sum = mk3(0.0f, 0.0f, 0.0f);
 	float rcp_samples = 1.0f / (float) p.sample_count;

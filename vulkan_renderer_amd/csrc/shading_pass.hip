@@ -94,33 +94,68 @@ struct wavefront_buffers {
 	uint8_t* codes;
 	float* terms_visible;
 	float* terms_hidden;
+	float4* base_color;
 	float4* ray_queue;
 	uint32_t* ray_queue_size;  // kRayCounterCount live counters (queue sizes, per-XCD work cursors), then last frame's copy
 	uint32_t thread_count, max_terms, max_codes, queue_capacity;
 };
 
-static void destroy_wavefront(shading_pass_t* pass) {
-	wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
-	if (!w) return;
+static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->codes); (void) hipFree(w->terms_visible); (void) hipFree(w->terms_hidden);
-	(void) hipFree(w->ray_queue); (void) hipFree(w->ray_queue_size);
-	free(w);
+	(void) hipFree(w->base_color); (void) hipFree(w->ray_queue); (void) hipFree(w->ray_queue_size);
+	memset(w, 0, sizeof(*w));
+}
+
+// What a frame in flight owns.  With frames_in_flight = 2 consecutive frames alternate
+// between the two contexts (and the device's two frame streams); otherwise only context 0
+// is used, on device->stream.
+struct frame_context {
+	wavefront_buffers buffers;
+	hipEvent_t done;  // recorded behind the last kernel of the frame
+	bool pending;     // device->stream has not been made to wait for `done` yet
+};
+struct frame_pipeline {
+	frame_context contexts[2];
+	hipEvent_t inputs_ready;  // marks what device->stream had submitted when a frame started
+	uint32_t next;            // frames started in pipelined mode
+	uint32_t last;            // context of the most recent frame
+};
+
+static void destroy_wavefront(shading_pass_t* pass) {
+	frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
+	if (!frames) return;
+	for (frame_context& c : frames->contexts) {
+		if (c.done) { (void) hipEventSynchronize(c.done); (void) hipEventDestroy(c.done); }
+		free_wavefront_buffers(&c.buffers);
+	}
+	if (frames->inputs_ready) (void) hipEventDestroy(frames->inputs_ready);
+	free(frames);
 	pass->wavefront = NULL;
 }
 
-static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_t max_terms, uint32_t light_count, uint32_t width, uint32_t height) {
-	wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
+static frame_pipeline* ensure_frames(shading_pass_t* pass) {
+	frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
+	if (frames) return frames;
+	frames = (frame_pipeline*) calloc(1, sizeof(frame_pipeline));
+	pass->wavefront = frames;
+	bool failed = !frames || hipEventCreateWithFlags(&frames->inputs_ready, hipEventDisableTiming) != hipSuccess;
+	for (int i = 0; i != 2 && !failed; ++i) failed = hipEventCreateWithFlags(&frames->contexts[i].done, hipEventDisableTiming) != hipSuccess;
+	if (failed) {
+		printf("Failed to create the events of the frame pipeline.\n");
+		destroy_wavefront(pass);
+		return NULL;
+	}
+	return frames;
+}
+
+static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
 	uint32_t max_codes = max_terms + light_count + 2;
-	(void) width; (void) height;
-	if (w && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
-	destroy_wavefront(pass);
-	w = (wavefront_buffers*) calloc(1, sizeof(wavefront_buffers));
-	pass->wavefront = w;
+	if (w->codes && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
+	free_wavefront_buffers(w);
 	w->thread_count = thread_count; w->max_terms = max_terms; w->max_codes = max_codes;
 	size_t terms = (size_t) max_terms * thread_count;
 	if (terms >= 0xFFFFFFFFull || (size_t) max_codes * thread_count >= 0xFFFFFFFFull) {
 		printf("The wavefront ray queue would need more than 2^32 entries (%u threads x %u terms); render in tiles or use inline rays.\n", thread_count, max_terms);
-		destroy_wavefront(pass);
 		return 1;
 	}
 	// a queue sees every 512th wave (8 XCDs x 64 queues, waves dealt round-robin), every
@@ -129,15 +164,34 @@ static int ensure_wavefront(shading_pass_t* pass, uint32_t thread_count, uint32_
 	if (hipMalloc(&w->codes, (size_t) max_codes * thread_count) != hipSuccess
 		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
 		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
+		|| hipMalloc(&w->base_color, sizeof(float4) * (size_t) thread_count) != hipSuccess
 		|| hipMalloc(&w->ray_queue, (size_t) w->queue_capacity * kRayQueueCount * 32) != hipSuccess
 		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess
 		|| hipMemset(w->ray_queue_size, 0, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess)
 	{
 		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", (terms * 56.0 + (double) max_codes * thread_count) / 1048576.0);
-		destroy_wavefront(pass);
+		free_wavefront_buffers(w);
 		return 1;
 	}
 	return 0;
+}
+
+// bytes that ensure_wavefront() would allocate
+static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
+	double queue_capacity = ((double) (thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * 64.0 * max_terms;
+	return (double) max_terms * thread_count * 24.0 + (double) (max_terms + light_count + 2) * thread_count + 16.0 * thread_count + queue_capacity * kRayQueueCount * 32.0;
+}
+
+extern "C" int finish_frames(application_t* app) {
+	frame_pipeline* frames = (frame_pipeline*) app->shading_pass.wavefront;
+	if (!frames) return 0;
+	int failed = 0;
+	for (frame_context& c : frames->contexts)
+		if (c.pending) {
+			failed |= hip_failed(hipStreamWaitEvent((hipStream_t) app->device.stream, c.done, 0), "waiting for a frame in flight");
+			c.pending = false;
+		}
+	return failed;
 }
 
 // The constant buffer is a small ring: the host may record several frames ahead, so
@@ -150,7 +204,11 @@ constexpr uint32_t kConstantSlots = 4;
 struct constants_ring {
 	void* host[kConstantSlots];
 	void* device[kConstantSlots];
-	hipEvent_t consumed[kConstantSlots];
+	// a slot may be read from device->stream and from the two frame streams
+	hipEvent_t consumed[kConstantSlots][3];
+	hipEvent_t uploaded[kConstantSlots];
+	// bit i: readers[i] (device->stream, frame stream 0, frame stream 1) is ordered behind the upload
+	uint32_t ordered[kConstantSlots];
 	bool in_flight[kConstantSlots];
 	void* scratch;    // write_constants target before it is known whether anything changed
 	uint32_t current; // slot whose device copy the next launch reads
@@ -163,7 +221,8 @@ static void destroy_constants_ring(shading_pass_t* pass, const device_t* device)
 	for (uint32_t i = 0; i != kConstantSlots; ++i) {
 		vkr_device_free(ring->device[i], device);
 		vkr_host_free_pinned(ring->host[i]);
-		if (ring->consumed[i]) (void) hipEventDestroy(ring->consumed[i]);
+		for (hipEvent_t event : ring->consumed[i]) if (event) (void) hipEventDestroy(event);
+		if (ring->uploaded[i]) (void) hipEventDestroy(ring->uploaded[i]);
 	}
 	free(ring->scratch);
 	free(ring);
@@ -180,8 +239,10 @@ static int create_constants_ring(shading_pass_t* pass, const device_t* device) {
 	for (uint32_t i = 0; i != kConstantSlots; ++i) {
 		if (vkr_device_alloc(&ring->device[i], device, pass->constants_size, "the constant buffer")
 			|| vkr_host_alloc_pinned(&ring->host[i], pass->constants_size)
-			|| hip_failed(hipEventCreateWithFlags(&ring->consumed[i], hipEventDisableTiming), "creating upload events"))
+			|| hip_failed(hipEventCreateWithFlags(&ring->uploaded[i], hipEventDisableTiming), "creating upload events"))
 			return 1;
+		for (hipEvent_t& event : ring->consumed[i])
+			if (hip_failed(hipEventCreateWithFlags(&event, hipEventDisableTiming), "creating upload events")) return 1;
 		memset(ring->host[i], 0, pass->constants_size);
 	}
 	pass->constants_device = ring->device[0];
@@ -189,28 +250,49 @@ static int create_constants_ring(shading_pass_t* pass, const device_t* device) {
 	return 0;
 }
 
-// write_constants and, if the bytes changed, upload them into the next free slot
+// write_constants and, if the bytes changed, upload them into the next free slot on
+// `stream`; in any case `stream` is made to wait for the upload of the slot it will read
 static int upload_constants(application_t* app, hipStream_t stream) {
 	shading_pass_t* pass = &app->shading_pass;
 	constants_ring* ring = (constants_ring*) pass->constants_ring;
+	hipStream_t readers[3] = {(hipStream_t) app->device.stream, (hipStream_t) app->device.frame_streams[0], (hipStream_t) app->device.frame_streams[1]};
 	write_constants(ring->scratch, app);
-	if (ring->valid && memcmp(ring->scratch, ring->host[ring->current], pass->constants_size) == 0) return 0;
-	uint32_t slot = ring->valid ? (ring->current + 1) % kConstantSlots : 0;
-	// everything launched so far may read the old slot: it is free again once the stream
-	// has passed this point
-	if (ring->valid) ring->in_flight[ring->current] = hipEventRecord(ring->consumed[ring->current], stream) == hipSuccess;
-	if (ring->in_flight[slot] && hip_failed(hipEventSynchronize(ring->consumed[slot]), "waiting for a free constant buffer")) return 1;
-	ring->in_flight[slot] = false;
-	memcpy(ring->host[slot], ring->scratch, pass->constants_size);
-	if (hip_failed(hipMemcpyAsync(ring->device[slot], ring->host[slot], pass->constants_size, hipMemcpyHostToDevice, stream), "uploading the constants")) return 1;
-	ring->current = slot;
-	ring->valid = true;
-	pass->constants_device = ring->device[slot];
-	pass->constants_host = ring->host[slot];
-	return 0;
+	if (!ring->valid || memcmp(ring->scratch, ring->host[ring->current], pass->constants_size) != 0) {
+		uint32_t slot = ring->valid ? (ring->current + 1) % kConstantSlots : 0;
+		// everything launched so far may read the old slot: it is free again once all three
+		// streams have passed this point
+		if (ring->valid) {
+			for (int i = 0; i != 3; ++i) (void) hipEventRecord(ring->consumed[ring->current][i], readers[i]);
+			ring->in_flight[ring->current] = true;
+		}
+		if (ring->in_flight[slot])
+			for (int i = 0; i != 3; ++i)
+				if (hip_failed(hipEventSynchronize(ring->consumed[slot][i]), "waiting for a free constant buffer")) return 1;
+		ring->in_flight[slot] = false;
+		memcpy(ring->host[slot], ring->scratch, pass->constants_size);
+		if (hip_failed(hipMemcpyAsync(ring->device[slot], ring->host[slot], pass->constants_size, hipMemcpyHostToDevice, stream), "uploading the constants")
+			|| hip_failed(hipEventRecord(ring->uploaded[slot], stream), "recording the upload"))
+			return 1;
+		ring->ordered[slot] = 0;
+		for (int i = 0; i != 3; ++i) if (readers[i] == stream) ring->ordered[slot] |= 1u << i;
+		ring->current = slot;
+		ring->valid = true;
+		pass->constants_device = ring->device[slot];
+		pass->constants_host = ring->host[slot];
+		return 0;
+	}
+	// unchanged constants that another stream uploaded: order this stream behind that upload
+	for (int i = 0; i != 3; ++i)
+		if (readers[i] == stream) {
+			if (ring->ordered[ring->current] & (1u << i)) return 0;
+			ring->ordered[ring->current] |= 1u << i;
+		}
+	return hip_failed(hipStreamWaitEvent(stream, ring->uploaded[ring->current], 0), "waiting for the constants");
 }
 
 extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
+	// frames in flight still read the buffers that are freed below
+	if (device && pass->wavefront) (void) wait_for_device(device);
 	destroy_constants_ring(pass, device);
 	if (pass->ray_counter) (void) hipFree(pass->ray_counter);
 	destroy_wavefront(pass);
@@ -292,9 +374,10 @@ static int create_timing_ring(shading_pass_t* pass) {
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	int32_t fast_math = pass->fast_math, inline_rays = pass->inline_rays;
-	uint32_t timing_stride = pass->timing_stride;
+	uint32_t timing_stride = pass->timing_stride, frames_in_flight = pass->frames_in_flight;
 	memset(pass, 0, sizeof(*pass));
 	pass->timing_stride = timing_stride;
+	pass->frames_in_flight = frames_in_flight;
 	pass->fast_math = fast_math ? 1 : 0;
 	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->variant = -1;
@@ -358,10 +441,8 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		return 1;
 	}
 	hipStream_t stream = (hipStream_t) device->stream;
-	if (upload_constants(app, stream)) return 1;
 	shade_params p;
 	memset(&p, 0, sizeof(p));
-	p.constants = (const uint8_t*) pass->constants_device;
 	p.light_count = app->scene_specification.polygonal_light_count;
 	p.max_light_vertex_count = get_max_polygonal_light_vertex_count(&app->scene_specification);
 	p.sample_count = app->render_settings.sample_count;
@@ -418,19 +499,45 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	if (pass->use_ray_tracing) {
 		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
-		if (pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 		p.ray_counter = (unsigned long long*) pass->ray_counter;
 	}
+	// Frames with wavefront rays may run two at a time: frame k on frame stream k mod 2 with
+	// its own buffers, so that the (latency-bound) tracing of one frame overlaps the
+	// (VALU-bound) shading of the next.  Everything else runs on device->stream, behind
+	// any frame that is still in flight.
+	frame_context* frame = NULL;
+	bool pipelined = false;
 	if (ray_mode == kRaysDeferred) {
-		if (ensure_wavefront(pass, grid_blocks * 256u, 2u * p.light_count * p.sample_count, p.light_count, p.width, p.height)) return 1;
-		wavefront_buffers* w = (wavefront_buffers*) pass->wavefront;
-		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden;
+		frame_pipeline* frames = ensure_frames(pass);
+		if (!frames) return 1;
+		uint32_t thread_count = grid_blocks * 256u, max_terms = 2u * p.light_count * p.sample_count;
+		// two sets of buffers must stay a small part of the 288 GB
+		pipelined = pass->frames_in_flight >= 2 && device->frame_streams[0] && device->frame_streams[1]
+			&& 2.0 * wavefront_bytes(thread_count, max_terms, p.light_count) < 64.0e9;
+		if (!pipelined && finish_frames(app)) return 1;
+		uint32_t index = pipelined ? (frames->next++ & 1u) : 0u;
+		frame = &frames->contexts[index];
+		frames->last = index;
+		if (pipelined) {
+			stream = (hipStream_t) device->frame_streams[index];
+			// inputs (visibility buffer, scene) that were produced on device->stream
+			if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")
+				|| hip_failed(hipStreamWaitEvent(stream, frames->inputs_ready, 0), "waiting for the inputs"))
+				return 1;
+		}
+		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
+		const wavefront_buffers* w = &frame->buffers;
+		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden; p.base_color = w->base_color;
 		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
 		p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
 		p.ray_queue_capacity = w->queue_capacity;
 		const char* knob = getenv("VKR_REFILL_THRESHOLD");
 		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
 	}
+	else if (finish_frames(app)) return 1;
+	if (pass->use_ray_tracing && pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
+	if (upload_constants(app, stream)) return 1;
+	p.constants = (const uint8_t*) pass->constants_device;
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
 	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle;
@@ -450,8 +557,17 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		// persistent: 8 waves per SIMD on every CU
 		uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
 		trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
+		if (pipelined) {
+			// both frames in flight may write the same target: keep the frame order there
+			frame_context* previous = &((frame_pipeline*) pass->wavefront)->contexts[1u - ((frame_pipeline*) pass->wavefront)->last];
+			if (previous->pending) (void) hipStreamWaitEvent(stream, previous->done, 0);
+		}
 		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
 		status = hipGetLastError() != hipSuccess;
+		if (pipelined) {
+			(void) hipEventRecord(frame->done, stream);
+			frame->pending = true;
+		}
 	}
 	if (timed) {
 		(void) hipEventRecord(ring[2 * slot + 1], stream);
@@ -463,7 +579,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	if (status > 0) {
 		// the resolve kernel did not run, so the ray queues may not be empty
-		if (pass->wavefront) (void) hipMemsetAsync(((wavefront_buffers*) pass->wavefront)->ray_queue_size, 0, sizeof(uint32_t) * kRayCounterCount, stream);
+		if (frame && frame->buffers.ray_queue_size) (void) hipMemsetAsync(frame->buffers.ray_queue_size, 0, sizeof(uint32_t) * kRayCounterCount, stream);
 		printf("Launching the shading kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
 		return 1;
 	}
@@ -481,6 +597,23 @@ extern "C" uint32_t get_dispatch_milliseconds(application_t* app, float* out, ui
 		float ms = 0.0f;
 		if (hipEventSynchronize(ring[2 * slot + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1]) != hipSuccess) ms = 0.0f;
 		out[i] = ms;
+	}
+	return count;
+}
+
+extern "C" uint32_t get_frame_period_milliseconds(application_t* app, float* out, uint32_t count) {
+	shading_pass_t* pass = &app->shading_pass;
+	if (!pass->timing_ring || pass->timing_cursor < 2) return 0;
+	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
+	uint32_t stride = pass->timing_stride > 1 ? pass->timing_stride : 1;
+	uint32_t available = (pass->timing_cursor < pass->timing_ring_size ? pass->timing_cursor : pass->timing_ring_size) - 1;
+	if (count > available) count = available;
+	for (uint32_t i = 0; i != count; ++i) {
+		uint32_t later = (pass->timing_cursor - count + i) % pass->timing_ring_size;
+		uint32_t earlier = (later + pass->timing_ring_size - 1) % pass->timing_ring_size;
+		float ms = 0.0f;
+		if (hipEventSynchronize(ring[2 * later + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[2 * earlier + 1], ring[2 * later + 1]) != hipSuccess) ms = 0.0f;
+		out[i] = ms / (float) stride;
 	}
 	return count;
 }
@@ -536,14 +669,16 @@ __global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, cons
 }
 
 extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]) {
-	const wavefront_buffers* w = (const wavefront_buffers*) app->shading_pass.wavefront;
-	if (!w || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays) {
+	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
+	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
+	if (!w || !w->ray_queue || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays) {
 		printf("get_traversal_statistics() needs a frame rendered with wavefront shadow rays.\n");
 		return 1;
 	}
 	unsigned long long* counters = NULL;
 	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 6), "allocating traversal counters")) return 1;
 	hipStream_t stream = (hipStream_t) app->device.stream;
+	(void) finish_frames(app);
 	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 6, stream);
 	bvh_view bvh = make_bvh_view(&app->scene.acceleration_structure);
 	k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
@@ -556,9 +691,10 @@ extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	unsigned long long rays = 0;
 	if (!app->shading_pass.ray_counter || !app->shading_pass.use_ray_tracing) return 0;
 	if (!app->shading_pass.inline_rays) {
-		const wavefront_buffers* w = (const wavefront_buffers*) app->shading_pass.wavefront;
+		const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
+		const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
 		uint32_t queued[kRayQueueCount];
-		if (!w || vkr_copy_to_host(queued, w->ray_queue_size + kRayCounterCount, sizeof(queued), &app->device)) return 0;
+		if (!w || !w->ray_queue_size || finish_frames((application_t*) app) || vkr_copy_to_host(queued, w->ray_queue_size + kRayCounterCount, sizeof(queued), &app->device)) return 0;
 		for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += queued[q];
 		return rays;
 	}
@@ -581,6 +717,7 @@ __global__ void __launch_bounds__(256) k_assemble_frame(const PIXEL* slabs, PIXE
 
 template <typename PIXEL>
 static int assemble_slabs(application_t* app, const void* gathered_slabs, void* out_frame) {
+	if (finish_frames(app)) return 1;
 	shade_params p;
 	memset(&p, 0, sizeof(p));
 	p.width = app->swapchain.extent.width;
@@ -646,6 +783,7 @@ __global__ void __launch_bounds__(256) k_encode_output(const float4* radiance, u
 }
 
 extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
+	if (finish_frames(app)) return 1;
 	uint64_t pixels = (uint64_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	if (!app->render_targets.radiance || !app->render_targets.encoded) return 1;
 	k_encode_output<<<(uint32_t) ((pixels + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) app->render_targets.radiance, (uint32_t*) app->render_targets.encoded,
@@ -654,6 +792,7 @@ extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 }
 
 extern "C" int encode_slab(application_t* app, const void* slab_radiance, void* slab_encoded, uint64_t pixel_count, VkBool32 output_linear_rgb) {
+	if (finish_frames(app)) return 1;
 	if (!slab_radiance || !slab_encoded) return 1;
 	k_encode_output<<<(uint32_t) ((pixel_count + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_encoded,
 		pixel_count, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
@@ -679,6 +818,8 @@ __global__ void __launch_bounds__(256) k_primary_visibility(const uint8_t* const
 }
 
 extern "C" int render_visibility_pass(application_t* app) {
+	// frames in flight read the visibility buffer that this pass overwrites
+	if (finish_frames(app)) return 1;
 	shading_pass_t* pass = &app->shading_pass;
 	const acceleration_structure_t* as = &app->scene.acceleration_structure;
 	if (!as->triangle_vertices || !pass->constants_device) {
@@ -697,18 +838,23 @@ extern "C" int render_visibility_pass(application_t* app) {
 // ---- transfers -------------------------------------------------------------------
 
 extern "C" int read_back_radiance(application_t* app, float* host_rgba) {
+	if (finish_frames(app)) return 1;
 	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	return vkr_copy_to_host(host_rgba, app->render_targets.radiance, sizeof(float) * 4 * pixels, &app->device);
 }
 extern "C" int read_back_encoded(application_t* app, uint8_t* host_rgba8) {
+	if (finish_frames(app)) return 1;
 	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	return vkr_copy_to_host(host_rgba8, app->render_targets.encoded, 4 * pixels, &app->device);
 }
 extern "C" int read_back_visibility(application_t* app, uint32_t* host_primitives) {
+	if (finish_frames(app)) return 1;
 	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	return vkr_copy_to_host(host_primitives, app->render_targets.visibility_buffer, sizeof(uint32_t) * pixels, &app->device);
 }
 extern "C" int upload_visibility(application_t* app, const uint32_t* host_primitives) {
+	// a blocking copy outside the streams: nothing may still be reading the old buffer
+	if (wait_for_device(&app->device)) return 1;
 	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	if (hip_failed(hipMemcpy(app->render_targets.visibility_buffer, host_primitives, sizeof(uint32_t) * pixels, hipMemcpyHostToDevice), "uploading the visibility buffer")) return 1;
 	return 0;

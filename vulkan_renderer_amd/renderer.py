@@ -172,9 +172,10 @@ class HostScene:
 class Renderer(HostScene):
     """The shading pass on one MI355X."""
 
-    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1):
+    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1):
         super().__init__()
         self.timing_stride = timing_stride
+        self.frames_in_flight = frames_in_flight
         if self.lib.create_hip_device(C.byref(self.app.device), hip_device, stream):
             raise RuntimeError("no usable HIP device: the shading pass has no CPU fallback")
         self._device = True
@@ -193,6 +194,7 @@ class Renderer(HostScene):
         self.app.shading_pass.fast_math = int(self.fast_math)
         self.app.shading_pass.inline_rays = int(self.inline_rays)
         self.app.shading_pass.timing_stride = int(self.timing_stride)
+        self.app.shading_pass.frames_in_flight = int(self.frames_in_flight)
         if self.lib.create_shading_pass(C.byref(self.app.shading_pass), C.byref(self.app)):
             raise RuntimeError("create_shading_pass failed")
 
@@ -220,6 +222,15 @@ class Renderer(HostScene):
         out = (C.c_float * count)()
         n = self.lib.get_dispatch_milliseconds(C.byref(self.app), out, count)
         return [float(out[i]) for i in range(n)]
+
+    def frame_period_ms(self, count):
+        out = (C.c_float * count)()
+        n = self.lib.get_frame_period_milliseconds(C.byref(self.app), out, count)
+        return [float(out[i]) for i in range(n)]
+
+    def finish_frames(self):
+        if self.lib.finish_frames(C.byref(self.app)):
+            raise RuntimeError("finish_frames failed")
 
     def last_ray_count(self):
         return int(self.lib.get_last_ray_count(C.byref(self.app)))
