@@ -22,6 +22,11 @@ import argparse
 import json
 import math
 import os
+
+# The two frame streams of the shading pass need hardware queues of their own next to torch's and
+# RCCL's streams; the HIP runtime multiplexes all streams onto 4 queues unless told otherwise.
+# Must be set before the runtime initialises (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import tempfile
 import time
@@ -118,7 +123,8 @@ def main():
         # while frame k + 1 is shaded (two sets of buffers); a frame counts as done when it
         # has been reassembled, and the timed region ends only after the last one has.
         slab_pixels = r.slab_pixel_count(0)
-        slab = torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda")
+        # two of everything: frame k + 1 is shaded while frame k is encoded and exchanged
+        slab = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         if args.exchange == "rgba8":
             send = [torch.zeros(slab_pixels, dtype=torch.int32, device="cuda") for _ in range(2)]
             gathered = [torch.zeros(world * slab_pixels, dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -129,6 +135,11 @@ def main():
             frame = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
         pending = [None, None]
         frame_counter = [0]
+        # The frames run on the device's two frame streams, not on torch's stream.  Before a
+        # frame overwrites buffer set b, those streams wait for the last reader of that set
+        # (the encode kernel resp. the collective), via an event recorded on torch's stream.
+        frame_streams = [torch.cuda.ExternalStream(int(r.app.device.frame_streams[i])) for i in range(2)] if args.frames_in_flight >= 2 else []
+        readers_done = [None, None]
 
         def finish(b):
             if pending[b] is not None:
@@ -137,17 +148,25 @@ def main():
                     r.assemble_encoded(gathered[b].data_ptr(), frame.data_ptr())
                 else:
                     r.assemble(gathered[b].data_ptr(), frame.data_ptr())
+                    readers_done[b] = torch.cuda.Event()
+                    readers_done[b].record()
                 pending[b] = None
 
         def step():
             b = frame_counter[0] & 1
             frame_counter[0] += 1
             finish(b)  # frame k - 2 is complete, its buffers are free again
+            if readers_done[b] is not None:
+                for s in frame_streams:
+                    s.wait_event(readers_done[b])
             if args.exchange == "rgba8":
-                r.render(slab.data_ptr())
-                r.encode_slab(slab.data_ptr(), send[b].data_ptr(), slab_pixels)
+                r.render(slab[b].data_ptr())
+                r.encode_slab(slab[b].data_ptr(), send[b].data_ptr(), slab_pixels)
+                readers_done[b] = torch.cuda.Event()
+                readers_done[b].record()
             else:
                 r.render(send[b].data_ptr())
+                r.finish_frames()  # torch's stream waits for the frame before RCCL reads it
             pending[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
 
         def drain():
@@ -173,6 +192,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    issue_seconds = time.perf_counter() - t0  # host time to queue the steps (a bound if the host cannot keep up)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -189,7 +209,7 @@ def main():
     period_ms = r.frame_period_ms(max(1, timed_frames - 1))
     # one launch of the pass = shade + trace + resolve of one frame.  With frames in flight two
     # launches share the GPU, so the duration that counts is the period between completions.
-    pipelined = args.frames_in_flight >= 2 and bool(settings["trace_shadow_rays"]) and not args.inline_rays and not distributed
+    pipelined = args.frames_in_flight >= 2 and bool(settings["trace_shadow_rays"]) and not args.inline_rays
     kernel_ms = period_ms if (pipelined and period_ms) else launch_ms
     kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     visibility = r.read_visibility()
@@ -290,6 +310,7 @@ def main():
                        "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
                        "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, " + RCCL all-gather of %s slabs overlapped with the next frame" % args.exchange if distributed else ""),
                        "scene_triangles": int(r.app.scene.mesh.triangle_count)},
+            "host_issue_ms_per_step": round(issue_seconds / args.steps * 1e3, 4),
             "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (kernel_avg_ms * 1e-3) / 1e6, 2) if rays else 0.0,
             "roofline": roofline,
         }

@@ -161,6 +161,10 @@ typedef struct shading_pass_s {
 		or post-process the targets (read_back_*, encode_*, assemble_*, take_screenshot,
 		render_visibility_pass, wait_for_device).  Set before create_shading_pass. */
 	uint32_t frames_in_flight;
+	/*! set by the entry points that produce inputs of the pass on device->stream
+		(render_visibility_pass, upload_visibility) and by mark_inputs_changed(): the
+		next frame in flight waits for device->stream once */
+	uint32_t inputs_changed;
 	/*! per frame in flight: buffers of the wavefront ray path (ray queues, term
 		streams, base colour), completion events */
 	void* wavefront;
@@ -234,6 +238,9 @@ VKR_API int render_shading_pass(application_t* app, void* out_radiance);
 /*! Makes device->stream wait (on the device, the host does not block) for the frames
 	that are still in flight; a no-op without frames_in_flight = 2 */
 VKR_API int finish_frames(application_t* app);
+/*! Tell a pass with frames in flight that work queued on device->stream by someone else
+	(not through this library) has changed its inputs - visibility buffer, mesh, tables */
+VKR_API void mark_inputs_changed(application_t* app);
 /*! Number of pixels / floats of one rank's slab for the current schedule */
 VKR_API uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank);
 /*! Pixel (x, y) of every slot of rank `rank`'s slab (0xFFFFFFFF for padding), so a

@@ -127,7 +127,7 @@ class TileSchedule(C.Structure):
 class ShadingPass(C.Structure):
     _fields_ = [("use_ray_tracing", C.c_uint32), ("variant", C.c_int32), ("max_polygon_vertex_count", C.c_uint32),
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t), ("constants_ring", C.c_void_p),
-                ("fast_math", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
+                ("fast_math", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
                 ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32)]
 
 
@@ -205,6 +205,7 @@ SIGNATURES = {
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_frame_period_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "finish_frames": (C.c_int, [P(Application)]),
+    "mark_inputs_changed": (None, [P(Application)]),
     "get_slab_pixel_coordinates": (C.c_uint64, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
     "get_abi_struct_sizes": (C.c_uint32, [P(C.c_uint64), C.c_uint32]),
     "create_experiment_list": (None, [P(ExperimentList)]),

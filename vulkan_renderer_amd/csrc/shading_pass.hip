@@ -182,6 +182,10 @@ static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_
 	return (double) max_terms * thread_count * 24.0 + (double) (max_terms + light_count + 2) * thread_count + 16.0 * thread_count + queue_capacity * kRayQueueCount * 32.0;
 }
 
+extern "C" void mark_inputs_changed(application_t* app) {
+	app->shading_pass.inputs_changed = 1;
+}
+
 extern "C" int finish_frames(application_t* app) {
 	frame_pipeline* frames = (frame_pipeline*) app->shading_pass.wavefront;
 	if (!frames) return 0;
@@ -378,6 +382,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	memset(pass, 0, sizeof(*pass));
 	pass->timing_stride = timing_stride;
 	pass->frames_in_flight = frames_in_flight;
+	pass->inputs_changed = 1;
 	pass->fast_math = fast_math ? 1 : 0;
 	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->variant = -1;
@@ -520,10 +525,16 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		frames->last = index;
 		if (pipelined) {
 			stream = (hipStream_t) device->frame_streams[index];
-			// inputs (visibility buffer, scene) that were produced on device->stream
-			if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")
-				|| hip_failed(hipStreamWaitEvent(stream, frames->inputs_ready, 0), "waiting for the inputs"))
-				return 1;
+			// Inputs that were produced on device->stream (visibility pass, uploads): both frame
+			// streams wait for them once.  Frames do not wait for anything else on
+			// device->stream - if they did, a consumer of frame k there would hold back frame k + 1.
+			if (pass->inputs_changed) {
+				if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")
+					|| hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[0], frames->inputs_ready, 0), "waiting for the inputs")
+					|| hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[1], frames->inputs_ready, 0), "waiting for the inputs"))
+					return 1;
+				pass->inputs_changed = 0;
+			}
 		}
 		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
 		const wavefront_buffers* w = &frame->buffers;
@@ -820,6 +831,7 @@ __global__ void __launch_bounds__(256) k_primary_visibility(const uint8_t* const
 extern "C" int render_visibility_pass(application_t* app) {
 	// frames in flight read the visibility buffer that this pass overwrites
 	if (finish_frames(app)) return 1;
+	app->shading_pass.inputs_changed = 1;
 	shading_pass_t* pass = &app->shading_pass;
 	const acceleration_structure_t* as = &app->scene.acceleration_structure;
 	if (!as->triangle_vertices || !pass->constants_device) {
@@ -855,6 +867,7 @@ extern "C" int read_back_visibility(application_t* app, uint32_t* host_primitive
 extern "C" int upload_visibility(application_t* app, const uint32_t* host_primitives) {
 	// a blocking copy outside the streams: nothing may still be reading the old buffer
 	if (wait_for_device(&app->device)) return 1;
+	app->shading_pass.inputs_changed = 1;
 	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	if (hip_failed(hipMemcpy(app->render_targets.visibility_buffer, host_primitives, sizeof(uint32_t) * pixels, hipMemcpyHostToDevice), "uploading the visibility buffer")) return 1;
 	return 0;
