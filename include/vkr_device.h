@@ -44,7 +44,7 @@ typedef struct device_s {
 	/*! Two internal hipStream_t on which consecutive frames of a shading pass with
 		frames_in_flight = 2 run, so that the ray tracing of one frame overlaps the
 		shading of the next (the analogue of the reference's frame queue,
-		main.h:361-398).  Owned by the device. */
+		main.h:353-390).  Owned by the device. */
 	void* frame_streams[2];
 } device_t;
 
