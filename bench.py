@@ -207,10 +207,13 @@ def main():
     timed_frames = max(1, min(args.steps // max(args.timing_stride, 1), 256))
     launch_ms = r.dispatch_ms(timed_frames)
     period_ms = r.frame_period_ms(max(1, timed_frames - 1))
-    # one launch of the pass = shade + trace + resolve of one frame.  With frames in flight two
-    # launches share the GPU, so the duration that counts is the period between completions.
+    # The dominant kernel is shade_pixels; its launches are bracketed by HIP events on the stream
+    # they run on (every timing_stride-th frame).  One launch of the whole pass is shade + trace +
+    # resolve; with frames in flight two passes share the GPU, so the pass duration that counts
+    # is the period between completions.
     pipelined = args.frames_in_flight >= 2 and bool(settings["trace_shadow_rays"]) and not args.inline_rays
-    kernel_ms = period_ms if (pipelined and period_ms) else launch_ms
+    kernel_ms = r.shading_kernel_ms(timed_frames)
+    pass_ms = float(np.mean(period_ms if (pipelined and period_ms) else launch_ms)) if launch_ms else float("nan")
     kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     visibility = r.read_visibility()
     own_pixels = r.slab_pixel_count(rank) if distributed else total_pixels
@@ -245,11 +248,14 @@ def main():
         traversal["lane_use"] = round(traversal["node_visits"] / max(64 * traversal["wave_steps"], 1), 3)
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                "kernel_ms": round(kernel_avg_ms, 4), "launch_latency_ms": round(float(np.mean(launch_ms)), 4) if launch_ms else None,
+                "kernel_ms": round(kernel_avg_ms, 4), "pass_ms": round(pass_ms, 4),
+                "achieved_over_pass": round(bytes_per_launch / (pass_ms * 1e-3) / 1e9, 3),
+                "pass_latency_ms": round(float(np.mean(launch_ms)), 4) if launch_ms else None,
                 "frames_in_flight": 2 if pipelined else 1, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count,
                                                                    int(r.app.shading_pass.use_ray_tracing), args.mode),
-                "note": "compute-bound pass: FP32 VALU + transcendental issue and BVH latency limit it, not HBM (SURVEY.md 8d)"}
+                "note": "kernel_ms = shade_pixels alone (dominant kernel), pass_ms = shade + trace + resolve per frame; "
+                        "compute-bound pass: FP32 VALU issue and BVH latency limit it, not HBM (SURVEY.md 8d)"}
 
     # ---- CPU baseline and parity on a bounded sample (rank 0, N = 1 only) ------------------------
     cpu_baseline = None
@@ -311,7 +317,7 @@ def main():
                        "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, " + RCCL all-gather of %s slabs overlapped with the next frame" % args.exchange if distributed else ""),
                        "scene_triangles": int(r.app.scene.mesh.triangle_count)},
             "host_issue_ms_per_step": round(issue_seconds / args.steps * 1e3, 4),
-            "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (kernel_avg_ms * 1e-3) / 1e6, 2) if rays else 0.0,
+            "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (pass_ms * 1e-3) / 1e6, 2) if rays else 0.0,
             "roofline": roofline,
         }
         if traversal:

@@ -270,6 +270,9 @@ VKR_API float get_last_dispatch_milliseconds(application_t* app);
 /*! Durations of the most recent `count` timed launches (oldest first, at most 256 are
 	kept; see timing_stride).  Returns how many were written. */
 VKR_API uint32_t get_dispatch_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
+/*! Durations of the shading kernel alone (the dominant kernel of the pass) in the most
+	recent `count` timed launches, HIP events on the stream it ran on */
+VKR_API uint32_t get_shading_kernel_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
 /*! Time from the end of one timed launch to the end of the next, divided by the number of
 	frames in between (timing_stride): the frame period when frames are submitted back to
 	back, which is what matters with frames in flight, where a launch's own duration

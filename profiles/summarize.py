@@ -52,7 +52,7 @@ def main():
             text = [l for l in open(bench).read().splitlines() if l.startswith("{")]
             if text:
                 d = json.loads(text[-1])
-                lines += ["bench.py (un-profiled): **%.1f %s**, %.4f ms/step, kernel %.4f ms (HIP events), %.0f Mrays/s, parity %s" % (
+                lines += ["bench.py (un-profiled): **%.1f %s**, %.4f ms/step, shade_pixels %.4f ms (HIP events), %.0f Mrays/s, parity %s" % (
                     d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d.get("Mrays_per_s", 0), json.dumps(d.get("parity"))), ""]
         stats = kernel_stats(os.path.join(base, "cfg%d_trace" % cfg))
         if stats:

@@ -203,6 +203,7 @@ SIGNATURES = {
     "encode_slab": (C.c_int, [P(Application), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "get_traversal_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
+    "get_shading_kernel_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_frame_period_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "finish_frames": (C.c_int, [P(Application)]),
     "mark_inputs_changed": (None, [P(Application)]),

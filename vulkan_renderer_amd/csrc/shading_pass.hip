@@ -302,7 +302,7 @@ extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* devic
 	destroy_wavefront(pass);
 	if (pass->timing_ring) {
 		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
-		for (uint32_t i = 0; i != 2 * pass->timing_ring_size; ++i) if (ring[i]) (void) hipEventDestroy(ring[i]);
+		for (uint32_t i = 0; i != 3 * pass->timing_ring_size; ++i) if (ring[i]) (void) hipEventDestroy(ring[i]);
 		free(ring);
 	}
 	memset(pass, 0, sizeof(*pass));
@@ -369,9 +369,10 @@ static int validate_settings(const application_t* app) {
 
 static int create_timing_ring(shading_pass_t* pass) {
 	pass->timing_ring_size = 256;
-	hipEvent_t* ring = (hipEvent_t*) calloc(2 * pass->timing_ring_size, sizeof(hipEvent_t));
+	// per timed frame: start, end of the shading kernel, end of the frame
+	hipEvent_t* ring = (hipEvent_t*) calloc(3 * pass->timing_ring_size, sizeof(hipEvent_t));
 	pass->timing_ring = ring;
-	for (uint32_t i = 0; i != 2 * pass->timing_ring_size; ++i)
+	for (uint32_t i = 0; i != 3 * pass->timing_ring_size; ++i)
 		if (hip_failed(hipEventCreate(&ring[i]), "creating timing events")) return 1;
 	return 0;
 }
@@ -559,10 +560,11 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
 	bool timed = pass->timing_stride <= 1 || pass->frame_counter % pass->timing_stride == 0;
 	++pass->frame_counter;
-	if (timed) (void) hipEventRecord(ring[2 * slot], stream);
+	if (timed) (void) hipEventRecord(ring[3 * slot], stream);
 	int status = error_mode != kErrorNone
 		? (pass->fast_math ? vkr_launch_error_display_fast : vkr_launch_error_display_exact)(strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
 		: g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
+	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
 	if (status == 0 && ray_mode == kRaysDeferred) {
 		// enough resident waves to fill the chip; each lane strides over the queue
 		// persistent: 8 waves per SIMD on every CU
@@ -581,7 +583,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		}
 	}
 	if (timed) {
-		(void) hipEventRecord(ring[2 * slot + 1], stream);
+		(void) hipEventRecord(ring[3 * slot + 2], stream);
 		++pass->timing_cursor;
 	}
 	if (status < 0) {
@@ -606,7 +608,22 @@ extern "C" uint32_t get_dispatch_milliseconds(application_t* app, float* out, ui
 	for (uint32_t i = 0; i != count; ++i) {
 		uint32_t slot = (pass->timing_cursor - count + i) % pass->timing_ring_size;
 		float ms = 0.0f;
-		if (hipEventSynchronize(ring[2 * slot + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1]) != hipSuccess) ms = 0.0f;
+		if (hipEventSynchronize(ring[3 * slot + 2]) != hipSuccess || hipEventElapsedTime(&ms, ring[3 * slot], ring[3 * slot + 2]) != hipSuccess) ms = 0.0f;
+		out[i] = ms;
+	}
+	return count;
+}
+
+extern "C" uint32_t get_shading_kernel_milliseconds(application_t* app, float* out, uint32_t count) {
+	shading_pass_t* pass = &app->shading_pass;
+	if (!pass->timing_ring) return 0;
+	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
+	uint32_t available = pass->timing_cursor < pass->timing_ring_size ? pass->timing_cursor : pass->timing_ring_size;
+	if (count > available) count = available;
+	for (uint32_t i = 0; i != count; ++i) {
+		uint32_t slot = (pass->timing_cursor - count + i) % pass->timing_ring_size;
+		float ms = 0.0f;
+		if (hipEventSynchronize(ring[3 * slot + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[3 * slot], ring[3 * slot + 1]) != hipSuccess) ms = 0.0f;
 		out[i] = ms;
 	}
 	return count;
@@ -623,7 +640,7 @@ extern "C" uint32_t get_frame_period_milliseconds(application_t* app, float* out
 		uint32_t later = (pass->timing_cursor - count + i) % pass->timing_ring_size;
 		uint32_t earlier = (later + pass->timing_ring_size - 1) % pass->timing_ring_size;
 		float ms = 0.0f;
-		if (hipEventSynchronize(ring[2 * later + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[2 * earlier + 1], ring[2 * later + 1]) != hipSuccess) ms = 0.0f;
+		if (hipEventSynchronize(ring[3 * later + 2]) != hipSuccess || hipEventElapsedTime(&ms, ring[3 * earlier + 2], ring[3 * later + 2]) != hipSuccess) ms = 0.0f;
 		out[i] = ms / (float) stride;
 	}
 	return count;

@@ -223,6 +223,11 @@ class Renderer(HostScene):
         n = self.lib.get_dispatch_milliseconds(C.byref(self.app), out, count)
         return [float(out[i]) for i in range(n)]
 
+    def shading_kernel_ms(self, count):
+        out = (C.c_float * count)()
+        n = self.lib.get_shading_kernel_milliseconds(C.byref(self.app), out, count)
+        return [float(out[i]) for i in range(n)]
+
     def frame_period_ms(self, count):
         out = (C.c_float * count)()
         n = self.lib.get_frame_period_milliseconds(C.byref(self.app), out, count)
