@@ -211,7 +211,7 @@ def main():
     # they run on (every timing_stride-th frame).  One launch of the whole pass is shade + trace +
     # resolve; with frames in flight two passes share the GPU, so the pass duration that counts
     # is the period between completions.
-    pipelined = args.frames_in_flight >= 2 and bool(settings["trace_shadow_rays"]) and not args.inline_rays
+    pipelined = bool(r.app.shading_pass.last_frame_in_flight)
     kernel_ms = r.shading_kernel_ms(timed_frames)
     pass_ms = float(np.mean(period_ms if (pipelined and period_ms) else launch_ms)) if launch_ms else float("nan")
     kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")

@@ -165,6 +165,9 @@ typedef struct shading_pass_s {
 		(render_visibility_pass, upload_visibility) and by mark_inputs_changed(): the
 		next frame in flight waits for device->stream once */
 	uint32_t inputs_changed;
+	/*! 1 if the last render_shading_pass ran on a frame stream (it falls back to
+		device->stream without wavefront rays or when two sets of buffers would not fit) */
+	uint32_t last_frame_in_flight;
 	/*! per frame in flight: buffers of the wavefront ray path (ray queues, term
 		streams, base colour), completion events */
 	void* wavefront;

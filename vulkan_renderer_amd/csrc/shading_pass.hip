@@ -547,6 +547,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
 	}
 	else if (finish_frames(app)) return 1;
+	pass->last_frame_in_flight = pipelined ? 1u : 0u;
 	if (pass->use_ray_tracing && pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 	if (upload_constants(app, stream)) return 1;
 	p.constants = (const uint8_t*) pass->constants_device;
