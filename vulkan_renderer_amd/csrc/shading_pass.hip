@@ -517,9 +517,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		frame_pipeline* frames = ensure_frames(pass);
 		if (!frames) return 1;
 		uint32_t thread_count = grid_blocks * 256u, max_terms = 2u * p.light_count * p.sample_count;
-		// two sets of buffers must stay a small part of the 288 GB
+		// two sets of buffers must fit comfortably into the 288 GB of HBM next to everything else
 		pipelined = pass->frames_in_flight >= 2 && device->frame_streams[0] && device->frame_streams[1]
-			&& 2.0 * wavefront_bytes(thread_count, max_terms, p.light_count) < 64.0e9;
+			&& 2.0 * wavefront_bytes(thread_count, max_terms, p.light_count) < 192.0e9;
 		if (!pipelined && finish_frames(app)) return 1;
 		uint32_t index = pipelined ? (frames->next++ & 1u) : 0u;
 		frame = &frames->contexts[index];
