@@ -73,7 +73,7 @@ def lib():
         L.oracle_psa_error.argtypes = [fp, C.c_uint32, C.c_float, C.c_float, fp, fp]
         L.oracle_solid_angle_sample.restype = C.c_float
         L.oracle_solid_angle_sample.argtypes = [C.c_uint32, C.c_uint32, fp, fp, C.c_float, C.c_float, fp]
-        for name in ("oracle_atan", "oracle_acos_unit", "oracle_fast_positive_atan"):
+        for name in ("oracle_atan", "oracle_acos_unit", "oracle_fast_positive_atan", "oracle_rsqrt", "oracle_log2"):
             getattr(L, name).restype = C.c_float
             getattr(L, name).argtypes = [C.c_float]
         L.oracle_sincos.argtypes = [C.c_float, fp, fp]

@@ -104,6 +104,8 @@ float oracle_solid_angle_sample(uint32_t vertex_count, uint32_t max_count, const
 /* math */
 float oracle_atan(float x);
 float oracle_acos_unit(float x);
+float oracle_rsqrt(float x);
+float oracle_log2(float x);
 void oracle_sincos(float x, float* s, float* c);
 float oracle_fast_positive_atan(float x);
 float oracle_kahan(float a, float b, float c, float d);

@@ -1480,6 +1480,8 @@ float oracle_solid_angle_sample(uint32_t vertex_count, uint32_t max_count, const
 }
 float oracle_atan(float x) { return o_atan(x); }
 float oracle_acos_unit(float x) { return o_acos_unit(x); }
+float oracle_rsqrt(float x) { return rsqrt_f(x); }
+float oracle_log2(float x) { return o_log2(x); }
 void oracle_sincos(float x, float* s, float* c) { o_sincos(x, s, c); }
 float oracle_fast_positive_atan(float x) { return fast_positive_atan(x); }
 float oracle_kahan(float a, float b, float c, float d) { return kahan(a, b, c, d); }

@@ -1,5 +1,7 @@
 """Size-independent properties of the sampling code (SURVEY.md 8c substitutes for
 the golden vectors the reference does not ship), checked on the CPU oracle."""
+import tempfile
+
 import numpy as np
 import pytest
 
@@ -176,6 +178,16 @@ def test_deterministic_math_is_accurate():
             L.oracle_sincos(float(x), C.byref(s), C.byref(c))
             worst = max(worst, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
         assert worst < 2.5e-7
+        # inversesqrt: integer seed + Newton, at most 0.85 ulp over the whole positive range
+        xs = np.concatenate([rng.uniform(1e-3, 4.0, 20000), np.exp(rng.uniform(-80, 80, 20000))]).astype(np.float32)
+        got = np.array([L.oracle_rsqrt(float(x)) for x in xs], np.float32).astype(np.float64)
+        ref = 1.0 / np.sqrt(xs.astype(np.float64))
+        ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+        assert np.max(np.abs(got - ref) / ulp) <= 0.9
+        # log2 of the range the error display feeds it (1 .. 1e5)
+        xs = np.exp(rng.uniform(0.0, np.log(1.0e5), 20000)).astype(np.float32)
+        got = np.array([L.oracle_log2(float(x)) for x in xs], np.float64)
+        assert np.max(np.abs(got - np.log2(xs.astype(np.float64)))) <= 2.5e-6
     finally:
         oracle.set_math_mode(0)
     # fast_positive_atan: documented maximal error 1.16e-5 (polygon_sampling.glsl:79-82)
@@ -280,3 +292,29 @@ def test_estimators_converge_to_the_same_image(dataset):
     assert lit.sum() > 100
     rel = np.abs(a[lit] - b[lit]).mean() / b[lit].mean()
     assert rel < 0.08, rel
+
+
+def test_deterministic_math_mode_renders_the_same_frames_as_libm():
+    """Math mode 1 (polynomial atan/acos/sincos/log2, Newton inversesqrt: what the GPU mirrors
+    bit for bit) against math mode 0 (libm / IEEE: what is pinned against the reference):
+    the same frames to well within the stated tolerance."""
+    from vulkan_renderer_amd import renderer, synthetic
+    import golden_cases
+    with tempfile.TemporaryDirectory() as d:
+        dataset = synthetic.write_dataset(d, **golden_cases.DATASET)
+        for case in golden_cases.FRAME_CASES:
+            if case.get("error_display") or not case.get("output_linear_rgb", True):
+                continue  # the error display shows rounding errors themselves (see test_gpu_golden.py)
+            hs, frame, _ = golden_cases.build_frame(case, dataset)
+            libm = oracle.shade(frame)
+            oracle.set_math_mode(1)
+            try:
+                deterministic = oracle.shade(frame)
+            finally:
+                oracle.set_math_mode(0)
+            hs.close()
+            difference = deterministic[..., :3].astype(np.float64) - libm[..., :3]
+            # pixels that hit the shader's NaN guard in one mode only are counted, not averaged
+            guard = (np.abs(difference).max(axis=-1) > 0.1)
+            assert guard.sum() <= 2, case["key"]
+            assert np.sqrt((difference[~guard] ** 2).mean()) <= 1.0e-4, case["key"]  # the stated tolerance
