@@ -196,6 +196,11 @@ static inline float vkr_log2f(float x) {
 
 static inline float o_log2(float x) { return g_oracle_math_mode ? vkr_log2f(x) : log2f(x); }
 static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : atanf(t); }
+/* acos on [-1, 1] from the [0, 1] form (mode 1) */
+static inline float o_acos(float x) {
+	if (!g_oracle_math_mode) return acosf(x);
+	return (x < 0.0f) ? (O_PI - vkr_acosf_unit(-x)) : vkr_acosf_unit(x);
+}
 static inline float o_acos_unit(float x) { return g_oracle_math_mode ? vkr_acosf_unit(x) : acosf(x); }
 static inline void o_sincos(float x, float* s, float* c) {
 	if (g_oracle_math_mode) vkr_sincosf(x, s, c);

@@ -1028,6 +1028,166 @@ static v3 display_sampling_error(pixel_ctx_t* ctx, const psa_polygon_t* polygon,
 	return mk3(color.x / ctx->k->exposure_factor, color.y / ctx->k->exposure_factor, color.z / ctx->k->exposure_factor);
 }
 
+/* ---- related work: Urena's rectangle sampling, Arvo's spherical triangles, Hart's warps ----
+ * (polygon_sampling_related_work.glsl:97-386) */
+
+typedef struct {
+	v3 o, x, y, z;
+	float z0, z0sq, x0, y0, y0sq, x1, y1, y1sq, b0, b1, b0sq, k, solid_angle;
+} urena_rectangle_t;
+
+/* prepare_solid_angle_rectangle_sampling_urena, :121-164 */
+static urena_rectangle_t prepare_urena(v3 s, float exl, float eyl, const v3 rotation[3], v3 o) {
+	urena_rectangle_t q;
+	q.o = o;
+	q.x = rotation[0]; q.y = rotation[1]; q.z = rotation[2];
+	v3 d = sub3(s, o);
+	q.z0 = dot3(d, q.z);
+	q.z = (q.z0 > 0.0f) ? neg3(q.z) : q.z;
+	q.z0 = -fabsf(q.z0);
+	q.z0sq = q.z0 * q.z0;
+	q.x0 = dot3(d, q.x);
+	q.y0 = dot3(d, q.y);
+	q.x1 = q.x0 + exl;
+	q.y1 = q.y0 + eyl;
+	q.y0sq = q.y0 * q.y0;
+	q.y1sq = q.y1 * q.y1;
+	v3 v00 = mk3(q.x0, q.y0, q.z0), v01 = mk3(q.x0, q.y1, q.z0), v10 = mk3(q.x1, q.y0, q.z0), v11 = mk3(q.x1, q.y1, q.z0);
+	v3 n0 = normalize3(cross3(v00, v10)), n1 = normalize3(cross3(v10, v11)), n2 = normalize3(cross3(v11, v01)), n3 = normalize3(cross3(v01, v00));
+	float g0 = o_acos(-dot3(n0, n1)), g1 = o_acos(-dot3(n1, n2)), g2 = o_acos(-dot3(n2, n3)), g3 = o_acos(-dot3(n3, n0));
+	q.b0 = n0.z;
+	q.b1 = n2.z;
+	q.b0sq = q.b0 * q.b0;
+	q.k = 2.0f * O_PI - g2 - g3;
+	q.solid_angle = g0 + g1 - q.k;
+	return q;
+}
+
+/* sample_solid_angle_rectangle_urena, :171-193 */
+static v3 sample_urena(const urena_rectangle_t* q, v2 random_numbers) {
+	float u = random_numbers.x, v = random_numbers.y;
+	float au = fmaf(u, q->solid_angle, q->k);
+	float sin_au, cos_au;
+	o_sincos(au, &sin_au, &cos_au);
+	float fu = fmaf(cos_au, q->b0, -q->b1) / sin_au;
+	float cu = rsqrt_f(fmaf(fu, fu, q->b0sq));
+	cu = (fu > 0.0f) ? cu : -cu;
+	cu = g_clamp(cu, -1.0f, 1.0f);
+	float xu = -(cu * q->z0) * rsqrt_f(fmaf(-cu, cu, 1.0f));
+	xu = g_clamp(xu, q->x0, q->x1);
+	float d = sqrtf(xu * xu + q->z0sq);
+	float h0 = q->y0 * rsqrt_f(fmaf(d, d, q->y0sq));
+	float h1 = q->y1 * rsqrt_f(fmaf(d, d, q->y1sq));
+	float hv = h0 + v * (h1 - h0);
+	float mhv2_1 = fmaf(-hv, hv, 1.0f);
+	float yv = (mhv2_1 >= 0.0f) ? ((hv * d) * rsqrt_f(mhv2_1)) : q->y1;
+	return normalize3(add3(add3(scale3(q->x, xu), scale3(q->y, yv)), scale3(q->z, q->z0)));
+}
+
+typedef struct {
+	uint32_t vertex_count;
+	v3 dirs[O_CAP];
+	float fan[O_CAP];
+	v2 opposite[O_CAP];
+	float solid_angle;
+} arvo_polygon_t;
+
+/* prepare_solid_angle_polygon_sampling_arvo, :219-254 */
+static arvo_polygon_t prepare_arvo(uint32_t vertex_count, uint32_t cap, const v3* verts, v3 shading_position) {
+	arvo_polygon_t p;
+	memset(&p, 0, sizeof(p));
+	for (uint32_t i = 0; i != cap; ++i) p.dirs[i] = normalize3(sub3(verts[i], shading_position));
+	float solid_angle = 0.0f;
+	for (uint32_t i = 0; i + 2 != cap; ++i) {
+		if (i >= 1 && i + 2 >= vertex_count) break;
+		v3 n0 = normalize3(cross3(sub3(p.dirs[i + 1], p.dirs[0]), p.dirs[0]));
+		v3 n1 = normalize3(cross3(sub3(p.dirs[i + 2], p.dirs[i + 1]), p.dirs[i + 1]));
+		p.opposite[i].x = -dot3(n0, n1);
+		p.opposite[i].y = sqrtf(g_max(0.0f, fmaf(-p.opposite[i].x, p.opposite[i].x, 1.0f)));
+		float d01 = dot3(p.dirs[0], p.dirs[i + 1]), d02 = dot3(p.dirs[0], p.dirs[i + 2]), d12 = dot3(p.dirs[i + 1], p.dirs[i + 2]);
+		/* determinant(mat3(c0, c1, c2)), expanded along the first column */
+		v3 c0 = p.dirs[0], c1 = p.dirs[i + 1], c2 = p.dirs[i + 2];
+		float volume = c0.x * (c1.y * c2.z - c2.y * c1.z) - c1.x * (c0.y * c2.z - c2.y * c0.z) + c2.x * (c0.y * c1.z - c1.y * c0.z);
+		float tangent = fabsf(volume) / (1.0f + d01 + d02 + d12);
+		solid_angle += 2.0f * positive_atan(tangent, 0);
+		p.fan[i] = solid_angle;
+	}
+	p.solid_angle = solid_angle;
+	p.vertex_count = vertex_count;
+	return p;
+}
+
+/* sample_solid_angle_polygon_arvo, :259-294 */
+static v3 sample_arvo(const arvo_polygon_t* p, uint32_t cap, v2 random_numbers) {
+	float target = p->solid_angle * random_numbers.x;
+	float sub = target;
+	v2 opposite = p->opposite[0];
+	v3 t0 = p->dirs[1], t1 = p->dirs[0], t2 = p->dirs[2];
+	for (uint32_t i = 0; i + 3 != cap; ++i) {
+		if (i + 3 >= p->vertex_count || p->fan[i] >= target) break;
+		sub = target - p->fan[i];
+		t0 = p->dirs[i + 2];
+		t2 = p->dirs[i + 3];
+		opposite = p->opposite[i + 1];
+	}
+	float sn, cs;
+	o_sincos(sub, &sn, &cs);
+	float pp = sn * opposite.x - cs * opposite.y;
+	float q = sn * opposite.y + cs * opposite.x;
+	float u = q - opposite.x;
+	float v = pp + opposite.y * dot3(t0, t1);
+	float s = ((v * q - u * pp) * opposite.x - v) / ((v * pp + u * q) * opposite.y);
+	v3 tangent_2_0 = normalize3(sub3(t2, scale3(t0, dot3(t0, t2))));
+	v3 vertex_2 = add3(scale3(t0, s), scale3(tangent_2_0, sqrtf(g_clamp(fmaf(-s, s, 1.0f), 0.0f, 1.0f))));
+	float z = 1.0f - random_numbers.y * (1.0f - dot3(vertex_2, t1));
+	v3 tangent_2_1 = normalize3(sub3(vertex_2, scale3(t1, dot3(t1, vertex_2))));
+	return add3(scale3(t1, z), scale3(tangent_2_1, sqrtf(g_clamp(fmaf(-z, z, 1.0f), 0.0f, 1.0f))));
+}
+
+typedef struct {
+	sa_polygon_t polygon;
+	float density_0;
+	v2 density_1;
+} hart_bilinear_t;
+
+/* prepare_bilinear_cosine_warp_polygon_sampling_hart, :316-337 */
+static hart_bilinear_t prepare_hart_bilinear(uint32_t vertex_count, uint32_t cap, const v3* verts) {
+	hart_bilinear_t h;
+	h.polygon = prepare_sa(vertex_count, cap, verts, mk3(0.0f, 0.0f, 0.0f));
+	h.density_0 = g_max(0.0f, h.polygon.dirs[0].z);
+	h.density_1.x = g_max(0.0f, h.polygon.dirs[1].z);
+	h.density_1.y = h.polygon.dirs[2].z;
+	for (uint32_t i = 3; i != cap; ++i) h.density_1.y = (i < vertex_count) ? h.polygon.dirs[i].z : h.density_1.y;
+	h.density_1.y = g_max(0.0f, h.density_1.y);
+	float density_sum = 2.0f * h.density_0 + h.density_1.x + h.density_1.y;
+	float normalization = 4.0f / (h.polygon.solid_angle * density_sum);
+	h.density_0 *= normalization;
+	h.density_1 = scale2(h.density_1, normalization);
+	float inv_solid_angle = 1.0f / h.polygon.solid_angle;
+	if (density_sum <= 0.0f) {
+		h.density_0 = inv_solid_angle;
+		h.density_1 = mk2(inv_solid_angle, inv_solid_angle);
+	}
+	return h;
+}
+
+/* linear_warp, :349-353 */
+static float linear_warp(float random_number, float density_0, float density_1) {
+	float lerped_density_sq = mix_fma(density_0 * density_0, density_1 * density_1, random_number);
+	float divisor = density_0 + sqrtf(lerped_density_sq);
+	return random_number * (density_0 + density_1) / divisor;
+}
+
+/* sample_bilinear_cosine_warp_polygon_hart, :373-380 */
+static v3 sample_hart_bilinear(float* out_density, const hart_bilinear_t* h, uint32_t cap, v2 u) {
+	u.y = linear_warp(u.y, 2.0f * h->density_0, h->density_1.x * 1.0f + h->density_1.y * 1.0f);
+	float density_0 = mix_fma(h->density_0, h->density_1.x, u.y);
+	float density_1 = mix_fma(h->density_0, h->density_1.y, u.y);
+	u.x = linear_warp(u.x, density_0, density_1);
+	*out_density = mix_fma(density_0, density_1, u.x);
+	return sample_sa(&h->polygon, cap, u);
+}
+
 /* sample_area_polygon_turk, polygon_sampling_related_work.glsl:38-64 (cap = MAX_POLYGON_VERTEX_COUNT) */
 static v3 sample_area_turk(uint32_t vertex_count, uint32_t cap, const v3* vertices, const v2* fan_areas, v2 u) {
 	float target_area = fan_areas[cap - 3].y * u.x;
@@ -1087,6 +1247,44 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 			v3 light_sample = sample_area_turk(light->vertex_count, vmax, light->vertices_world, light->fan_areas, next_noise_2(f, k, noise));
 			v3 dir;
 			float density = area_sample_density(&dir, light_sample, sd->position, mk3(light->plane.x, light->plane.y, light->plane.z), light->area);
+			result = add3(result, light_mis_estimate(ctx, dir, density, sd, light));
+		}
+	}
+	else if (technique == O_TECHNIQUE_RECTANGLE_SOLID_ANGLE_URENA) {
+		/* :352-362: the light is taken to be the unit square of its plane */
+		urena_rectangle_t pd = prepare_urena(light->translation, light->scaling_x, light->scaling_y, light->rotation_columns, sd->position);
+		for (uint32_t s = 0; s != S; ++s) {
+			v3 dir = sample_urena(&pd, next_noise_2(f, k, noise));
+			result = add3(result, light_mis_estimate(ctx, dir, 1.0f / pd.solid_angle, sd, light));
+		}
+		density_factor = 1.0f / pd.solid_angle;
+	}
+	else if (technique == O_TECHNIQUE_SOLID_ANGLE_ARVO) {
+		/* :364-373 */
+		arvo_polygon_t pd = prepare_arvo(light->vertex_count, vmax, light->vertices_world, sd->position);
+		for (uint32_t s = 0; s != S; ++s) {
+			v3 dir = sample_arvo(&pd, vmax, next_noise_2(f, k, noise));
+			result = add3(result, light_mis_estimate(ctx, dir, 1.0f / pd.solid_angle, sd, light));
+		}
+		density_factor = 1.0f / pd.solid_angle;
+	}
+	else if (technique == O_TECHNIQUE_BILINEAR_COSINE_WARP_HART || technique == O_TECHNIQUE_BILINEAR_COSINE_WARP_CLIPPING_HART) {
+		/* :386-427 */
+		int clipping = technique == O_TECHNIQUE_BILINEAR_COSINE_WARP_CLIPPING_HART;
+		uint32_t cap = vmax + (clipping ? 1 : 0);
+		v3 vs[O_CAP];
+		memset(vs, 0, sizeof(vs));
+		for (uint32_t i = 0; i != vmax; ++i) vs[i] = m43_mul(&ltc.world_to_shading, light->vertices_world[i], 1.0f);
+		uint32_t clipped = light->vertex_count;
+		if (clipping) {
+			clipped = clip_polygon(light->vertex_count, 3, cap, vs);
+			if (clipped == 0) return zero;
+		}
+		hart_bilinear_t pd = prepare_hart_bilinear(clipped, cap, vs);
+		for (uint32_t s = 0; s != S; ++s) {
+			float density;
+			v3 dir = sample_hart_bilinear(&density, &pd, cap, next_noise_2(f, k, noise));
+			dir = m43_mul_transposed(&ltc.world_to_shading, dir);
 			result = add3(result, light_mis_estimate(ctx, dir, density, sd, light));
 		}
 	}

@@ -30,10 +30,11 @@ def translate(name, text):
     out = []
     in_uniform_block = False
     if name == "polygon_sampling_related_work.glsl":
-        # Only the first two functions of the related-work file are in scope (uniform area
-        # sampling by Turk and its solid-angle density); the Urena / Arvo / Hart samplers
-        # that follow are cut off, together with the cubic solver they include.
-        text = text[:text.index("/*! Holds intermediate values for sampling the solid angle of rectangles")]
+        # The first part of the related-work file is in scope: uniform area sampling (Turk),
+        # Urena's rectangle sampling, Arvo's spherical triangles and Hart's bilinear warp.
+        # The biquadratic warp (needs the cubic solver) and Arvo's projected solid angle
+        # sampling that follow are cut off.
+        text = text[:text.index("//! Like bilinear_cosine_warp_polygon_hart_t but for the biquadratic density")]
         text = text.replace('#include "cubic_solver.glsl"', "")
     for line in text.split("\n"):
         s = line.strip()
@@ -89,7 +90,8 @@ def variant_defines(v):
     biased = technique == "projected_solid_angle_biased"
     if biased:
         technique = "projected_solid_angle"
-    clipped = technique in ("clipped_solid_angle", "projected_solid_angle")
+    clipped = technique in ("clipped_solid_angle", "projected_solid_angle", "bilinear_cosine_warp_clipping_hart",
+                            "biquadratic_cosine_warp_clipping_hart", "projected_solid_angle_arvo")
     vmax, vmin = v["max_light_vertices"], v.get("min_light_vertices", v["max_light_vertices"])
     d = {
         "MATERIAL_COUNT": v.get("materials", 3), "POLYGONAL_LIGHT_COUNT": v["lights"], "POLYGONAL_LIGHT_ARRAY_SIZE": max(v["lights"], 1),
@@ -148,6 +150,12 @@ VARIANTS = [
     # the two simplest related-work techniques (run time baseline, Turk's area sampling)
     dict(strategy=0, technique="baseline", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
     dict(strategy=0, technique="area_turk", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
+    # Urena (a unit-square light), Arvo's spherical triangles, Hart's bilinear cosine warp
+    dict(strategy=1, heuristic=0, technique="rectangle_solid_angle_urena", lights=1, max_light_vertices=4, samples=2),
+    dict(strategy=0, technique="solid_angle_arvo", lights=3, min_light_vertices=3, max_light_vertices=6, samples=1),
+    dict(strategy=1, heuristic=1, technique="solid_angle_arvo", lights=1, max_light_vertices=5, samples=2),
+    dict(strategy=0, technique="bilinear_cosine_warp_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
+    dict(strategy=0, technique="bilinear_cosine_warp_clipping_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
     # error display: backward (diffuse-only path), backward times PSA and forward (combined path)
     dict(strategy=0, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=1),
     dict(strategy=3, heuristic=3, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=2),

@@ -43,6 +43,11 @@ FRAME_CASES = [
     dict(key="clipped_solid_angle_ggx", lights=QUAD, strategy=1, heuristic=0, samples=1, technique="clipped_solid_angle"),
     dict(key="baseline_technique", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="baseline"),
     dict(key="area_turk_rays", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="area_turk", rays=True),
+    dict(key="urena_rectangle_ggx", lights=QUAD, strategy=1, heuristic=0, samples=2, technique="rectangle_solid_angle_urena"),
+    dict(key="arvo_solid_angle_mixed", lights=MIXED, strategy=0, heuristic=0, samples=1, technique="solid_angle_arvo"),
+    dict(key="arvo_solid_angle_ggx", lights=PENTAGON, strategy=1, heuristic=1, samples=2, technique="solid_angle_arvo"),
+    dict(key="hart_bilinear", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="bilinear_cosine_warp_hart"),
+    dict(key="hart_bilinear_clipping_rays", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="bilinear_cosine_warp_clipping_hart", rays=True),
     dict(key="error_backward_diffuse_only", lights=MIXED, strategy=0, heuristic=0, samples=1, error_display=1),
     dict(key="error_backward_scaled_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=2),
     dict(key="error_forward_specular_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=6),

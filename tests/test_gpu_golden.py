@@ -158,7 +158,7 @@ def test_missing_variant_and_bad_settings_fail_loudly(golden_dataset):
     r = renderer.Renderer()
     golden_cases.apply_case(r, golden_cases.FRAME_CASES[0], golden_dataset)
     r.create_targets()
-    r.app.render_settings.polygon_sampling_technique = 3  # Arvo's solid angle sampling: related work, out of scope
+    r.app.render_settings.polygon_sampling_technique = 10  # Arvo's projected solid angle sampling: related work, not built
     assert r.lib.create_shading_pass(C.byref(r.app.shading_pass), C.byref(r.app)) == 1
     r.app.render_settings.polygon_sampling_technique = 1  # area sampling exists only for the diffuse-only strategy
     r.app.render_settings.sampling_strategies = 1

@@ -41,8 +41,10 @@ def random_light(rng, n):
 def random_case(seed):
     rng = np.random.default_rng(1000 + seed)
     strategy = int(rng.integers(0, 5))
-    if strategy == 0 and rng.random() < 0.2:
-        technique = ["baseline", "area_turk"][int(rng.integers(0, 2))]
+    if strategy == 0 and rng.random() < 0.35:
+        technique = ["baseline", "area_turk", "bilinear_cosine_warp_hart", "bilinear_cosine_warp_clipping_hart"][int(rng.integers(0, 4))]
+    elif strategy <= 1 and rng.random() < 0.25:
+        technique = ["rectangle_solid_angle_urena", "solid_angle_arvo"][int(rng.integers(0, 2))]
     elif strategy <= 1:
         technique = ["projected_solid_angle", "projected_solid_angle_biased", "solid_angle", "clipped_solid_angle"][int(rng.integers(0, 4))]
     else:

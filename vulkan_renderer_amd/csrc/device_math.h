@@ -178,6 +178,9 @@ VKR_DEV float arccos_unit(float x) {
 	return 2.0f * (z + asin_tail(z, s));
 }
 
+// acos on [-1, 1] (o_acos of oracle/oracle_math.h in math mode 1)
+VKR_DEV float arccos(float x) { return (x < 0.0f) ? (kPi - arccos_unit(-x)) : arccos_unit(x); }
+
 // log2 of a positive normal number: exponent + odd series of the mantissa in
 // [sqrt(1/2), sqrt(2)]; same operations as vkr_log2f in oracle/oracle_math.h
 VKR_DEV float log2_poly(float x) {

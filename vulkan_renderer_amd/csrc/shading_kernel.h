@@ -17,12 +17,14 @@
 // Light count, sample count and the MIS heuristic are wave-uniform run-time values.
 #pragma once
 #include "polygon_sampling.h"
+#include "related_work.h"
 #include "lbvh.h"
 
 namespace vkr {
 
 enum { kStrategyDiffuseOnly = 0, kStrategyDiffuseGgxMis = 1, kStrategySeparately = 2, kStrategyMis = 3, kStrategyRandom = 4 };
-enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3, kTechniqueBaseline = 4, kTechniqueAreaTurk = 5, kTechniqueCount = 6 };
+enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3, kTechniqueBaseline = 4, kTechniqueAreaTurk = 5,
+	kTechniqueUrena = 6, kTechniqueArvoSolidAngle = 7, kTechniqueHartBilinear = 8, kTechniqueHartBilinearClipping = 9, kTechniqueCount = 10 };
 enum { kMisBalance = 0, kMisPower = 1, kMisWeighted = 2, kMisOptimalClamped = 3, kMisOptimal = 4 };
 
 struct shade_params {
@@ -653,6 +655,51 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			f3 dir = d * rsqrt(distance_squared);
 			float projected_area = fabsf(dot(plane_normal(light), dir)) * light_area(light);
 			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, divide(distance_squared, projected_area), sd, light);
+		}
+	}
+	else if constexpr (TECHNIQUE == kTechniqueUrena) {
+		// shading_pass.frag.glsl:352-362: the light is taken to be the unit square of its plane
+		urena_rectangle pd = prepare_urena(light_translation(light), load_f(light.base, 12), load_f(light.base, 28),
+			light_rotation_column(light, 0), light_rotation_column(light, 1), light_rotation_column(light, 2), sd.position);
+		density_factor = rcp(pd.solid_angle);
+		for (uint32_t s = 0; s != S; ++s) {
+			f3 dir = sample_urena(pd, next_noise_2(p, noise));
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
+		}
+	}
+	else if constexpr (TECHNIQUE == kTechniqueArvoSolidAngle) {
+		// :364-373
+		f3 vw[V];
+#pragma unroll
+		for (int i = 0; i < V; ++i) vw[i] = light_vertex(light, min((uint32_t) i, p.max_light_vertex_count - 1));
+		arvo_polygon<V> pd;
+		prepare_arvo<V>(pd, count, vw, sd.position);
+		density_factor = rcp(pd.solid_angle);
+		for (uint32_t s = 0; s != S; ++s) {
+			f3 dir = sample_arvo<V>(pd, next_noise_2(p, noise));
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
+		}
+	}
+	else if constexpr (TECHNIQUE == kTechniqueHartBilinear || TECHNIQUE == kTechniqueHartBilinearClipping) {
+		// :386-427; without clipping the polygon keeps MAX_POLYGONAL_LIGHT_VERTEX_COUNT slots
+		constexpr bool kClipping = TECHNIQUE == kTechniqueHartBilinearClipping;
+		constexpr int kLightSlots = kClipping ? V - 1 : V;
+		f3 vs[V];
+#pragma unroll
+		for (int i = 0; i < kLightSlots; ++i) vs[i] = mul_point(world_to_shading, light_vertex(light, min((uint32_t) i, p.max_light_vertex_count - 1)));
+		if constexpr (kClipping) vs[V - 1] = zero;
+		uint32_t clipped = count;
+		if constexpr (kClipping) {
+			clipped = clip_polygon<V>(count, vs);
+			if (clipped == 0) return zero;
+		}
+		hart_bilinear<V> pd;
+		prepare_hart_bilinear<V>(pd, clipped, vs);
+		for (uint32_t s = 0; s != S; ++s) {
+			float density;
+			f3 dir = sample_hart_bilinear<V>(density, pd, next_noise_2(p, noise));
+			dir = mul_transposed(world_to_shading, dir);
+			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueSolidAngle) {

@@ -45,6 +45,10 @@ static int technique_index(sample_polygon_technique_t technique) {
 	case sample_polygon_clipped_solid_angle: return kTechniqueClippedSolidAngle;
 	case sample_polygon_baseline: return kTechniqueBaseline;
 	case sample_polygon_area_turk: return kTechniqueAreaTurk;
+	case sample_polygon_rectangle_solid_angle_urena: return kTechniqueUrena;
+	case sample_polygon_solid_angle_arvo: return kTechniqueArvoSolidAngle;
+	case sample_polygon_bilinear_cosine_warp_hart: return kTechniqueHartBilinear;
+	case sample_polygon_bilinear_cosine_warp_clipping_hart: return kTechniqueHartBilinearClipping;
 	default: return -1;
 	}
 }
@@ -315,7 +319,7 @@ static int validate_settings(const application_t* app) {
 	const scene_specification_t* spec = &app->scene_specification;
 	int technique = technique_index(s->polygon_sampling_technique);
 	if (technique < 0) {
-		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Use baseline, area (Turk), solid angle, clipped solid angle or (biased) projected solid angle sampling.\n", (int) s->polygon_sampling_technique);
+		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Built: baseline, area (Turk), rectangle solid angle (Urena), solid angle (Arvo and ours), clipped solid angle, bilinear cosine warp (Hart, with and without clipping), (biased) projected solid angle.\n", (int) s->polygon_sampling_technique);
 		return 1;
 	}
 	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased;
@@ -331,8 +335,10 @@ static int validate_settings(const application_t* app) {
 	bool needs_specular = s->sampling_strategies == sampling_strategies_diffuse_specular_separately
 		|| s->sampling_strategies == sampling_strategies_diffuse_specular_mis
 		|| s->sampling_strategies == sampling_strategies_diffuse_specular_random;
-	if ((technique == kTechniqueBaseline || technique == kTechniqueAreaTurk) && s->sampling_strategies != sampling_strategies_diffuse_only) {
-		printf("The baseline and area sampling techniques only exist for the diffuse-only sampling strategy (as in the reference shader).\n");
+	if ((technique == kTechniqueBaseline || technique == kTechniqueAreaTurk || technique == kTechniqueHartBilinear || technique == kTechniqueHartBilinearClipping)
+		&& s->sampling_strategies != sampling_strategies_diffuse_only)
+	{
+		printf("The baseline, area sampling and cosine warp techniques only exist for the diffuse-only sampling strategy (as in the reference shader).\n");
 		return 1;
 	}
 	if (needs_specular && !is_psa) {
@@ -553,7 +559,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	p.constants = (const uint8_t*) pass->constants_device;
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
-	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle;
+	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
 	// every timing_stride-th frame is bracketed by a pair of events (an event record costs
 	// about 5 us of idle time on the stream, a tenth of a config-2 frame for the pair)

@@ -28,13 +28,15 @@ static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t s
 
 template <int TECHNIQUE>
 static int launch_capacity(int capacity, int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
+	// techniques that clip the polygon at the horizon need one more vertex slot (reference main.c:194-216)
+	constexpr bool kClips = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased || TECHNIQUE == kTechniqueClippedSolidAngle || TECHNIQUE == kTechniqueHartBilinearClipping;
 	switch (capacity) {
-	case 3: if constexpr (TECHNIQUE == kTechniqueSolidAngle || TECHNIQUE == kTechniqueBaseline || TECHNIQUE == kTechniqueAreaTurk) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
+	case 3: if constexpr (!kClips) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
 	case 4: return launch_rays<TECHNIQUE, 4>(rays, p, grid, stream);
 	case 5: return launch_rays<TECHNIQUE, 5>(rays, p, grid, stream);
 	case 6: return launch_rays<TECHNIQUE, 6>(rays, p, grid, stream);
 	case 7: return launch_rays<TECHNIQUE, 7>(rays, p, grid, stream);
-	case 8: if constexpr (TECHNIQUE != kTechniqueSolidAngle && TECHNIQUE != kTechniqueBaseline && TECHNIQUE != kTechniqueAreaTurk) return launch_rays<TECHNIQUE, 8>(rays, p, grid, stream); else return -1;
+	case 8: if constexpr (kClips) return launch_rays<TECHNIQUE, 8>(rays, p, grid, stream); else return -1;
 	default: return -1;
 	}
 }
@@ -51,12 +53,17 @@ extern "C" int VKR_LAUNCH_NAME(int technique, int capacity, int rays, const shad
 	// (reference shading_pass.frag.glsl:305-323 returns black otherwise)
 	case kTechniqueSolidAngle: return launch_capacity<kTechniqueSolidAngle>(capacity, rays, *p, grid, s);
 	case kTechniqueClippedSolidAngle: return launch_capacity<kTechniqueClippedSolidAngle>(capacity, rays, *p, grid, s);
+	// related work whose shader branches define a solid angle for the GGX MIS tail
+	case kTechniqueUrena: return launch_capacity<kTechniqueUrena>(capacity, rays, *p, grid, s);
+	case kTechniqueArvoSolidAngle: return launch_capacity<kTechniqueArvoSolidAngle>(capacity, rays, *p, grid, s);
 #endif
 #if VKR_STRATEGY == 0
 	// the two simplest related-work techniques of the reference's comparison set; their shader
 	// branches only exist for the diffuse-only strategy (shading_pass.frag.glsl:332-350, :676-686)
 	case kTechniqueBaseline: return launch_capacity<kTechniqueBaseline>(capacity, rays, *p, grid, s);
 	case kTechniqueAreaTurk: return launch_capacity<kTechniqueAreaTurk>(capacity, rays, *p, grid, s);
+	case kTechniqueHartBilinear: return launch_capacity<kTechniqueHartBilinear>(capacity, rays, *p, grid, s);
+	case kTechniqueHartBilinearClipping: return launch_capacity<kTechniqueHartBilinearClipping>(capacity, rays, *p, grid, s);
 #endif
 	default: return -1;
 	}
