@@ -25,7 +25,8 @@ enum { O_STRATEGY_DIFFUSE_ONLY = 0, O_STRATEGY_DIFFUSE_GGX_MIS = 1, O_STRATEGY_D
 	O_STRATEGY_DIFFUSE_SPECULAR_MIS = 3, O_STRATEGY_DIFFUSE_SPECULAR_RANDOM = 4 };
 enum { O_MIS_BALANCE = 0, O_MIS_POWER = 1, O_MIS_WEIGHTED = 2, O_MIS_OPTIMAL_CLAMPED = 3, O_MIS_OPTIMAL = 4 };
 enum { O_TECHNIQUE_BASELINE = 0, O_TECHNIQUE_AREA_TURK = 1, O_TECHNIQUE_RECTANGLE_SOLID_ANGLE_URENA = 2, O_TECHNIQUE_SOLID_ANGLE_ARVO = 3,
-	O_TECHNIQUE_BILINEAR_COSINE_WARP_HART = 6, O_TECHNIQUE_BILINEAR_COSINE_WARP_CLIPPING_HART = 7, O_TECHNIQUE_SOLID_ANGLE = 4, O_TECHNIQUE_CLIPPED_SOLID_ANGLE = 5,
+	O_TECHNIQUE_BILINEAR_COSINE_WARP_HART = 6, O_TECHNIQUE_BILINEAR_COSINE_WARP_CLIPPING_HART = 7,
+	O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_HART = 8, O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_CLIPPING_HART = 9, O_TECHNIQUE_SOLID_ANGLE = 4, O_TECHNIQUE_CLIPPED_SOLID_ANGLE = 5,
 	O_TECHNIQUE_PROJECTED_SOLID_ANGLE = 11, O_TECHNIQUE_PROJECTED_SOLID_ANGLE_BIASED = 12 };
 
 /* Everything the per-pixel program reads.  Buffers are byte-identical to what
@@ -107,6 +108,8 @@ float oracle_atan(float x);
 float oracle_acos_unit(float x);
 float oracle_rsqrt(float x);
 float oracle_log2(float x);
+float oracle_atan2(float y, float x);
+float oracle_pow_third(float x);
 void oracle_sincos(float x, float* s, float* c);
 float oracle_fast_positive_atan(float x);
 float oracle_kahan(float a, float b, float c, float d);

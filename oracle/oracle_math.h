@@ -60,9 +60,12 @@ static inline v2 fma2s(float s, v2 a, v2 b) { return mk2(fmaf(s, a.x, b.x), fmaf
  * mode 1 (the form shared with the GPU, where 1 / sqrt costs 28 instructions): integer
  * seed, two Newton steps and a third one in residual form; at most 0.85 ulp off over
  * the whole positive range (oracle/tools/fit_math.py checks that), deterministic because
- * every step is a single IEEE operation.  Zero gives a large finite number, not inf. */
+ * every step is a single IEEE operation. */
 extern int g_oracle_math_mode;
 static inline float vkr_rsqrtf(float x) {
+	/* zero, negative numbers, infinity and NaN keep their IEEE results (+-inf, NaN, 0, NaN):
+	 * the shaders lean on them (e.g. 0 * inversesqrt(0) = NaN, then max(0, NaN) = 0) */
+	if (!(x >= 1.17549435e-38f && x < INFINITY)) return 1.0f / sqrtf(x);
 	float hx = 0.5f * x;
 	float y = u2f(0x5F3759DFu - (f2u(x) >> 1));
 	float t = y * y;
@@ -194,7 +197,37 @@ static inline float vkr_log2f(float x) {
 	return fmaf(s * r, 1.44269502f, (float) e);
 }
 
+/* 2^t for |t| < 120: integer part into the exponent, fraction in [-0.5, 0.5] by a Taylor
+ * polynomial of degree 7 in t ln 2 (relative error < 2e-7).  Mirrored by exp2_poly. */
+static inline float vkr_exp2f(float t) {
+	float n = rintf(t);
+	float r = (t - n) * 0.693147182f;
+	float p = 1.98412698e-04f;
+	p = fmaf(p, r, 1.38888892e-03f);
+	p = fmaf(p, r, 8.33333377e-03f);
+	p = fmaf(p, r, 4.16666679e-02f);
+	p = fmaf(p, r, 1.66666672e-01f);
+	p = fmaf(p, r, 0.5f);
+	p = fmaf(p, r, 1.0f);
+	p = fmaf(p, r, 1.0f);
+	return p * u2f((uint32_t) ((int) n + 127) << 23);
+}
+/* pow(x, 1/3) for x >= 0 as the cubic solver of the reference needs it (cubic_solver.glsl:66) */
+static inline float vkr_cbrt_positive(float x) {
+	if (!(x > 0.0f)) return x;
+	return vkr_exp2f(vkr_log2f(x) * (1.0f / 3.0f));
+}
+/* two-argument arctangent from the one-argument form */
+static inline float vkr_atanf(float t);
+static inline float vkr_atan2f(float y, float x) {
+	float a = vkr_atanf(y / x);
+	if (x < 0.0f) a += (y >= 0.0f) ? O_PI : -O_PI;
+	return a;
+}
+
 static inline float o_log2(float x) { return g_oracle_math_mode ? vkr_log2f(x) : log2f(x); }
+static inline float o_atan2(float y, float x) { return g_oracle_math_mode ? vkr_atan2f(y, x) : atan2f(y, x); }
+static inline float o_pow_third(float x) { return g_oracle_math_mode ? vkr_cbrt_positive(x) : powf(x, 1.0f / 3.0f); }
 static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : atanf(t); }
 /* acos on [-1, 1] from the [0, 1] form (mode 1) */
 static inline float o_acos(float x) {

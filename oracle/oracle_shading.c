@@ -1188,6 +1188,113 @@ static v3 sample_hart_bilinear(float* out_density, const hart_bilinear_t* h, uin
 	return sample_sa(&h->polygon, cap, u);
 }
 
+/* solve_cubic, cubic_solver.glsl:29-76: c[0] + c[1] x + c[2] x^2 + c[3] x^3; returns 1 with three
+ * roots or 0 with one root in roots[0] */
+static int solve_cubic(float roots[3], const float coeffs[4]) {
+	float c0 = coeffs[0] / coeffs[3], c1 = coeffs[1] / coeffs[3], c2 = coeffs[2] / coeffs[3];
+	c1 = c1 / 3.0f;
+	c2 = c2 / 3.0f;
+	float d0 = fmaf(-c2, c2, c1), d1 = fmaf(-c1, c2, c0), d2 = c2 * c0 - c1 * c1;
+	float discriminant = 4.0f * d0 * d2 - d1 * d1;
+	float sqrt_abs_discriminant = sqrtf(fabsf(discriminant));
+	float depressed_0 = fmaf(-2.0f * c2, d0, d1), depressed_1 = d0;
+	if (discriminant >= 0.0f) {
+		float theta = o_atan2(sqrt_abs_discriminant, -depressed_0) * (1.0f / 3.0f);
+		float sn, cs;
+		o_sincos(theta, &sn, &cs);
+		const float sqrt_three_quarters = 0.866025388f; /* sqrt(0.75f) */
+		float r0 = cs, r1 = fmaf(-sqrt_three_quarters, sn, -0.5f * cs), r2 = fmaf(sqrt_three_quarters, sn, -0.5f * cs);
+		float scale = 2.0f * sqrtf(-depressed_1);
+		roots[0] = fmaf(scale, r0, -c2);
+		roots[1] = fmaf(scale, r1, -c2);
+		roots[2] = fmaf(scale, r2, -c2);
+		return 1;
+	}
+	float signed_sqrt_discriminant = (depressed_0 < 0.0f) ? sqrt_abs_discriminant : -sqrt_abs_discriminant;
+	float quadratic_root = 0.5f * (signed_sqrt_discriminant - depressed_0);
+	float cube_root_0 = o_pow_third(fabsf(quadratic_root));
+	cube_root_0 = (quadratic_root < 0.0f) ? -cube_root_0 : cube_root_0;
+	float cube_root_1 = -depressed_1 / cube_root_0;
+	roots[0] = (cube_root_0 + cube_root_1) - c2;
+	roots[1] = roots[2] = 0.0f;
+	return 0;
+}
+
+typedef struct {
+	sa_polygon_t polygon;
+	float density_0;
+	v3 density_1, density_2;
+} hart_biquadratic_t;
+
+/* prepare_biquadratic_cosine_warp_polygon_sampling_hart, :405-446 */
+static hart_biquadratic_t prepare_hart_biquadratic(uint32_t vertex_count, uint32_t cap, const v3* verts) {
+	hart_biquadratic_t h;
+	h.polygon = prepare_sa(vertex_count, cap, verts, mk3(0.0f, 0.0f, 0.0f));
+	v3 last_vertex = h.polygon.dirs[2];
+	for (uint32_t i = 3; i != cap; ++i) last_vertex = (i < vertex_count) ? h.polygon.dirs[i] : last_vertex;
+	v3 vertex_0 = h.polygon.dirs[0];
+	h.density_0 = g_max(0.0f, vertex_0.z);
+	h.density_2.x = g_max(0.0f, h.polygon.dirs[1].z);
+	h.density_2.z = g_max(0.0f, last_vertex.z);
+	v3 sample_2_1 = sample_sa(&h.polygon, cap, mk2(0.5f, 1.0f));
+	h.density_2.y = g_max(0.0f, sample_2_1.z);
+	v3 far_vertices[3] = {vertex_0, sample_2_1, last_vertex};
+	float density_1[3];
+	for (int i = 0; i != 3; ++i) {
+		float s2 = dot3(vertex_0, far_vertices[i]);
+		float s = fmaf(0.5f, s2, 0.5f);
+		float t = sqrtf(g_max(0.0f, fmaf(-s, s, 1.0f)));
+		float t_axis_z = fmaf(-s2, vertex_0.z, far_vertices[i].z);
+		float normalization_t_axis = rsqrt_f(2.0f * fmaf(-s2, s2, 1.0f));
+		float sample_1_i_z = s * vertex_0.z + (t * normalization_t_axis) * t_axis_z;
+		density_1[i] = g_max(0.0f, sample_1_i_z);
+	}
+	h.density_1 = mk3(density_1[0], density_1[1], density_1[2]);
+	float density_sum = 3.0f * h.density_0 + ((h.density_1.x + h.density_1.y) + h.density_1.z) + ((h.density_2.x + h.density_2.y) + h.density_2.z);
+	float normalization = 9.0f / (h.polygon.solid_angle * density_sum);
+	h.density_0 *= normalization;
+	h.density_1 = scale3(h.density_1, normalization);
+	h.density_2 = scale3(h.density_2, normalization);
+	float inv_solid_angle = 1.0f / h.polygon.solid_angle;
+	if (density_sum <= 0.0f) {
+		h.density_0 = inv_solid_angle;
+		h.density_1 = h.density_2 = mk3(inv_solid_angle, inv_solid_angle, inv_solid_angle);
+	}
+	return h;
+}
+
+/* quadratic_warp, :457-474 */
+static float quadratic_warp(float random_number, float density_0, float density_1, float density_2) {
+	float q0 = density_0, q1 = 2.0f * (density_1 - density_0), q2 = density_0 - 2.0f * density_1 + density_2;
+	float cubic[4] = {0.0f, q0, 0.5f * q1, (1.0f / 3.0f) * q2};
+	random_number *= (cubic[1] + cubic[2]) + cubic[3];
+	cubic[0] = -random_number;
+	float roots[3];
+	if (solve_cubic(roots, cubic)) {
+		float result = roots[0];
+		result = (roots[1] >= 0.0f && roots[1] <= 1.0f) ? roots[1] : result;
+		result = (roots[2] >= 0.0f && roots[2] <= 1.0f) ? roots[2] : result;
+		return result;
+	}
+	return roots[0];
+}
+
+/* quadratic_bezier, :484-488 */
+static float quadratic_bezier(float b00, float b01, float b02, float location) {
+	return mix_fma(mix_fma(b00, b01, location), mix_fma(b01, b02, location), location);
+}
+
+/* sample_biquadratic_cosine_warp_polygon_hart, :493-503 */
+static v3 sample_hart_biquadratic(float* out_density, const hart_biquadratic_t* h, uint32_t cap, v2 u) {
+	u.y = quadratic_warp(u.y, 3.0f * h->density_0, (h->density_1.x + h->density_1.y) + h->density_1.z, (h->density_2.x + h->density_2.y) + h->density_2.z);
+	float density_0 = quadratic_bezier(h->density_0, h->density_1.x, h->density_2.x, u.y);
+	float density_1 = quadratic_bezier(h->density_0, h->density_1.y, h->density_2.y, u.y);
+	float density_2 = quadratic_bezier(h->density_0, h->density_1.z, h->density_2.z, u.y);
+	u.x = quadratic_warp(u.x, density_0, density_1, density_2);
+	*out_density = quadratic_bezier(density_0, density_1, density_2, u.x);
+	return sample_sa(&h->polygon, cap, u);
+}
+
 /* sample_area_polygon_turk, polygon_sampling_related_work.glsl:38-64 (cap = MAX_POLYGON_VERTEX_COUNT) */
 static v3 sample_area_turk(uint32_t vertex_count, uint32_t cap, const v3* vertices, const v2* fan_areas, v2 u) {
 	float target_area = fan_areas[cap - 3].y * u.x;
@@ -1284,6 +1391,26 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 		for (uint32_t s = 0; s != S; ++s) {
 			float density;
 			v3 dir = sample_hart_bilinear(&density, &pd, cap, next_noise_2(f, k, noise));
+			dir = m43_mul_transposed(&ltc.world_to_shading, dir);
+			result = add3(result, light_mis_estimate(ctx, dir, density, sd, light));
+		}
+	}
+	else if (technique == O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_HART || technique == O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_CLIPPING_HART) {
+		/* :386-401, :428-438 */
+		int clipping = technique == O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_CLIPPING_HART;
+		uint32_t cap = vmax + (clipping ? 1 : 0);
+		v3 vs[O_CAP];
+		memset(vs, 0, sizeof(vs));
+		for (uint32_t i = 0; i != vmax; ++i) vs[i] = m43_mul(&ltc.world_to_shading, light->vertices_world[i], 1.0f);
+		uint32_t clipped = light->vertex_count;
+		if (clipping) {
+			clipped = clip_polygon(light->vertex_count, 3, cap, vs);
+			if (clipped == 0) return zero;
+		}
+		hart_biquadratic_t pd = prepare_hart_biquadratic(clipped, cap, vs);
+		for (uint32_t s = 0; s != S; ++s) {
+			float density;
+			v3 dir = sample_hart_biquadratic(&density, &pd, cap, next_noise_2(f, k, noise));
 			dir = m43_mul_transposed(&ltc.world_to_shading, dir);
 			result = add3(result, light_mis_estimate(ctx, dir, density, sd, light));
 		}
@@ -1680,6 +1807,8 @@ float oracle_atan(float x) { return o_atan(x); }
 float oracle_acos_unit(float x) { return o_acos_unit(x); }
 float oracle_rsqrt(float x) { return rsqrt_f(x); }
 float oracle_log2(float x) { return o_log2(x); }
+float oracle_atan2(float y, float x) { return o_atan2(y, x); }
+float oracle_pow_third(float x) { return o_pow_third(x); }
 void oracle_sincos(float x, float* s, float* c) { o_sincos(x, s, c); }
 float oracle_fast_positive_atan(float x) { return fast_positive_atan(x); }
 float oracle_kahan(float a, float b, float c, float d) { return kahan(a, b, c, d); }

@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SHADER_FILES = ["shading_pass.frag.glsl", "polygon_sampling.glsl", "polygon_clipping.glsl", "ltc_utility.glsl",
                 "brdfs.glsl", "noise_utility.glsl", "mesh_quantization.glsl", "polygonal_light_utility.glsl",
                 "shared_constants.glsl", "srgb_utility.glsl", "math_constants.glsl", "unrolling.glsl",
-                "polygon_sampling_related_work.glsl"]
+                "polygon_sampling_related_work.glsl", "cubic_solver.glsl"]
 
 
 def translate(name, text):
@@ -31,11 +31,9 @@ def translate(name, text):
     in_uniform_block = False
     if name == "polygon_sampling_related_work.glsl":
         # The first part of the related-work file is in scope: uniform area sampling (Turk),
-        # Urena's rectangle sampling, Arvo's spherical triangles and Hart's bilinear warp.
-        # The biquadratic warp (needs the cubic solver) and Arvo's projected solid angle
-        # sampling that follow are cut off.
-        text = text[:text.index("//! Like bilinear_cosine_warp_polygon_hart_t but for the biquadratic density")]
-        text = text.replace('#include "cubic_solver.glsl"', "")
+        # Urena's rectangle sampling, Arvo's spherical triangles and Hart's cosine warps.
+        # Arvo's projected solid angle sampling, which follows, is cut off.
+        text = text[:text.index("//! Holds information that Arvo's projected solid angle sampling technique")]
     for line in text.split("\n"):
         s = line.strip()
         # directives that mean nothing to a C++ compiler
@@ -156,6 +154,8 @@ VARIANTS = [
     dict(strategy=1, heuristic=1, technique="solid_angle_arvo", lights=1, max_light_vertices=5, samples=2),
     dict(strategy=0, technique="bilinear_cosine_warp_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
     dict(strategy=0, technique="bilinear_cosine_warp_clipping_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
+    dict(strategy=0, technique="biquadratic_cosine_warp_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
+    dict(strategy=0, technique="biquadratic_cosine_warp_clipping_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
     # error display: backward (diffuse-only path), backward times PSA and forward (combined path)
     dict(strategy=0, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=1),
     dict(strategy=3, heuristic=3, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=2),

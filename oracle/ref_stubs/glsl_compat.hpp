@@ -30,6 +30,7 @@ template <class V, class T, int A, int B> struct swz2 {
 	swz2& operator=(const V& v) { T a = v.x, b = v.y; d[A] = a; d[B] = b; return *this; }
 	swz2& operator=(const swz2& o) { return *this = V(o); }
 	swz2& operator*=(T s) { d[A] *= s; d[B] *= s; return *this; }
+	swz2& operator/=(T s) { d[A] /= s; d[B] /= s; return *this; }
 	swz2& operator*=(const V& v) { d[A] *= v.x; d[B] *= v.y; return *this; }
 	swz2& operator+=(const V& v) { d[A] += v.x; d[B] += v.y; return *this; }
 };
@@ -39,6 +40,7 @@ template <class V, class T, int A, int B, int C> struct swz3 {
 	swz3& operator=(const V& v) { T a = v.x, b = v.y, c = v.z; d[A] = a; d[B] = b; d[C] = c; return *this; }
 	swz3& operator=(const swz3& o) { return *this = V(o); }
 	swz3& operator*=(T s) { d[A] *= s; d[B] *= s; d[C] *= s; return *this; }
+	swz3& operator/=(T s) { d[A] /= s; d[B] /= s; d[C] /= s; return *this; }
 };
 template <class V, class T, int A, int B, int C, int D> struct swz4 {
 	T d[4];
@@ -73,7 +75,7 @@ struct P##vec3 { \
 }; \
 struct P##vec4 { \
 	union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; T d[4]; \
-		swz2<P##vec2, T, 0, 1> xy; swz2<P##vec2, T, 2, 3> zw; swz2<P##vec2, T, 0, 1> rg; swz2<P##vec2, T, 2, 3> ba; \
+		swz2<P##vec2, T, 0, 1> xy; swz2<P##vec2, T, 1, 2> yz; swz2<P##vec2, T, 2, 3> zw; swz2<P##vec2, T, 0, 1> rg; swz2<P##vec2, T, 2, 3> ba; \
 		swz3<P##vec3, T, 0, 1, 2> xyz; swz3<P##vec3, T, 1, 2, 3> yzw; swz3<P##vec3, T, 0, 1, 2> rgb; \
 		swz4<P##vec4, T, 2, 3, 0, 1> zwxy; }; \
 	P##vec4() : x(0), y(0), z(0), w(0) {} \

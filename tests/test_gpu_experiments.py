@@ -64,4 +64,4 @@ def test_experiment_from_the_table_runs_end_to_end(tmp_path):
     assert 2 <= len(colors) <= 22  # background + a subset of the 20 colour bins
     # an experiment that needs a related-work sampler is refused with the library's message
     with pytest.raises(RuntimeError):
-        experiments.run_experiment(index + 13, root, frames=1, warmup=0, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
+        experiments.run_experiment(index + 15, root, frames=1, warmup=0, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)

@@ -42,7 +42,8 @@ def random_case(seed):
     rng = np.random.default_rng(1000 + seed)
     strategy = int(rng.integers(0, 5))
     if strategy == 0 and rng.random() < 0.35:
-        technique = ["baseline", "area_turk", "bilinear_cosine_warp_hart", "bilinear_cosine_warp_clipping_hart"][int(rng.integers(0, 4))]
+        technique = ["baseline", "area_turk", "bilinear_cosine_warp_hart", "bilinear_cosine_warp_clipping_hart",
+                     "biquadratic_cosine_warp_hart", "biquadratic_cosine_warp_clipping_hart"][int(rng.integers(0, 6))]
     elif strategy <= 1 and rng.random() < 0.25:
         technique = ["rectangle_solid_angle_urena", "solid_angle_arvo"][int(rng.integers(0, 2))]
     elif strategy <= 1:

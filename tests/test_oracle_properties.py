@@ -305,6 +305,12 @@ def test_deterministic_math_mode_renders_the_same_frames_as_libm():
         for case in golden_cases.FRAME_CASES:
             if case.get("error_display") or not case.get("output_linear_rgb", True):
                 continue  # the error display shows rounding errors themselves (see test_gpu_golden.py)
+            if "biquadratic" in case.get("technique", ""):
+                # Hart's biquadratic warp evaluates inversesqrt(2 (1 - (v0 . v0)^2)) for the unit vector
+                # v0 (polygon_sampling_related_work.glsl:431-435): the argument is rounding noise of
+                # either sign, so one of its nine density samples - and with it every warped sample -
+                # changes with the last bit of normalize().  Not comparable between arithmetic modes.
+                continue
             hs, frame, _ = golden_cases.build_frame(case, dataset)
             libm = oracle.shade(frame)
             oracle.set_math_mode(1)

@@ -103,9 +103,15 @@ VKR_DEV float rsqrt(float x) {
 	t = y * y;
 	y = y * fmaf(-hx, t, 1.5f);
 	t = y * y;
-	return fmaf(y, fmaf(-hx, t, 0.5f), y);
+	y = fmaf(y, fmaf(-hx, t, 0.5f), y);
+	// zero, negative numbers, infinity and NaN keep their IEEE results (+-inf, NaN, 0, NaN), which
+	// the hardware instruction delivers exactly; the shaders lean on them.  (Denormal arguments
+	// would differ from the oracle's 1 / sqrt; sums of squares are zero or far above 1e-38.)
+	bool ordinary = x >= 1.17549435e-38f && x < __builtin_inff();
+	return ordinary ? y : __builtin_amdgcn_rsqf(x);
 #endif
 }
+
 VKR_DEV f3 normalize(f3 a) { return a * rsqrt(dot(a, a)); }
 VKR_DEV f2 normalize(f2 a) { return a * rsqrt(dot(a, a)); }
 
@@ -199,6 +205,40 @@ VKR_DEV float log2_poly(float x) {
 	r = fmaf(r, z, 6.66666687e-01f);
 	r = fmaf(r, z, 2.0f);
 	return fmaf(s * r, 1.44269502f, (float) e);
+#endif
+}
+
+// 2^t, pow(x, 1/3) for x >= 0 and the two-argument arctangent: the same operations as
+// vkr_exp2f / vkr_cbrt_positive / vkr_atan2f in oracle/oracle_math.h (exact mode)
+VKR_DEV float exp2_poly(float t) {
+	float n = rintf(t);
+	float r = (t - n) * 0.693147182f;
+	float p = 1.98412698e-04f;
+	p = fmaf(p, r, 1.38888892e-03f);
+	p = fmaf(p, r, 8.33333377e-03f);
+	p = fmaf(p, r, 4.16666679e-02f);
+	p = fmaf(p, r, 1.66666672e-01f);
+	p = fmaf(p, r, 0.5f);
+	p = fmaf(p, r, 1.0f);
+	p = fmaf(p, r, 1.0f);
+	return p * __uint_as_float((uint32_t) ((int) n + 127) << 23);
+}
+VKR_DEV float cube_root_positive(float x) {
+#if VKR_FAST_MATH
+	return __powf(x, 1.0f / 3.0f);
+#else
+	if (!(x > 0.0f)) return x;
+	return exp2_poly(log2_poly(x) * (1.0f / 3.0f));
+#endif
+}
+VKR_DEV float arctan(float t);
+VKR_DEV float arctan2(float y, float x) {
+#if VKR_FAST_MATH
+	return atan2f(y, x);
+#else
+	float a = arctan(divide(y, x));
+	if (x < 0.0f) a += (y >= 0.0f) ? kPi : -kPi;
+	return a;
 #endif
 }
 

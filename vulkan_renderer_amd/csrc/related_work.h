@@ -180,4 +180,113 @@ VKR_DEV f3 sample_hart_bilinear(float& out_density, const hart_bilinear<V>& h, f
 	return sample_sa<V>(h.polygon, u);
 }
 
+// ---- Hart et al. 2020: biquadratic warp (needs the roots of a cubic) -------------------------
+
+// solve_cubic, cubic_solver.glsl:29-76: c0 + c1 x + c2 x^2 + c3 x^3; true with three roots, false
+// with one root in r0
+VKR_DEV bool solve_cubic(float& r0, float& r1, float& r2, float k0, float k1, float k2, float k3) {
+	float c0 = divide(k0, k3), c1 = divide(k1, k3), c2 = divide(k2, k3);
+	c1 = divide(c1, 3.0f);
+	c2 = divide(c2, 3.0f);
+	float d0 = fmaf(-c2, c2, c1), d1 = fmaf(-c1, c2, c0), d2 = c2 * c0 - c1 * c1;
+	float discriminant = 4.0f * d0 * d2 - d1 * d1;
+	float sqrt_abs_discriminant = square_root(fabsf(discriminant));
+	float depressed_0 = fmaf(-2.0f * c2, d0, d1), depressed_1 = d0;
+	if (discriminant >= 0.0f) {
+		float theta = arctan2(sqrt_abs_discriminant, -depressed_0) * (1.0f / 3.0f);
+		float sn, cs;
+		sincos_poly(theta, sn, cs);
+		const float sqrt_three_quarters = 0.866025388f;
+		float q0 = cs, q1 = fmaf(-sqrt_three_quarters, sn, -0.5f * cs), q2 = fmaf(sqrt_three_quarters, sn, -0.5f * cs);
+		float scale = 2.0f * square_root(-depressed_1);
+		r0 = fmaf(scale, q0, -c2);
+		r1 = fmaf(scale, q1, -c2);
+		r2 = fmaf(scale, q2, -c2);
+		return true;
+	}
+	float signed_sqrt_discriminant = (depressed_0 < 0.0f) ? sqrt_abs_discriminant : -sqrt_abs_discriminant;
+	float quadratic_root = 0.5f * (signed_sqrt_discriminant - depressed_0);
+	float cube_root_0 = cube_root_positive(fabsf(quadratic_root));
+	cube_root_0 = (quadratic_root < 0.0f) ? -cube_root_0 : cube_root_0;
+	float cube_root_1 = divide(-depressed_1, cube_root_0);
+	r0 = (cube_root_0 + cube_root_1) - c2;
+	r1 = r2 = 0.0f;
+	return false;
+}
+
+template <int V>
+struct hart_biquadratic {
+	sa_polygon<V> polygon;
+	float density_0;
+	f3 density_1, density_2;
+};
+
+// prepare_biquadratic_cosine_warp_polygon_sampling_hart, :405-446
+template <int V>
+VKR_DEV void prepare_hart_biquadratic(hart_biquadratic<V>& h, uint32_t vertex_count, const f3 (&verts)[V]) {
+	prepare_sa<V>(h.polygon, vertex_count, verts, mk3(0.0f, 0.0f, 0.0f));
+	f3 last_vertex = h.polygon.dirs[2];
+#pragma unroll
+	for (int i = 3; i < V; ++i) last_vertex = ((uint32_t) i < vertex_count) ? h.polygon.dirs[i] : last_vertex;
+	f3 vertex_0 = h.polygon.dirs[0];
+	h.density_0 = gmax(0.0f, vertex_0.z);
+	f3 sample_2_1 = sample_sa<V>(h.polygon, mk2(0.5f, 1.0f));
+	h.density_2 = mk3(gmax(0.0f, h.polygon.dirs[1].z), gmax(0.0f, sample_2_1.z), gmax(0.0f, last_vertex.z));
+	f3 far_vertices[3] = {vertex_0, sample_2_1, last_vertex};
+	float density_1[3];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		float s2 = dot(vertex_0, far_vertices[i]);
+		float s = fmaf(0.5f, s2, 0.5f);
+		float t = square_root(gmax(0.0f, fmaf(-s, s, 1.0f)));
+		float t_axis_z = fmaf(-s2, vertex_0.z, far_vertices[i].z);
+		float normalization_t_axis = rsqrt(2.0f * fmaf(-s2, s2, 1.0f));
+		float sample_1_i_z = s * vertex_0.z + (t * normalization_t_axis) * t_axis_z;
+		density_1[i] = gmax(0.0f, sample_1_i_z);
+	}
+	h.density_1 = mk3(density_1[0], density_1[1], density_1[2]);
+	float density_sum = (3.0f * h.density_0 + ((h.density_1.x + h.density_1.y) + h.density_1.z)) + ((h.density_2.x + h.density_2.y) + h.density_2.z);
+	float normalization = divide(9.0f, h.polygon.solid_angle * density_sum);
+	h.density_0 *= normalization;
+	h.density_1 = h.density_1 * normalization;
+	h.density_2 = h.density_2 * normalization;
+	float inv_solid_angle = rcp(h.polygon.solid_angle);
+	if (density_sum <= 0.0f) {
+		h.density_0 = inv_solid_angle;
+		h.density_1 = h.density_2 = mk3(inv_solid_angle, inv_solid_angle, inv_solid_angle);
+	}
+}
+
+// quadratic_warp, :457-474
+VKR_DEV float quadratic_warp(float random_number, float density_0, float density_1, float density_2) {
+	float q0 = density_0, q1 = 2.0f * (density_1 - density_0), q2 = density_0 - 2.0f * density_1 + density_2;
+	float k1 = q0, k2 = 0.5f * q1, k3 = (1.0f / 3.0f) * q2;
+	random_number *= (k1 + k2) + k3;
+	float r0, r1, r2;
+	if (solve_cubic(r0, r1, r2, -random_number, k1, k2, k3)) {
+		float result = r0;
+		result = (r1 >= 0.0f && r1 <= 1.0f) ? r1 : result;
+		result = (r2 >= 0.0f && r2 <= 1.0f) ? r2 : result;
+		return result;
+	}
+	return r0;
+}
+
+// quadratic_bezier, :484-488
+VKR_DEV float quadratic_bezier(float b00, float b01, float b02, float location) {
+	return mix_fma(mix_fma(b00, b01, location), mix_fma(b01, b02, location), location);
+}
+
+// sample_biquadratic_cosine_warp_polygon_hart, :493-503
+template <int V>
+VKR_DEV f3 sample_hart_biquadratic(float& out_density, const hart_biquadratic<V>& h, f2 u) {
+	u.y = quadratic_warp(u.y, 3.0f * h.density_0, (h.density_1.x + h.density_1.y) + h.density_1.z, (h.density_2.x + h.density_2.y) + h.density_2.z);
+	float density_0 = quadratic_bezier(h.density_0, h.density_1.x, h.density_2.x, u.y);
+	float density_1 = quadratic_bezier(h.density_0, h.density_1.y, h.density_2.y, u.y);
+	float density_2 = quadratic_bezier(h.density_0, h.density_1.z, h.density_2.z, u.y);
+	u.x = quadratic_warp(u.x, density_0, density_1, density_2);
+	out_density = quadratic_bezier(density_0, density_1, density_2, u.x);
+	return sample_sa<V>(h.polygon, u);
+}
+
 }  // namespace vkr

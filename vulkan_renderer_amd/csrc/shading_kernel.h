@@ -24,7 +24,8 @@ namespace vkr {
 
 enum { kStrategyDiffuseOnly = 0, kStrategyDiffuseGgxMis = 1, kStrategySeparately = 2, kStrategyMis = 3, kStrategyRandom = 4 };
 enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3, kTechniqueBaseline = 4, kTechniqueAreaTurk = 5,
-	kTechniqueUrena = 6, kTechniqueArvoSolidAngle = 7, kTechniqueHartBilinear = 8, kTechniqueHartBilinearClipping = 9, kTechniqueCount = 10 };
+	kTechniqueUrena = 6, kTechniqueArvoSolidAngle = 7, kTechniqueHartBilinear = 8, kTechniqueHartBilinearClipping = 9,
+	kTechniqueHartBiquadratic = 10, kTechniqueHartBiquadraticClipping = 11, kTechniqueCount = 12 };
 enum { kMisBalance = 0, kMisPower = 1, kMisWeighted = 2, kMisOptimalClamped = 3, kMisOptimal = 4 };
 
 struct shade_params {
@@ -680,9 +681,12 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
-	else if constexpr (TECHNIQUE == kTechniqueHartBilinear || TECHNIQUE == kTechniqueHartBilinearClipping) {
-		// :386-427; without clipping the polygon keeps MAX_POLYGONAL_LIGHT_VERTEX_COUNT slots
-		constexpr bool kClipping = TECHNIQUE == kTechniqueHartBilinearClipping;
+	else if constexpr (TECHNIQUE == kTechniqueHartBilinear || TECHNIQUE == kTechniqueHartBilinearClipping
+		|| TECHNIQUE == kTechniqueHartBiquadratic || TECHNIQUE == kTechniqueHartBiquadraticClipping)
+	{
+		// :386-438; without clipping the polygon keeps MAX_POLYGONAL_LIGHT_VERTEX_COUNT slots
+		constexpr bool kClipping = TECHNIQUE == kTechniqueHartBilinearClipping || TECHNIQUE == kTechniqueHartBiquadraticClipping;
+		constexpr bool kBiquadratic = TECHNIQUE == kTechniqueHartBiquadratic || TECHNIQUE == kTechniqueHartBiquadraticClipping;
 		constexpr int kLightSlots = kClipping ? V - 1 : V;
 		f3 vs[V];
 #pragma unroll
@@ -693,13 +697,25 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			clipped = clip_polygon<V>(count, vs);
 			if (clipped == 0) return zero;
 		}
-		hart_bilinear<V> pd;
-		prepare_hart_bilinear<V>(pd, clipped, vs);
-		for (uint32_t s = 0; s != S; ++s) {
-			float density;
-			f3 dir = sample_hart_bilinear<V>(density, pd, next_noise_2(p, noise));
-			dir = mul_transposed(world_to_shading, dir);
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+		if constexpr (kBiquadratic) {
+			hart_biquadratic<V> pd;
+			prepare_hart_biquadratic<V>(pd, clipped, vs);
+			for (uint32_t s = 0; s != S; ++s) {
+				float density;
+				f3 dir = sample_hart_biquadratic<V>(density, pd, next_noise_2(p, noise));
+				dir = mul_transposed(world_to_shading, dir);
+				add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+			}
+		}
+		else {
+			hart_bilinear<V> pd;
+			prepare_hart_bilinear<V>(pd, clipped, vs);
+			for (uint32_t s = 0; s != S; ++s) {
+				float density;
+				f3 dir = sample_hart_bilinear<V>(density, pd, next_noise_2(p, noise));
+				dir = mul_transposed(world_to_shading, dir);
+				add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+			}
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueSolidAngle) {

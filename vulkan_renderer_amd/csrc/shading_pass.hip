@@ -49,6 +49,8 @@ static int technique_index(sample_polygon_technique_t technique) {
 	case sample_polygon_solid_angle_arvo: return kTechniqueArvoSolidAngle;
 	case sample_polygon_bilinear_cosine_warp_hart: return kTechniqueHartBilinear;
 	case sample_polygon_bilinear_cosine_warp_clipping_hart: return kTechniqueHartBilinearClipping;
+	case sample_polygon_biquadratic_cosine_warp_hart: return kTechniqueHartBiquadratic;
+	case sample_polygon_biquadratic_cosine_warp_clipping_hart: return kTechniqueHartBiquadraticClipping;
 	default: return -1;
 	}
 }
@@ -319,7 +321,7 @@ static int validate_settings(const application_t* app) {
 	const scene_specification_t* spec = &app->scene_specification;
 	int technique = technique_index(s->polygon_sampling_technique);
 	if (technique < 0) {
-		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Built: baseline, area (Turk), rectangle solid angle (Urena), solid angle (Arvo and ours), clipped solid angle, bilinear cosine warp (Hart, with and without clipping), (biased) projected solid angle.\n", (int) s->polygon_sampling_technique);
+		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Built: baseline, area (Turk), rectangle solid angle (Urena), solid angle (Arvo and ours), clipped solid angle, bilinear and biquadratic cosine warp (Hart, with and without clipping), (biased) projected solid angle.\n", (int) s->polygon_sampling_technique);
 		return 1;
 	}
 	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased;
@@ -335,7 +337,8 @@ static int validate_settings(const application_t* app) {
 	bool needs_specular = s->sampling_strategies == sampling_strategies_diffuse_specular_separately
 		|| s->sampling_strategies == sampling_strategies_diffuse_specular_mis
 		|| s->sampling_strategies == sampling_strategies_diffuse_specular_random;
-	if ((technique == kTechniqueBaseline || technique == kTechniqueAreaTurk || technique == kTechniqueHartBilinear || technique == kTechniqueHartBilinearClipping)
+	if ((technique == kTechniqueBaseline || technique == kTechniqueAreaTurk || technique == kTechniqueHartBilinear || technique == kTechniqueHartBilinearClipping
+			|| technique == kTechniqueHartBiquadratic || technique == kTechniqueHartBiquadraticClipping)
 		&& s->sampling_strategies != sampling_strategies_diffuse_only)
 	{
 		printf("The baseline, area sampling and cosine warp techniques only exist for the diffuse-only sampling strategy (as in the reference shader).\n");
@@ -559,7 +562,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	p.constants = (const uint8_t*) pass->constants_device;
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(app->render_settings.polygon_sampling_technique);
-	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping;
+	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
 	// every timing_stride-th frame is bracketed by a pair of events (an event record costs
 	// about 5 us of idle time on the stream, a tenth of a config-2 frame for the pair)

@@ -29,7 +29,8 @@ static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t s
 template <int TECHNIQUE>
 static int launch_capacity(int capacity, int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
 	// techniques that clip the polygon at the horizon need one more vertex slot (reference main.c:194-216)
-	constexpr bool kClips = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased || TECHNIQUE == kTechniqueClippedSolidAngle || TECHNIQUE == kTechniqueHartBilinearClipping;
+	constexpr bool kClips = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased || TECHNIQUE == kTechniqueClippedSolidAngle || TECHNIQUE == kTechniqueHartBilinearClipping
+		|| TECHNIQUE == kTechniqueHartBiquadraticClipping;
 	switch (capacity) {
 	case 3: if constexpr (!kClips) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
 	case 4: return launch_rays<TECHNIQUE, 4>(rays, p, grid, stream);
@@ -64,6 +65,8 @@ extern "C" int VKR_LAUNCH_NAME(int technique, int capacity, int rays, const shad
 	case kTechniqueAreaTurk: return launch_capacity<kTechniqueAreaTurk>(capacity, rays, *p, grid, s);
 	case kTechniqueHartBilinear: return launch_capacity<kTechniqueHartBilinear>(capacity, rays, *p, grid, s);
 	case kTechniqueHartBilinearClipping: return launch_capacity<kTechniqueHartBilinearClipping>(capacity, rays, *p, grid, s);
+	case kTechniqueHartBiquadratic: return launch_capacity<kTechniqueHartBiquadratic>(capacity, rays, *p, grid, s);
+	case kTechniqueHartBiquadraticClipping: return launch_capacity<kTechniqueHartBiquadraticClipping>(capacity, rays, *p, grid, s);
 #endif
 	default: return -1;
 	}
