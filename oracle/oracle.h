@@ -26,7 +26,8 @@ enum { O_STRATEGY_DIFFUSE_ONLY = 0, O_STRATEGY_DIFFUSE_GGX_MIS = 1, O_STRATEGY_D
 enum { O_MIS_BALANCE = 0, O_MIS_POWER = 1, O_MIS_WEIGHTED = 2, O_MIS_OPTIMAL_CLAMPED = 3, O_MIS_OPTIMAL = 4 };
 enum { O_TECHNIQUE_BASELINE = 0, O_TECHNIQUE_AREA_TURK = 1, O_TECHNIQUE_RECTANGLE_SOLID_ANGLE_URENA = 2, O_TECHNIQUE_SOLID_ANGLE_ARVO = 3,
 	O_TECHNIQUE_BILINEAR_COSINE_WARP_HART = 6, O_TECHNIQUE_BILINEAR_COSINE_WARP_CLIPPING_HART = 7,
-	O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_HART = 8, O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_CLIPPING_HART = 9, O_TECHNIQUE_SOLID_ANGLE = 4, O_TECHNIQUE_CLIPPED_SOLID_ANGLE = 5,
+	O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_HART = 8, O_TECHNIQUE_BIQUADRATIC_COSINE_WARP_CLIPPING_HART = 9,
+	O_TECHNIQUE_PROJECTED_SOLID_ANGLE_ARVO = 10, O_TECHNIQUE_SOLID_ANGLE = 4, O_TECHNIQUE_CLIPPED_SOLID_ANGLE = 5,
 	O_TECHNIQUE_PROJECTED_SOLID_ANGLE = 11, O_TECHNIQUE_PROJECTED_SOLID_ANGLE_BIASED = 12 };
 
 /* Everything the per-pixel program reads.  Buffers are byte-identical to what

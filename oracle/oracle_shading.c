@@ -1028,6 +1028,296 @@ static v3 display_sampling_error(pixel_ctx_t* ctx, const psa_polygon_t* polygon,
 	return mk3(color.x / ctx->k->exposure_factor, color.y / ctx->k->exposure_factor, color.z / ctx->k->exposure_factor);
 }
 
+/* ---- related work: Arvo's projected solid angle sampling
+ * (polygon_sampling_related_work.glsl:509-1048) ---------------------------------------------- */
+
+typedef struct {
+	float cdf_factor;
+	v2 length_coeffs, elevations;
+} edge_arvo_t;
+
+typedef struct {
+	uint32_t vertex_count;
+	float azimuths[O_CAP];
+	edge_arvo_t edges[O_CAP];
+	edge_arvo_t inner_edge_0;
+	float sector_psa[O_CAP];
+	float psa;
+} psa_arvo_t;
+
+/* prepare_edge_arvo, :559-578 */
+static edge_arvo_t prepare_edge_arvo(v3 vertex_0, v3 vertex_1) {
+	edge_arvo_t edge;
+	v3 normal_a = normalize3(cross3(vertex_0, vertex_1));
+	edge.cdf_factor = 0.5f * normal_a.z;
+	v3 ccw_vertex = (edge.cdf_factor > 0.0f) ? vertex_0 : vertex_1;
+	v2 normal_c = rot90(normalize2(mk2(ccw_vertex.x, ccw_vertex.y)));
+	float cos_beta = -dot2(mk2(normal_a.x, normal_a.y), normal_c);
+	float sin_beta_sq = fmaf(-cos_beta, cos_beta, 1.0f);
+	float csc_beta = rsqrt_f(g_max(0.0f, sin_beta_sq));
+	float csc_c = rsqrt_f(g_max(0.0f, fmaf(-ccw_vertex.z, ccw_vertex.z, 1.0f)));
+	edge.length_coeffs.x = sin_beta_sq;
+	edge.length_coeffs.y = dot2(mk2(normal_a.x, normal_a.y), rot90(normal_c)) * cos_beta;
+	edge.length_coeffs = scale2(edge.length_coeffs, csc_beta * csc_c);
+	edge.elevations.x = ccw_vertex.z;
+	edge.elevations.y = cross3(ccw_vertex, normal_a).z;
+	edge.elevations.y = (edge.cdf_factor > 0.0f) ? -edge.elevations.y : edge.elevations.y;
+	return edge;
+}
+
+/* get_edge_projected_solid_angle_in_sector_arvo, :599-609 */
+static float edge_psa_in_sector_arvo(const edge_arvo_t* edge, float relative_azimuth_0, float relative_azimuth_1) {
+	float s0, c0, s1, c1;
+	o_sincos(relative_azimuth_0, &s0, &c0);
+	o_sincos(relative_azimuth_1, &s1, &c1);
+	v2 point_0 = mk2(dot2(edge->length_coeffs, mk2(c0, s0)), s0);
+	v2 point_1 = mk2(dot2(edge->length_coeffs, mk2(c1, s1)), s1);
+	v2 rotated = mk2(point_0.x * point_1.x + point_0.y * point_1.y, point_0.x * point_1.y - point_0.y * point_1.x);
+	float length = positive_atan(fabsf(rotated.y) / rotated.x, 0);
+	return edge->cdf_factor * length;
+}
+
+/* get_edge_projected_solid_angle_in_sector_derivative_arvo, :618-640 */
+static v2 edge_psa_in_sector_derivative_arvo(const edge_arvo_t* edge, float relative_azimuth_0, float relative_azimuth_1) {
+	float s0, c0, s1, c1;
+	o_sincos(relative_azimuth_0, &s0, &c0);
+	o_sincos(relative_azimuth_1, &s1, &c1);
+	v2 point_0 = mk2(dot2(edge->length_coeffs, mk2(c0, s0)), s0);
+	v2 dir_1 = mk2(c1, s1);
+	v2 point_1 = mk2(dot2(edge->length_coeffs, dir_1), dir_1.y);
+	v2 rotated = mk2(point_0.x * point_1.x + point_0.y * point_1.y, point_0.x * point_1.y - point_0.y * point_1.x);
+	float quotient = fabsf(rotated.y) / rotated.x;
+	float length = positive_atan(quotient, 0);
+	v2 dir_1_deriv = rot90(dir_1);
+	v2 point_1_deriv = mk2(dot2(edge->length_coeffs, dir_1_deriv), dir_1_deriv.y);
+	v2 rotated_deriv = mk2(point_0.x * point_1_deriv.x + point_0.y * point_1_deriv.y, point_0.x * point_1_deriv.y - point_0.y * point_1_deriv.x);
+	float quotient_derivative = (rotated_deriv.y * rotated.x - rotated.y * rotated_deriv.x) / (rotated.x * rotated.x);
+	quotient_derivative = (rotated.y < 0.0f) ? (-quotient_derivative) : quotient_derivative;
+	float length_deriv = quotient_derivative / fmaf(quotient, quotient, 1.0f);
+	return mk2(edge->cdf_factor * length, edge->cdf_factor * length_deriv);
+}
+
+/* get_edge_elevation_arvo, :648-653 */
+static float edge_elevation_arvo(const edge_arvo_t* edge, float relative_azimuth) {
+	float sn, cs;
+	o_sincos(relative_azimuth, &sn, &cs);
+	v2 point = normalize2(mk2(dot2(edge->length_coeffs, mk2(cs, sn)), sn));
+	return dot2(point, edge->elevations);
+}
+
+/* compare_and_swap_arvo, :661-669 */
+static void compare_and_swap_arvo(psa_arvo_t* p, uint32_t lhs, uint32_t rhs) {
+	float lhs_azimuth = p->azimuths[lhs];
+	float flip = p->azimuths[lhs] - p->azimuths[rhs];
+	p->azimuths[lhs] = (flip > 0.0f) ? p->azimuths[rhs] : lhs_azimuth;
+	p->azimuths[rhs] = (flip > 0.0f) ? lhs_azimuth : p->azimuths[rhs];
+	edge_arvo_t lhs_edge = p->edges[lhs];
+	p->edges[lhs] = (flip > 0.0f) ? p->edges[rhs] : lhs_edge;
+	p->edges[rhs] = (flip > 0.0f) ? lhs_edge : p->edges[rhs];
+}
+
+/* sort_convex_polygon_vertices_arvo, :674-739: the same networks as sort_convex_polygon_vertices */
+static void sort_vertices_arvo(psa_arvo_t* p, uint32_t cap) {
+	static const uint8_t networks[9][9][2] = {
+		{{0}}, {{0}}, {{0}},
+		/* 3 */ {{1, 2}},
+		/* 4 */ {{1, 3}},
+		/* 5 */ {{2, 4}, {1, 3}, {1, 2}, {0, 3}, {3, 4}},
+		/* 6 */ {{3, 5}, {2, 4}, {1, 5}, {0, 4}, {4, 5}, {1, 3}},
+		/* 7 */ {{2, 5}, {1, 6}, {5, 6}, {3, 4}, {0, 4}, {4, 6}, {1, 3}, {3, 5}, {4, 5}},
+		/* 8 */ {{2, 6}, {3, 7}, {1, 5}, {0, 4}, {4, 6}, {5, 7}, {6, 7}, {4, 5}, {1, 3}}};
+	static const uint8_t lengths[9] = {0, 0, 0, 1, 1, 5, 6, 9, 9};
+	uint32_t n = p->vertex_count;
+	if (n >= 3 && n <= 8 && n <= cap)
+		for (uint32_t i = 0; i != lengths[n]; ++i) compare_and_swap_arvo(p, networks[n][i][0], networks[n][i][1]);
+	compare_and_swap_arvo(p, 0, 2);
+	if (cap >= 4 && n >= 4) compare_and_swap_arvo(p, 2, 3);
+	compare_and_swap_arvo(p, 0, 1);
+}
+
+/* prepare_projected_solid_angle_polygon_sampling_arvo, :744-812 */
+static psa_arvo_t prepare_psa_arvo(uint32_t vertex_count, uint32_t cap, const v3* in_vertices) {
+	psa_arvo_t p;
+	memset(&p, 0, sizeof(p));
+	v3 vertices[O_CAP];
+	for (uint32_t i = 0; i != cap; ++i) vertices[i] = normalize3(in_vertices[i]);
+	p.vertex_count = vertex_count;
+	p.inner_edge_0.cdf_factor = 1.0f;
+	p.inner_edge_0.length_coeffs = p.inner_edge_0.elevations = mk2(0.0f, 0.0f);
+	p.azimuths[0] = o_atan2(vertices[0].y, vertices[0].x);
+	p.edges[0] = prepare_edge_arvo(vertices[0], vertices[1]);
+	edge_arvo_t previous_edge = p.edges[0];
+	for (uint32_t i = 1; i != cap; ++i) {
+		p.azimuths[i] = o_atan2(vertices[i].y, vertices[i].x);
+		p.azimuths[i] -= (p.azimuths[i] > p.azimuths[0] + O_PI) ? (2.0f * O_PI) : 0.0f;
+		p.azimuths[i] += (p.azimuths[i] < p.azimuths[0] - O_PI) ? (2.0f * O_PI) : 0.0f;
+		if (i > 2 && i == p.vertex_count) break;
+		edge_arvo_t edge = prepare_edge_arvo(vertices[i], vertices[(i + 1) % cap]);
+		p.edges[i] = (edge.cdf_factor >= 0.0f) ? edge : previous_edge;
+		p.inner_edge_0 = (previous_edge.cdf_factor < 0.0f && edge.cdf_factor >= 0.0f) ? previous_edge : p.inner_edge_0;
+		previous_edge = edge;
+	}
+	edge_arvo_t edge = p.edges[0];
+	p.edges[0] = (edge.cdf_factor >= 0.0f) ? edge : previous_edge;
+	p.inner_edge_0 = (previous_edge.cdf_factor < 0.0f && edge.cdf_factor >= 0.0f) ? previous_edge : p.inner_edge_0;
+	p.psa = 0.0f;
+	if (p.inner_edge_0.cdf_factor > 0.0f) {
+		for (uint32_t i = 0; i != cap; ++i) {
+			if (i > 2 && i == p.vertex_count) break;
+			p.sector_psa[i] = edge_psa_in_sector_arvo(&p.edges[i], 0.0f, p.azimuths[(i + 1) % cap] - p.azimuths[i]);
+			p.psa += p.sector_psa[i];
+		}
+	}
+	else {
+		sort_vertices_arvo(&p, cap);
+		edge_arvo_t inner_edge = p.inner_edge_0;
+		float inner_azimuth = p.azimuths[0];
+		edge_arvo_t outer_edge;
+		memset(&outer_edge, 0, sizeof(outer_edge));
+		float outer_azimuth = p.azimuths[0];
+		for (uint32_t i = 0; i + 1 != cap; ++i) {
+			if (i > 1 && i + 1 == p.vertex_count) break;
+			edge_arvo_t vertex_edge = p.edges[i];
+			float vertex_azimuth = p.azimuths[i];
+			if (i == 0) outer_edge = vertex_edge;
+			else {
+				int outer = vertex_edge.cdf_factor >= 0.0f;
+				inner_edge = outer ? inner_edge : vertex_edge;
+				inner_azimuth = outer ? inner_azimuth : vertex_azimuth;
+				outer_edge = outer ? vertex_edge : outer_edge;
+				outer_azimuth = outer ? vertex_azimuth : outer_azimuth;
+			}
+			p.sector_psa[i] = edge_psa_in_sector_arvo(&outer_edge, p.azimuths[i] - outer_azimuth, p.azimuths[i + 1] - outer_azimuth);
+			p.sector_psa[i] += edge_psa_in_sector_arvo(&inner_edge, p.azimuths[i] - inner_azimuth, p.azimuths[i + 1] - inner_azimuth);
+			p.psa += p.sector_psa[i];
+		}
+	}
+	return p;
+}
+
+/* evaluate_cubic_interpolation_polynomial, :822-830 */
+static float cubic_interpolation(float sample_x, const float x[4], const float y[4]) {
+	float y01 = (y[0] - y[1]) / (x[0] - x[1]);
+	float y12 = (y[1] - y[2]) / (x[1] - x[2]);
+	float y23 = (y[2] - y[3]) / (x[2] - x[3]);
+	float y012 = (y01 - y12) / (x[0] - x[2]);
+	float y123 = (y12 - y23) / (x[1] - x[3]);
+	float y0123 = (y012 - y123) / (x[0] - x[3]);
+	return fmaf(sample_x - x[0], fmaf(sample_x - x[1], fmaf(sample_x - x[2], y0123, y012), y01), y[0]);
+}
+
+/* sample_sector_within_edge (inner_edge == NULL), :838-866, and sample_sector_between_edges, :890-925 */
+static v3 sample_sector_arvo(v2 random_numbers, float target, const edge_arvo_t* inner_edge, float inner_azimuth, const edge_arvo_t* outer_edge, float outer_azimuth, float azimuth_0, float azimuth_1, uint32_t iteration_count) {
+	float azimuths[4] = {azimuth_0, mix_fma(azimuth_0, azimuth_1, 1.0f / 3.0f), mix_fma(azimuth_0, azimuth_1, 2.0f / 3.0f), azimuth_1};
+	float psas[4];
+	for (int i = 0; i != 4; ++i) {
+		psas[i] = edge_psa_in_sector_arvo(outer_edge, azimuth_0 - outer_azimuth, azimuths[i] - outer_azimuth);
+		if (inner_edge) psas[i] += edge_psa_in_sector_arvo(inner_edge, azimuth_0 - inner_azimuth, azimuths[i] - inner_azimuth);
+	}
+	float sampled_azimuth = cubic_interpolation(target, psas, azimuths);
+	for (uint32_t i = 0; i != iteration_count; ++i) {
+		v2 outer_psa = edge_psa_in_sector_derivative_arvo(outer_edge, azimuth_0 - outer_azimuth, sampled_azimuth - outer_azimuth);
+		float error, derivative;
+		if (inner_edge) {
+			v2 inner_psa = edge_psa_in_sector_derivative_arvo(inner_edge, azimuth_0 - inner_azimuth, sampled_azimuth - inner_azimuth);
+			error = inner_psa.x + outer_psa.x - target;
+			derivative = inner_psa.y + outer_psa.y;
+		}
+		else {
+			error = outer_psa.x - target;
+			derivative = outer_psa.y;
+		}
+		sampled_azimuth -= error / derivative;
+		sampled_azimuth = g_clamp(sampled_azimuth, azimuth_0, azimuth_1);
+	}
+	v3 dir;
+	float sn, cs;
+	o_sincos(sampled_azimuth, &sn, &cs);
+	dir.x = cs;
+	dir.y = sn;
+	float outer_z = edge_elevation_arvo(outer_edge, sampled_azimuth - outer_azimuth);
+	if (inner_edge) {
+		float inner_z = edge_elevation_arvo(inner_edge, sampled_azimuth - inner_azimuth);
+		dir.z = sqrtf(mix_fma(inner_z * inner_z, outer_z * outer_z, random_numbers.y));
+	}
+	else
+		dir.z = sqrtf(mix_fma(1.0f, outer_z * outer_z, random_numbers.y));
+	float scale = sqrtf(fmaf(-dir.z, dir.z, 1.0f));
+	dir.x *= scale;
+	dir.y *= scale;
+	return dir;
+}
+
+/* the sector search shared by sampling and error computation in the decentral case, :965-988, :1015-1035 */
+static void find_sector_arvo(const psa_arvo_t* p, uint32_t cap, float* target, float* sector_psa, edge_arvo_t* inner_edge, float* inner_azimuth, edge_arvo_t* outer_edge, float* outer_azimuth, float* azimuth_0, float* azimuth_1) {
+	*inner_edge = p->inner_edge_0;
+	*inner_azimuth = p->azimuths[0];
+	for (uint32_t i = 0; i + 1 != cap; ++i) {
+		if ((i > 1 && i + 1 == p->vertex_count) || (i > 0 && *target < 0.0f)) break;
+		*sector_psa = p->sector_psa[i];
+		*target -= *sector_psa;
+		edge_arvo_t vertex_edge = p->edges[i];
+		float vertex_azimuth = p->azimuths[i];
+		if (i == 0) {
+			*outer_edge = vertex_edge;
+			*outer_azimuth = vertex_azimuth;
+		}
+		else {
+			int outer = vertex_edge.cdf_factor >= 0.0f;
+			*inner_edge = outer ? *inner_edge : vertex_edge;
+			*inner_azimuth = outer ? *inner_azimuth : vertex_azimuth;
+			*outer_edge = outer ? vertex_edge : *outer_edge;
+			*outer_azimuth = outer ? vertex_azimuth : *outer_azimuth;
+		}
+		*azimuth_0 = p->azimuths[i];
+		*azimuth_1 = p->azimuths[i + 1];
+	}
+	*target += *sector_psa;
+}
+
+/* sample_projected_solid_angle_polygon_arvo, :934-991 */
+static v3 sample_psa_arvo(const psa_arvo_t* p, uint32_t cap, v2 random_numbers, uint32_t iteration_count) {
+	float target = random_numbers.x * p->psa;
+	float sector_psa = 0.0f;
+	edge_arvo_t outer_edge;
+	memset(&outer_edge, 0, sizeof(outer_edge));
+	float outer_azimuth = 0.0f, azimuth_1 = 0.0f;
+	if (p->inner_edge_0.cdf_factor > 0.0f) {
+		for (uint32_t i = 0; i != cap; ++i) {
+			if ((i > 2 && i == p->vertex_count) || (i > 0 && target < 0.0f)) break;
+			sector_psa = p->sector_psa[i];
+			target -= sector_psa;
+			outer_edge = p->edges[i];
+			outer_azimuth = p->azimuths[i];
+			azimuth_1 = p->azimuths[(i + 1) % cap];
+		}
+		azimuth_1 = (azimuth_1 < outer_azimuth) ? (azimuth_1 + 2.0f * O_PI) : azimuth_1;
+		target += sector_psa;
+		random_numbers.x = g_clamp(target / sector_psa, 0.0f, 1.0f);
+		return sample_sector_arvo(random_numbers, target, NULL, 0.0f, &outer_edge, outer_azimuth, outer_azimuth, azimuth_1, iteration_count);
+	}
+	edge_arvo_t inner_edge;
+	float inner_azimuth, azimuth_0 = 0.0f;
+	find_sector_arvo(p, cap, &target, &sector_psa, &inner_edge, &inner_azimuth, &outer_edge, &outer_azimuth, &azimuth_0, &azimuth_1);
+	random_numbers.x = g_clamp(target / sector_psa, 0.0f, 1.0f);
+	return sample_sector_arvo(random_numbers, target, &inner_edge, inner_azimuth, &outer_edge, outer_azimuth, azimuth_0, azimuth_1, iteration_count);
+}
+
+/* compute_projected_solid_angle_polygon_sampling_error_arvo, :998-1047: (backward, backward scaled) */
+static v2 psa_sampling_error_arvo(const psa_arvo_t* p, uint32_t cap, v2 random_numbers, v3 sampled_dir) {
+	float target = random_numbers.x * p->psa;
+	if (p->inner_edge_0.cdf_factor > 0.0f) return mk2(0.0f, 0.0f);
+	edge_arvo_t inner_edge, outer_edge;
+	memset(&outer_edge, 0, sizeof(outer_edge));
+	float inner_azimuth, outer_azimuth = 0.0f, sector_psa = 0.0f, azimuth_0 = 0.0f, azimuth_1 = 0.0f;
+	find_sector_arvo(p, cap, &target, &sector_psa, &inner_edge, &inner_azimuth, &outer_edge, &outer_azimuth, &azimuth_0, &azimuth_1);
+	float sampled_azimuth = o_atan2(sampled_dir.y, sampled_dir.x);
+	float outer_psa = edge_psa_in_sector_derivative_arvo(&outer_edge, azimuth_0 - outer_azimuth, sampled_azimuth - outer_azimuth).x;
+	float inner_psa = edge_psa_in_sector_derivative_arvo(&inner_edge, azimuth_0 - inner_azimuth, sampled_azimuth - inner_azimuth).x;
+	float sampled_psa = outer_psa + inner_psa;
+	return mk2((target - sampled_psa) / p->psa, target - sampled_psa);
+}
+
 /* ---- related work: Urena's rectangle sampling, Arvo's spherical triangles, Hart's warps ----
  * (polygon_sampling_related_work.glsl:97-386) */
 
@@ -1440,8 +1730,12 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 		}
 		density_factor = 1.0f / pd.solid_angle;
 	}
-	else if (is_psa) {
+	else if (is_psa || technique == O_TECHNIQUE_PROJECTED_SOLID_ANGLE_ARVO) {
 		uint32_t cap = vmax + 1;
+		/* Arvo's sampler only exists in the diffuse-only / GGX-MIS branch (:462-481); the combined
+		 * branch uses the paper's own sampler whatever the technique says (:506-547) */
+		int is_arvo = technique == O_TECHNIQUE_PROJECTED_SOLID_ANGLE_ARVO
+			&& (strategy == O_STRATEGY_DIFFUSE_ONLY || strategy == O_STRATEGY_DIFFUSE_GGX_MIS);
 		/* :444-449 flip the frame when the shading point is behind the light */
 		float side = dot4_point(sd->position, light->plane);
 		if (side < 0.0f)
@@ -1456,6 +1750,25 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 			for (uint32_t i = 0; i != vmax; ++i) vs[i] = m43_mul(&ltc.world_to_shading, light->vertices_world[i], 1.0f);
 			uint32_t clipped = clip_polygon(light->vertex_count, 3, cap, vs);
 			if (clipped == 0) return zero;
+			if (is_arvo) {
+				psa_arvo_t pa = prepare_psa_arvo(clipped, cap, vs);
+				if (pa.psa <= 0.0f) return zero;
+				if (f->error_display == 1) {
+					v2 u = next_noise_2(f, k, noise);
+					v3 dir = sample_psa_arvo(&pa, cap, u, 3);
+					v2 e = psa_sampling_error_arvo(&pa, cap, u, dir);
+					v3 color = error_to_color(k, (f->error_index == 0) ? e.x : e.y);
+					return mk3(color.x / k->exposure_factor, color.y / k->exposure_factor, color.z / k->exposure_factor);
+				}
+				for (uint32_t s = 0; s != S; ++s) {
+					v3 dir = sample_psa_arvo(&pa, cap, next_noise_2(f, k, noise), 3);
+					float density = dir.z / pa.psa;
+					dir = m43_mul_transposed(&ltc.world_to_shading, dir);
+					result = add3(result, light_mis_estimate(ctx, dir, density, sd, light));
+				}
+				density_factor = 1.0f / pa.psa;
+				goto ggx_tail;
+			}
 			psa_polygon_t pd = prepare_psa(clipped, cap, vs, biased);
 			if (pd.psa <= 0.0f) return zero;
 			if (f->error_display == 1) return display_sampling_error(ctx, &pd, cap, noise, biased);
@@ -1574,6 +1887,7 @@ static v3 evaluate_light(pixel_ctx_t* ctx, const shading_data_t* sd, const ltc_t
 		}
 	}
 
+ggx_tail:
 	if (strategy == O_STRATEGY_DIFFUSE_GGX_MIS) {
 		/* :676-709 */
 		v3 out_shading = m43_mul(&ltc.world_to_shading, sd->outgoing, 0.0f);

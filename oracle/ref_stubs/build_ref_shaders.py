@@ -30,10 +30,7 @@ def translate(name, text):
     out = []
     in_uniform_block = False
     if name == "polygon_sampling_related_work.glsl":
-        # The first part of the related-work file is in scope: uniform area sampling (Turk),
-        # Urena's rectangle sampling, Arvo's spherical triangles and Hart's cosine warps.
-        # Arvo's projected solid angle sampling, which follows, is cut off.
-        text = text[:text.index("//! Holds information that Arvo's projected solid angle sampling technique")]
+        pass  # the whole related-work file is in scope
     for line in text.split("\n"):
         s = line.strip()
         # directives that mean nothing to a C++ compiler
@@ -154,6 +151,10 @@ VARIANTS = [
     dict(strategy=1, heuristic=1, technique="solid_angle_arvo", lights=1, max_light_vertices=5, samples=2),
     dict(strategy=0, technique="bilinear_cosine_warp_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
     dict(strategy=0, technique="bilinear_cosine_warp_clipping_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
+    # Arvo's projected solid angle sampling: diffuse only, GGX MIS (the tail uses the density without the cosine), error display
+    dict(strategy=0, technique="projected_solid_angle_arvo", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
+    dict(strategy=1, heuristic=0, technique="projected_solid_angle_arvo", lights=1, max_light_vertices=5, samples=1, rays=True),
+    dict(strategy=0, technique="projected_solid_angle_arvo", lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, error_display=1),
     dict(strategy=0, technique="biquadratic_cosine_warp_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
     dict(strategy=0, technique="biquadratic_cosine_warp_clipping_hart", lights=3, min_light_vertices=3, max_light_vertices=6, samples=2, rays=True),
     # error display: backward (diffuse-only path), backward times PSA and forward (combined path)

@@ -50,6 +50,9 @@ FRAME_CASES = [
     dict(key="hart_bilinear_clipping_rays", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="bilinear_cosine_warp_clipping_hart", rays=True),
     dict(key="hart_biquadratic", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="biquadratic_cosine_warp_hart"),
     dict(key="hart_biquadratic_clipping_rays", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="biquadratic_cosine_warp_clipping_hart", rays=True),
+    dict(key="arvo_psa_mixed", lights=MIXED, strategy=0, heuristic=0, samples=2, technique="projected_solid_angle_arvo"),
+    dict(key="arvo_psa_ggx_rays", lights=PENTAGON, strategy=1, heuristic=0, samples=1, technique="projected_solid_angle_arvo", rays=True),
+    dict(key="arvo_psa_error_backward", lights=MIXED, strategy=0, heuristic=0, samples=1, technique="projected_solid_angle_arvo", error_display=1),
     dict(key="error_backward_diffuse_only", lights=MIXED, strategy=0, heuristic=0, samples=1, error_display=1),
     dict(key="error_backward_scaled_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=2),
     dict(key="error_forward_specular_mis", lights=MIXED, strategy=3, heuristic=3, samples=1, error_display=6),

@@ -62,6 +62,8 @@ def test_experiment_from_the_table_runs_end_to_end(tmp_path):
     assert os.path.basename(result["screenshot"]).startswith("error_attic_backward_") and not result["rays"]
     colors = np.unique(decode_png(open(result["screenshot"], "rb").read()).reshape(-1, 3), axis=0)
     assert 2 <= len(colors) <= 22  # background + a subset of the 20 colour bins
-    # an experiment that needs a related-work sampler is refused with the library's message
-    with pytest.raises(RuntimeError):
-        experiments.run_experiment(index + 15, root, frames=1, warmup=0, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
+    # the related-work samplers of the comparison figures run too (entry 49: Arvo's projected solid
+    # angle sampling in the Cornell box)
+    result = experiments.run_experiment(49, root, frames=2, warmup=1, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
+    assert os.path.basename(result["screenshot"]).startswith("cornell_box_projected_solid_angle_arvo_1spp_")
+    assert decode_png(open(result["screenshot"], "rb").read()).max() > 0

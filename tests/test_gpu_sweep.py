@@ -45,7 +45,7 @@ def random_case(seed):
         technique = ["baseline", "area_turk", "bilinear_cosine_warp_hart", "bilinear_cosine_warp_clipping_hart",
                      "biquadratic_cosine_warp_hart", "biquadratic_cosine_warp_clipping_hart"][int(rng.integers(0, 6))]
     elif strategy <= 1 and rng.random() < 0.25:
-        technique = ["rectangle_solid_angle_urena", "solid_angle_arvo"][int(rng.integers(0, 2))]
+        technique = ["rectangle_solid_angle_urena", "solid_angle_arvo", "projected_solid_angle_arvo"][int(rng.integers(0, 3))]
     elif strategy <= 1:
         technique = ["projected_solid_angle", "projected_solid_angle_biased", "solid_angle", "clipped_solid_angle"][int(rng.integers(0, 4))]
     else:
@@ -56,6 +56,8 @@ def random_case(seed):
     error_display = 0
     if technique.startswith("projected") and rng.random() < 0.15:
         error_display = int(rng.integers(1, 4)) if strategy <= 1 else int(rng.integers(1, 7))
+        if technique.endswith("arvo"):
+            error_display = int(rng.integers(1, 3))  # Arvo's error function has no forward error
     return dict(strategy=strategy, technique=technique, heuristic=heuristic, lights=lights, samples=int(rng.integers(1, 4)),
                 rays=bool(rng.random() < 0.6), show_lights=bool(rng.random() < 0.3), error_display=error_display,
                 roughness_factor=float(rng.uniform(0.3, 1.5)), exposure_factor=float(rng.uniform(1.0, 10.0)),

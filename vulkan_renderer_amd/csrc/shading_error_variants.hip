@@ -31,6 +31,9 @@ template <int STRATEGY, int ERROR>
 static int launch_technique(int technique, int capacity, const shade_params& p, dim3 grid, hipStream_t stream) {
 	if (technique == kTechniquePsa) return launch_capacity<STRATEGY, kTechniquePsa, ERROR>(capacity, p, grid, stream);
 	if (technique == kTechniquePsaBiased) return launch_capacity<STRATEGY, kTechniquePsaBiased, ERROR>(capacity, p, grid, stream);
+	// Arvo's sampler has its own error function, in the diffuse-only preparation only
+	if constexpr (STRATEGY == kStrategyDiffuseOnly && ERROR == kErrorDiffuse)
+		if (technique == kTechniquePsaArvo) return launch_capacity<STRATEGY, kTechniquePsaArvo, ERROR>(capacity, p, grid, stream);
 	return -1;
 }
 

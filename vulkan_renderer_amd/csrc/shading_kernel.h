@@ -25,7 +25,7 @@ namespace vkr {
 enum { kStrategyDiffuseOnly = 0, kStrategyDiffuseGgxMis = 1, kStrategySeparately = 2, kStrategyMis = 3, kStrategyRandom = 4 };
 enum { kTechniquePsa = 0, kTechniquePsaBiased = 1, kTechniqueSolidAngle = 2, kTechniqueClippedSolidAngle = 3, kTechniqueBaseline = 4, kTechniqueAreaTurk = 5,
 	kTechniqueUrena = 6, kTechniqueArvoSolidAngle = 7, kTechniqueHartBilinear = 8, kTechniqueHartBilinearClipping = 9,
-	kTechniqueHartBiquadratic = 10, kTechniqueHartBiquadraticClipping = 11, kTechniqueCount = 12 };
+	kTechniqueHartBiquadratic = 10, kTechniqueHartBiquadraticClipping = 11, kTechniquePsaArvo = 12, kTechniqueCount = 13 };
 enum { kMisBalance = 0, kMisPower = 1, kMisWeighted = 2, kMisOptimalClamped = 3, kMisOptimal = 4 };
 
 struct shade_params {
@@ -765,17 +765,41 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			vs[V - 1] = zero;
 			uint32_t clipped = clip_polygon<V>(count, vs);
 			if (clipped == 0) return zero;
-			psa_polygon<V> pd;
-			prepare_psa<V, kBiased>(pd, clipped, vs);
-			if (pd.total <= 0.0f) return zero;
-			if constexpr (ERROR == kErrorDiffuse) return display_sampling_error<V, kBiased>(p, pd, noise);
-			for (uint32_t s = 0; s != S; ++s) {
-				f3 dir = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
-				float density = divide(dir.z, pd.total);
-				dir = mul_transposed(world_to_shading, dir);
-				add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+			if constexpr (TECHNIQUE == kTechniquePsaArvo) {
+				// Arvo's sampler, three Newton iterations (:462-481); the GGX tail below uses its
+				// density without the cosine, like the reference
+				psa_arvo<V> pa;
+				prepare_psa_arvo<V>(pa, clipped, vs);
+				if (pa.total <= 0.0f) return zero;
+				if constexpr (ERROR == kErrorDiffuse) {
+					f2 u = next_noise_2(p, noise);
+					f3 dir = sample_psa_arvo<V>(pa, u, 3u);
+					f2 e = psa_sampling_error_arvo<V>(pa, u, dir);
+					f3 color = error_to_color(p, (p.error_index == 0) ? e.x : e.y);
+					float exposure = load_f(p.constants, 176);
+					return mk3(divide(color.x, exposure), divide(color.y, exposure), divide(color.z, exposure));
+				}
+				for (uint32_t s = 0; s != S; ++s) {
+					f3 dir = sample_psa_arvo<V>(pa, next_noise_2(p, noise), 3u);
+					float density = divide(dir.z, pa.total);
+					dir = mul_transposed(world_to_shading, dir);
+					add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+				}
+				density_factor = rcp(pa.total);
 			}
-			density_factor = rcp(pd.total);
+			else {
+				psa_polygon<V> pd;
+				prepare_psa<V, kBiased>(pd, clipped, vs);
+				if (pd.total <= 0.0f) return zero;
+				if constexpr (ERROR == kErrorDiffuse) return display_sampling_error<V, kBiased>(p, pd, noise);
+				for (uint32_t s = 0; s != S; ++s) {
+					f3 dir = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
+					float density = divide(dir.z, pd.total);
+					dir = mul_transposed(world_to_shading, dir);
+					add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+				}
+				density_factor = rcp(pd.total);
+			}
 		}
 		else {
 			// both techniques are prepared by the same code path (:506-547)

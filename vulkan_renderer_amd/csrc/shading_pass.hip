@@ -37,8 +37,13 @@ static bvh_view make_bvh_view(const acceleration_structure_t* structure) {
 	return view;
 }
 
-static int technique_index(sample_polygon_technique_t technique) {
-	switch (technique) {
+static int technique_index(const render_settings_t* settings) {
+	switch (settings->polygon_sampling_technique) {
+	// Arvo's sampler only exists in the diffuse-only / GGX-MIS branch of the reference shader; its
+	// combined diffuse + specular branch uses the paper's own sampler whatever the technique says
+	// (shading_pass.frag.glsl:441, :506-547)
+	case sample_polygon_projected_solid_angle_arvo:
+		return settings->sampling_strategies >= sampling_strategies_diffuse_specular_separately ? kTechniquePsa : kTechniquePsaArvo;
 	case sample_polygon_projected_solid_angle: return kTechniquePsa;
 	case sample_polygon_projected_solid_angle_biased: return kTechniquePsaBiased;
 	case sample_polygon_solid_angle: return kTechniqueSolidAngle;
@@ -319,12 +324,12 @@ extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* devic
 static int validate_settings(const application_t* app) {
 	const render_settings_t* s = &app->render_settings;
 	const scene_specification_t* spec = &app->scene_specification;
-	int technique = technique_index(s->polygon_sampling_technique);
+	int technique = technique_index(s);
 	if (technique < 0) {
-		printf("Polygon sampling technique %d belongs to the related-work comparison set of the reference and is not part of the shading pass. Built: baseline, area (Turk), rectangle solid angle (Urena), solid angle (Arvo and ours), clipped solid angle, bilinear and biquadratic cosine warp (Hart, with and without clipping), (biased) projected solid angle.\n", (int) s->polygon_sampling_technique);
+		printf("Invalid polygon sampling technique %d.\n", (int) s->polygon_sampling_technique);
 		return 1;
 	}
-	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased;
+	bool is_psa = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniquePsaArvo;
 	// An out-of-range strategy selects none of the strategy defines of the reference, i.e.
 	// the combined diffuse + specular preparation with no estimator behind it.  That is
 	// only meaningful with an error display (the reference's own experiment table does it,
@@ -356,6 +361,10 @@ static int validate_settings(const application_t* app) {
 	}
 	if (s->error_display >= error_display_count) {
 		printf("Invalid error display mode.\n");
+		return 1;
+	}
+	if (technique == kTechniquePsaArvo && s->error_display == error_display_diffuse_forward) {
+		printf("Arvo's sampler only defines the backward errors (the reference shader does not compile with the forward error either).\n");
 		return 1;
 	}
 	if (s->sample_count == 0) {
@@ -402,7 +411,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	if (app->render_settings.trace_shadow_rays && !pass->use_ray_tracing)
 		printf("Shadow rays were requested but the scene has no acceleration structure; rendering without shadows.\n");
 	pass->max_polygon_vertex_count = get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings);
-	pass->variant = (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(app->render_settings.polygon_sampling_technique);
+	pass->variant = (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(&app->render_settings);
 	pass->constants_size = get_constant_buffer_size(app);
 	if (create_constants_ring(pass, device) || create_timing_ring(pass))
 	{
@@ -450,7 +459,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	if (get_constant_buffer_size(app) != pass->constants_size
 		|| get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings) != pass->max_polygon_vertex_count
-		|| (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(app->render_settings.polygon_sampling_technique) != pass->variant)
+		|| (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(&app->render_settings) != pass->variant)
 	{
 		printf("Lights or render settings changed in a way that needs a different kernel variant. Recreate the shading pass (the reference recompiles its shader in this situation, main.c:1833-1881).\n");
 		return 1;
@@ -497,9 +506,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	int error_mode = kErrorNone;
 	{
 		int display = (int) app->render_settings.error_display;
-		int technique_now = technique_index(app->render_settings.polygon_sampling_technique);
+		int technique_now = technique_index(&app->render_settings);
 		bool combined = app->render_settings.sampling_strategies >= sampling_strategies_diffuse_specular_separately;
-		if (display != error_display_none && (technique_now == kTechniquePsa || technique_now == kTechniquePsaBiased)) {
+		if (display != error_display_none && (technique_now == kTechniquePsa || technique_now == kTechniquePsaBiased || technique_now == kTechniquePsaArvo)) {
 			bool specular = display == error_display_specular_backward || display == error_display_specular_backward_scaled || display == error_display_specular_forward;
 			error_mode = specular ? (combined ? kErrorSpecular : kErrorNone) : kErrorDiffuse;
 		}
@@ -561,8 +570,8 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	if (upload_constants(app, stream)) return 1;
 	p.constants = (const uint8_t*) pass->constants_device;
 	int strategy = (int) app->render_settings.sampling_strategies;
-	int technique = technique_index(app->render_settings.polygon_sampling_technique);
-	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping;
+	int technique = technique_index(&app->render_settings);
+	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping || technique == kTechniquePsaArvo;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
 	// every timing_stride-th frame is bracketed by a pair of events (an event record costs
 	// about 5 us of idle time on the stream, a tenth of a config-2 frame for the pair)

@@ -30,7 +30,7 @@ template <int TECHNIQUE>
 static int launch_capacity(int capacity, int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
 	// techniques that clip the polygon at the horizon need one more vertex slot (reference main.c:194-216)
 	constexpr bool kClips = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased || TECHNIQUE == kTechniqueClippedSolidAngle || TECHNIQUE == kTechniqueHartBilinearClipping
-		|| TECHNIQUE == kTechniqueHartBiquadraticClipping;
+		|| TECHNIQUE == kTechniqueHartBiquadraticClipping || TECHNIQUE == kTechniquePsaArvo;
 	switch (capacity) {
 	case 3: if constexpr (!kClips) return launch_rays<TECHNIQUE, 3>(rays, p, grid, stream); else return -1;
 	case 4: return launch_rays<TECHNIQUE, 4>(rays, p, grid, stream);
@@ -57,6 +57,7 @@ extern "C" int VKR_LAUNCH_NAME(int technique, int capacity, int rays, const shad
 	// related work whose shader branches define a solid angle for the GGX MIS tail
 	case kTechniqueUrena: return launch_capacity<kTechniqueUrena>(capacity, rays, *p, grid, s);
 	case kTechniqueArvoSolidAngle: return launch_capacity<kTechniqueArvoSolidAngle>(capacity, rays, *p, grid, s);
+	case kTechniquePsaArvo: return launch_capacity<kTechniquePsaArvo>(capacity, rays, *p, grid, s);
 #endif
 #if VKR_STRATEGY == 0
 	// the two simplest related-work techniques of the reference's comparison set; their shader

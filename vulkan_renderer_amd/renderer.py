@@ -17,7 +17,8 @@ STRATEGY = {"diffuse_only": 0, "diffuse_ggx_mis": 1, "diffuse_specular_separatel
 MIS = {"balance": 0, "power": 1, "weighted": 2, "optimal_clamped": 3, "optimal": 4}
 TECHNIQUE = {"baseline": 0, "area_turk": 1, "rectangle_solid_angle_urena": 2, "solid_angle_arvo": 3,
              "bilinear_cosine_warp_hart": 6, "bilinear_cosine_warp_clipping_hart": 7,
-             "biquadratic_cosine_warp_hart": 8, "biquadratic_cosine_warp_clipping_hart": 9, "solid_angle": 4, "clipped_solid_angle": 5, "projected_solid_angle": 11,
+             "biquadratic_cosine_warp_hart": 8, "biquadratic_cosine_warp_clipping_hart": 9,
+             "projected_solid_angle_arvo": 10, "solid_angle": 4, "clipped_solid_angle": 5, "projected_solid_angle": 11,
              "projected_solid_angle_biased": 12}
 NOISE = {"white": 0, "blue": 1, "ahmed": 2}
 
