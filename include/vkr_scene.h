@@ -29,7 +29,8 @@ typedef enum material_texture_type_e {
 	material_texture_count
 } material_texture_type_t;
 
-/*! reference scene.h:143-156, with textures collapsed to constants */
+/*! reference scene.h:143-156.  Half / float textures are reduced to one constant texel,
+	8-bit and block-compressed ones are decoded to RGBA8 mip chains. */
 typedef struct materials_s {
 	uint64_t material_count;
 	char** material_names;
@@ -37,6 +38,19 @@ typedef struct materials_s {
 		roughness, metalicity), normal.xy (0.5, 0.5 is the geometric normal) */
 	float* host_constants;
 	void* constants;
+	/*! VK_TRUE if at least one material texture is a real image (8-bit or BC1 / BC5 *.vkt):
+		then the pass samples textures per pixel (trilinear, software) instead of constants */
+	VkBool32 textured;
+	/*! 3 per material, 4 uint32 each: first texel in texels, width, height,
+		mip_count | srgb << 16.  Width 0: this texture is the constant in host_constants. */
+	uint32_t* host_texture_descriptors;
+	/*! RGBA8 texels of all textures and mip levels */
+	uint8_t* host_texels;
+	uint64_t texel_count;
+	void* texture_descriptors;
+	void* texels;
+	/*! 256 floats: sRGB decoding table used by the sampler */
+	void* srgb_table;
 } materials_t;
 
 /*! Replaces reference scene.h:161-175: a binary BVH over the de-quantised

@@ -173,6 +173,9 @@ typedef struct shading_pass_s {
 	void* wavefront;
 	/*! device counter of the rays traced inside the shading kernel (inline_rays) */
 	void* ray_counter;
+	/*! textured scenes: 8 floats per pixel sampled from the material textures before shading */
+	void* pixel_materials;
+	size_t pixel_materials_size;
 	/*! timing of the last dispatch in milliseconds (HIP events on device->stream) */
 	float last_dispatch_ms;
 	/*! ring of HIP event pairs, one pair per timed render_shading_pass call */

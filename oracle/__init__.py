@@ -47,7 +47,12 @@ class Frame(C.Structure):
         ("sample_count", C.c_uint32), ("trace_shadow_rays", C.c_int32), ("show_polygonal_lights", C.c_int32),
         ("bvh", C.c_void_p), ("brute_force_rays", C.c_int32),
         ("error_display", C.c_int32), ("error_index", C.c_int32),
+        ("material_textures", C.c_void_p),
     ]
+
+
+class Texture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("mip_count", C.c_uint32), ("srgb", C.c_uint32)]
 
 
 _lib = None
@@ -214,6 +219,18 @@ def make_frame(inputs, settings, bvh=None):
     display = int(settings.get("error_display", 0))
     f.error_display = 0 if display == 0 else (1 if display <= 3 else 2)
     f.error_index = (display - 1) % 3 if display else 0
+    # material textures: list of dicts {"texels": uint8 array of all mips (RGBA8), "width", "height", "mip_count", "srgb"},
+    # three per material (base colour, specular, normal)
+    textures = inputs.get("material_textures")
+    if textures:
+        array = (Texture * len(textures))()
+        for index, (t, entry) in enumerate(zip(array, textures)):
+            texels = np.ascontiguousarray(entry["texels"], np.uint8)
+            keep["texture_texels_%d" % index] = texels
+            t.texels = texels.ctypes.data
+            t.width, t.height, t.mip_count, t.srgb = int(entry["width"]), int(entry["height"]), int(entry["mip_count"]), int(entry["srgb"])
+        keep["texture_array"] = array
+        f.material_textures = C.cast(array, C.c_void_p)
     f._keep = keep
     f._bvh = bvh
     return f

@@ -30,6 +30,16 @@ enum { O_TECHNIQUE_BASELINE = 0, O_TECHNIQUE_AREA_TURK = 1, O_TECHNIQUE_RECTANGL
 	O_TECHNIQUE_PROJECTED_SOLID_ANGLE_ARVO = 10, O_TECHNIQUE_SOLID_ANGLE = 4, O_TECHNIQUE_CLIPPED_SOLID_ANGLE = 5,
 	O_TECHNIQUE_PROJECTED_SOLID_ANGLE = 11, O_TECHNIQUE_PROJECTED_SOLID_ANGLE_BIASED = 12 };
 
+/* One material texture (reference: a VkImage with its mip chain, scene.c:486-559): RGBA8 texels,
+ * mip 0 first, every level tightly packed, rows top to bottom.  The filter that stands in for the
+ * driver's sampler (unpinned by the reference) is oracle_sample_texture below. */
+typedef struct oracle_texture_s {
+	const uint8_t* texels;
+	uint32_t width, height, mip_count;
+	/* 1: the colour channels are sRGB encoded (VK_FORMAT_*_SRGB) */
+	uint32_t srgb;
+} oracle_texture_t;
+
 /* Everything the per-pixel program reads.  Buffers are byte-identical to what
  * the product uploads to the GPU. */
 typedef struct oracle_frame_s {
@@ -69,7 +79,17 @@ typedef struct oracle_frame_s {
 	 * error_display 0 none, 1 diffuse, 2 specular; error_index 0 backward, 1 backward
 	 * times projected solid angle, 2 forward */
 	int32_t error_display, error_index;
+	/* 3 textures per material (base colour, specular, normal) or NULL: then material_constants
+	 * stand for constant textures and the texture coordinate derivatives are not computed */
+	const oracle_texture_t* material_textures;
 } oracle_frame_t;
+
+/* textureGrad() of this build: isotropic trilinear filtering, repeat addressing.  level of detail
+ * = log2 of the longer of the two screen-space derivative vectors in texels, clamped to the mip
+ * chain; bilinear weights in exact fp32, x first; sRGB texels are decoded before filtering. */
+void oracle_sample_texture(const oracle_texture_t* texture, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]);
+/* the sRGB -> linear table that the sampler uses (256 floats); the product uploads the same table */
+const float* oracle_srgb_table(void);
 
 /* Shades rows [y0, y1) of the frame into out_rgba (width*height*4 floats,
  * vec4(final_color * exposure, 1), reference shading_pass.frag.glsl:866).

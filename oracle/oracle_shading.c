@@ -282,6 +282,70 @@ static float ggx_reflected_density(float out_dot_n, v3 out_dir, v3 in_dir, v3 no
 /* ------------------------------------------------------------------------ */
 /* get_shading_data, shading_pass.frag.glsl:721-822                          */
 
+/* ---- material textures: the software sampler (unpinned by the reference, see oracle.h) ---- */
+
+const float* oracle_srgb_table(void) {
+	static float table[256];
+	static int ready = 0;
+	if (!ready) {
+		for (int i = 0; i != 256; ++i) {
+			float v = (float) i / 255.0f;
+			table[i] = (v <= 0.04045f) ? (v / 12.92f) : powf((v + 0.055f) / 1.055f, 2.4f);
+		}
+		ready = 1;
+	}
+	return table;
+}
+
+static void fetch_texel(const oracle_texture_t* t, const uint8_t* level, int width, int height, int x, int y, float out[4]) {
+	x = ((x % width) + width) % width;
+	y = ((y % height) + height) % height;
+	const uint8_t* texel = level + 4 * ((size_t) y * (size_t) width + (size_t) x);
+	const float* srgb = oracle_srgb_table();
+	for (int c = 0; c != 3; ++c) out[c] = t->srgb ? srgb[texel[c]] : (float) texel[c] * (1.0f / 255.0f);
+	out[3] = (float) texel[3] * (1.0f / 255.0f);
+}
+
+static void sample_level(const oracle_texture_t* t, uint32_t level, float u, float v, float out[4]) {
+	const uint8_t* texels = t->texels;
+	int width = (int) t->width, height = (int) t->height;
+	for (uint32_t l = 0; l != level; ++l) {
+		texels += 4 * (size_t) width * (size_t) height;
+		width = width > 1 ? width / 2 : 1;
+		height = height > 1 ? height / 2 : 1;
+	}
+	float x = u * (float) width - 0.5f, y = v * (float) height - 0.5f;
+	float x0 = floorf(x), y0 = floorf(y);
+	float fx = x - x0, fy = y - y0;
+	float t00[4], t10[4], t01[4], t11[4];
+	fetch_texel(t, texels, width, height, (int) x0, (int) y0, t00);
+	fetch_texel(t, texels, width, height, (int) x0 + 1, (int) y0, t10);
+	fetch_texel(t, texels, width, height, (int) x0, (int) y0 + 1, t01);
+	fetch_texel(t, texels, width, height, (int) x0 + 1, (int) y0 + 1, t11);
+	for (int c = 0; c != 4; ++c) {
+		float top = t00[c] * (1.0f - fx) + t10[c] * fx;
+		float bottom = t01[c] * (1.0f - fx) + t11[c] * fx;
+		out[c] = top * (1.0f - fy) + bottom * fy;
+	}
+}
+
+void oracle_sample_texture(const oracle_texture_t* t, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]) {
+	float w = (float) t->width, h = (float) t->height;
+	float ax = duv_dx[0] * w, ay = duv_dx[1] * h, bx = duv_dy[0] * w, by = duv_dy[1] * h;
+	float rho = g_max(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+	float max_level = (float) (t->mip_count - 1);
+	/* rho <= 1 (magnification), NaN and 0 all select the finest level */
+	float lambda = (rho > 1.0f) ? g_min(o_log2(rho), max_level) : 0.0f;
+	float level_0 = floorf(lambda);
+	float fraction = lambda - level_0;
+	uint32_t l0 = (uint32_t) level_0;
+	uint32_t l1 = (l0 + 1 < t->mip_count) ? l0 + 1 : l0;
+	float c0[4], c1[4];
+	sample_level(t, l0, uv[0], uv[1], c0);
+	sample_level(t, l1, uv[0], uv[1], c1);
+	for (int c = 0; c != 4; ++c) out_rgba[c] = c0[c] * (1.0f - fraction) + c1[c] * fraction;
+}
+
 static shading_data_t get_shading_data(const oracle_frame_t* f, const frame_constants_t* k, uint32_t primitive, v3 ray_direction) {
 	shading_data_t r;
 	v3 pos[3], nrm[3];
@@ -303,12 +367,44 @@ static shading_data_t get_shading_data(const oracle_frame_t* f, const frame_cons
 	v3 e0_cross_to0 = cross3(e0, to0);
 	b[2] = -rcp_det * dot3(ray_direction, e0_cross_to0);
 	b[0] = 1.0f - (b[1] + b[2]);
-	/* the screen-space derivatives (:754-766, :772-777) only feed textureGrad; material
-	   textures are constant here, so they are dead code and omitted */
 	r.position = fma3s(b[0], pos[0], fma3s(b[1], pos[1], scale3(pos[2], b[2])));
 	v3 interpolated_normal = normalize3(fma3s(b[0], nrm[0], fma3s(b[1], nrm[1], scale3(nrm[2], b[2]))));
 	uint32_t material = f->material_indices[primitive];
 	const float* mc = f->material_constants + 8 * (size_t) material;
+	float sampled[8];
+	if (f->material_textures) {
+		/* screen-space derivatives of the barycentrics (:754-766) and of the texture coordinate (:772-777) */
+		v3 derivs[2];
+		for (int i = 0; i != 2; ++i) {
+			v3 ray_deriv = mk3(k->pixel_to_ray[0][i], k->pixel_to_ray[1][i], k->pixel_to_ray[2][i]);
+			v3 ray_cross_e1_deriv = cross3(ray_deriv, e1);
+			float rcp_det_deriv = -dot3(e0, ray_cross_e1_deriv) * rcp_det * rcp_det;
+			float det_0_dir_e1 = dot3(to0, ray_cross_e1);
+			float det_0_dir_e1_deriv = dot3(to0, ray_cross_e1_deriv);
+			derivs[i].y = rcp_det_deriv * det_0_dir_e1 + rcp_det * det_0_dir_e1_deriv;
+			float det_dir_e0_0 = dot3(ray_direction, e0_cross_to0);
+			float det_dir_e0_0_deriv = dot3(ray_deriv, e0_cross_to0);
+			derivs[i].z = -rcp_det_deriv * det_dir_e0_0 - rcp_det * det_dir_e0_0_deriv;
+			derivs[i].x = -(derivs[i].y + derivs[i].z);
+		}
+		v2 tex_coord = fma2s(b[0], uv[0], fma2s(b[1], uv[1], scale2(uv[2], b[2])));
+		v2 tex_derivs[2] = {mk2(0.0f, 0.0f), mk2(0.0f, 0.0f)};
+		for (int i = 0; i != 2; ++i) {
+			const float weights[3] = {derivs[i].x, derivs[i].y, derivs[i].z};
+			for (int j = 0; j != 3; ++j) tex_derivs[i] = add2(tex_derivs[i], scale2(uv[j], weights[j]));
+		}
+		const float uv_[2] = {tex_coord.x, tex_coord.y}, dx_[2] = {tex_derivs[0].x, tex_derivs[0].y}, dy_[2] = {tex_derivs[1].x, tex_derivs[1].y};
+		for (int type = 0; type != 3; ++type) {
+			const oracle_texture_t* texture = &f->material_textures[3 * material + type];
+			/* width 0: this texture is a constant (half / float *.vkt or absent file) */
+			float texel[4] = {mc[3 * type], mc[3 * type + 1], type < 2 ? mc[3 * type + 2] : 0.0f, 1.0f};
+			if (texture->width != 0) oracle_sample_texture(texture, uv_, dx_, dy_, texel);
+			sampled[3 * type] = texel[0];
+			sampled[3 * type + 1] = texel[1];
+			if (type < 2) sampled[3 * type + 2] = texel[2];
+		}
+		mc = sampled;
+	}
 	v3 base_color = mk3(mc[0], mc[1], mc[2]);
 	v3 specular_data = mk3(mc[3], mc[4], mc[5]);
 	v3 nt;

@@ -235,7 +235,10 @@ struct utextureBuffer { const void* data = nullptr; int kind = 0; };  // 0: RG32
 struct textureBuffer { const uint16_t* data = nullptr; };             // RGBA16_UNORM
 struct texture2DArray { const uint16_t* data = nullptr; int width = 0, height = 0, depth = 0; };  // RGBA16_UNORM
 struct sampler2DArray { const uint16_t* data = nullptr; int channels = 0, resolution = 0, layers = 0; };
-struct sampler2D { vec4 constant; };
+// a constant texel, or a view onto an oracle_texture_t that is filtered by the oracle's sampler
+// (texture filtering is the driver's in the reference; oracle.h documents the stand-in)
+struct sampler2D { vec4 constant; const void* texture = nullptr; };
+extern "C" void oracle_sample_texture(const void* texture, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]);
 struct usubpassInput { const uint32_t* data = nullptr; int width = 0; };
 struct accelerationStructureEXT { const void* bvh = nullptr; int brute_force = 0; };
 struct rayQueryEXT { bool hit = false; };
@@ -256,7 +259,13 @@ inline vec4 texelFetch(const texture2DArray& t, const ivec3& c, int) {
 	return vec4((float) p[0] / 65535.0f, (float) p[1] / 65535.0f, (float) p[2] / 65535.0f, (float) p[3] / 65535.0f);
 }
 inline uvec4 subpassLoad(const usubpassInput& s) { return uvec4(s.data[(size_t) g_current_pixel_y * s.width + g_current_pixel_x], 0, 0, 1); }
-inline vec4 textureGrad(const sampler2D& s, const vec2&, const vec2&, const vec2&) { return s.constant; }
+inline vec4 textureGrad(const sampler2D& s, const vec2& uv, const vec2& dx, const vec2& dy) {
+	if (!s.texture) return s.constant;
+	const float uv_[2] = {uv.x, uv.y}, dx_[2] = {dx.x, dx.y}, dy_[2] = {dy.x, dy.y};
+	float out[4];
+	oracle_sample_texture(s.texture, uv_, dx_, dy_, out);
+	return vec4(out[0], out[1], out[2], out[3]);
+}
 inline vec4 textureLod(const sampler2D& s, const vec2&, float) { return s.constant; }
 // VK_FILTER_LINEAR, clamp to edge, nearest array layer (round to nearest even);
 // weights in exact fp32, x filtered first (the oracle's documented choice)

@@ -96,6 +96,7 @@ extern "C" void ref_shade_rows(const oracle_frame_t* f, float* out_rgba, uint32_
 		g_material_textures[3 * m + 0].constant = vec4(k[0], k[1], k[2], 1.0f);
 		g_material_textures[3 * m + 1].constant = vec4(k[3], k[4], k[5], 1.0f);
 		g_material_textures[3 * m + 2].constant = vec4(k[6], k[7], 1.0f, 1.0f);
+		for (int t = 0; t != 3; ++t) g_material_textures[3 * m + t].texture = f->material_textures ? (const void*) &f->material_textures[3 * m + t] : nullptr;
 	}
 	for (int t = 0; t != LIGHT_TEXTURE_COUNT; ++t) g_light_textures[t].constant = vec4(1.0f, 1.0f, 1.0f, 1.0f);
 	g_noise_table.data = f->noise; g_noise_table.width = (int) f->noise_width; g_noise_table.height = (int) f->noise_height; g_noise_table.depth = (int) f->noise_depth;

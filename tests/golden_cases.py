@@ -122,3 +122,16 @@ def random_polygon(rng, n):
     center[2] = abs(center[2]) + rng.uniform(-0.6, 1.2)
     radius = rng.uniform(0.3, 1.8)
     return np.array([center + radius * (np.cos(a) * t + np.sin(a) * b) for a in ang], np.float32)
+
+
+# Textured scenes: the same reference variants, material textures as real images (BC1 sRGB base
+# colour, RGBA8 specular, BC5 normal with mip chains).  The texture filter itself is the
+# driver's in the reference; the compiled reference shader calls the oracle's sampler for it
+# (oracle.h), so these frames pin everything around the filter: derivatives, coordinates,
+# how the texels enter the BRDF parameters.
+TEXTURED_DATASET = dict(DATASET, textured=True, texture_size=32)
+TEXTURED_CASES = [
+    dict(key="textured_cfg2_ggx_mis_rays", lights=PENTAGON, strategy=1, heuristic=0, samples=1, rays=True),
+    dict(key="textured_mis_clamped", lights=QUADS, strategy=3, heuristic=3, samples=2, rays=True),
+    dict(key="textured_diffuse_only", lights=TRIANGLE, strategy=0, heuristic=0, samples=1),
+]

@@ -69,7 +69,9 @@ class Mesh(C.Structure):
 
 class Materials(C.Structure):
     _fields_ = [("material_count", C.c_uint64), ("material_names", C.POINTER(C.c_char_p)),
-                ("host_constants", c_float_p), ("constants", C.c_void_p)]
+                ("host_constants", c_float_p), ("constants", C.c_void_p),
+                ("textured", C.c_uint32), ("host_texture_descriptors", C.POINTER(C.c_uint32)), ("host_texels", C.POINTER(C.c_uint8)),
+                ("texel_count", C.c_uint64), ("texture_descriptors", C.c_void_p), ("texels", C.c_void_p), ("srgb_table", C.c_void_p)]
 
 
 class AccelerationStructure(C.Structure):
@@ -127,7 +129,7 @@ class TileSchedule(C.Structure):
 class ShadingPass(C.Structure):
     _fields_ = [("use_ray_tracing", C.c_uint32), ("variant", C.c_int32), ("max_polygon_vertex_count", C.c_uint32),
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t), ("constants_ring", C.c_void_p),
-                ("fast_math", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("last_frame_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
+                ("fast_math", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("last_frame_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("pixel_materials", C.c_void_p), ("pixel_materials_size", C.c_size_t), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
                 ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32)]
 
 

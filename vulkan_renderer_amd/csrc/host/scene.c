@@ -82,6 +82,21 @@ static int read_constant_texel(float out[4], const char* path) {
 	return 0;
 }
 
+/* The sRGB decoding table of the software sampler: the same formula and the same libm as the
+   oracle's oracle_srgb_table(), so that both sides filter identical floats. */
+void vkr_fill_srgb_table(float table[256]) {
+	for (int i = 0; i != 256; ++i) {
+		float v = (float) i / 255.0f;
+		table[i] = (v <= 0.04045f) ? (v / 12.92f) : powf((v + 0.055f) / 1.055f, 2.4f);
+	}
+}
+
+static int vkr_upload_srgb_table(void** out, const device_t* device) {
+	float table[256];
+	vkr_fill_srgb_table(table);
+	return vkr_device_upload(out, device, table, sizeof(table), "the sRGB table");
+}
+
 static void free_mesh(mesh_t* mesh, const device_t* device) {
 	free(mesh->host_positions);
 	free(mesh->host_normals_and_tex_coords);
@@ -94,6 +109,11 @@ static void free_mesh(mesh_t* mesh, const device_t* device) {
 
 void destroy_scene(scene_t* scene, const device_t* device) {
 	free_mesh(&scene->mesh, device);
+	free(scene->materials.host_texture_descriptors);
+	free(scene->materials.host_texels);
+	vkr_device_free(scene->materials.texture_descriptors, device);
+	vkr_device_free(scene->materials.texels, device);
+	vkr_device_free(scene->materials.srgb_table, device);
 	if (scene->materials.material_names)
 		for (uint64_t i = 0; i != scene->materials.material_count; ++i) free(scene->materials.material_names[i]);
 	free(scene->materials.material_names);
@@ -166,6 +186,7 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 		}
 	/* material constants */
 	scene->materials.host_constants = (float*) malloc(sizeof(float) * 8 * (material_count ? material_count : 1));
+	scene->materials.host_texture_descriptors = (uint32_t*) calloc(12 * (material_count ? material_count : 1), sizeof(uint32_t));
 	for (uint64_t i = 0; i != material_count; ++i) {
 		float* k = scene->materials.host_constants + 8 * i;
 		const float defaults[8] = {0.8f, 0.8f, 0.8f, 1.0f, 0.5f, 0.0f, 0.5f, 0.5f};
@@ -173,8 +194,31 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 		for (uint32_t type = 0; type != material_texture_count && texture_path; ++type) {
 			const char* pieces[] = {texture_path, "/", scene->materials.material_names[i], "_", get_material_texture_suffix((material_texture_type_t) type), ".vkt"};
 			char* path = vkr_concatenate(VKR_COUNT_OF(pieces), pieces);
+			/* 8-bit and block-compressed textures become RGBA8 mip chains, half / float ones a constant */
+			vkr_host_texture_t image;
+			int status = vkr_load_texture_rgba8(&image, path);
+			if (status == 0) {
+				uint32_t* descriptor = scene->materials.host_texture_descriptors + 4 * (3 * i + type);
+				uint8_t* grown = (uint8_t*) realloc(scene->materials.host_texels, 4 * (scene->materials.texel_count + image.texel_count));
+				if (!grown || scene->materials.texel_count + image.texel_count > 0xFFFFFFFFull) {
+					printf("Out of memory for the material textures of the scene file at path %s.\n", file_path);
+					free(path); vkr_free_host_texture(&image);
+					destroy_scene(scene, device);
+					return 1;
+				}
+				scene->materials.host_texels = grown;
+				memcpy(grown + 4 * scene->materials.texel_count, image.texels, 4 * image.texel_count);
+				descriptor[0] = (uint32_t) scene->materials.texel_count;
+				descriptor[1] = image.width; descriptor[2] = image.height;
+				descriptor[3] = image.mip_count | (image.srgb << 16);
+				scene->materials.texel_count += image.texel_count;
+				scene->materials.textured = VK_TRUE;
+				vkr_free_host_texture(&image);
+				free(path);
+				continue;
+			}
 			float texel[4];
-			int status = read_constant_texel(texel, path);
+			if (status == 3) status = read_constant_texel(texel, path);
 			free(path);
 			if (status == 2) {
 				printf("Failed to load material textures for the scene file at path %s using texture path %s.\n", file_path, texture_path);
@@ -191,7 +235,11 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 		if (vkr_device_upload(&mesh->positions, device, mesh->host_positions, sizeof(uint32_t) * 2 * vertex_count, "vertex positions")
 			|| vkr_device_upload(&mesh->normals_and_tex_coords, device, mesh->host_normals_and_tex_coords, sizeof(uint16_t) * 4 * vertex_count, "normals and texture coordinates")
 			|| vkr_device_upload(&mesh->material_indices, device, mesh->host_material_indices, mesh->triangle_count, "material indices")
-			|| vkr_device_upload(&scene->materials.constants, device, scene->materials.host_constants, sizeof(float) * 8 * (material_count ? material_count : 1), "material constants"))
+			|| vkr_device_upload(&scene->materials.constants, device, scene->materials.host_constants, sizeof(float) * 8 * (material_count ? material_count : 1), "material constants")
+			|| (scene->materials.textured && (
+				vkr_device_upload(&scene->materials.texture_descriptors, device, scene->materials.host_texture_descriptors, sizeof(uint32_t) * 12 * material_count, "texture descriptors")
+				|| vkr_device_upload(&scene->materials.texels, device, scene->materials.host_texels, 4 * scene->materials.texel_count, "material textures")
+				|| vkr_upload_srgb_table(&scene->materials.srgb_table, device))))
 		{
 			printf("Failed to copy mesh data of the scene file at path %s to the device. It has %llu triangles.\n", file_path, (unsigned long long) mesh->triangle_count);
 			destroy_scene(scene, device);

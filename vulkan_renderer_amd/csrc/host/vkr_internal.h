@@ -29,6 +29,18 @@ void vkr_host_free_pinned(void* pointer);
 int vkr_copy_to_device_async(void* device_pointer, const void* host, size_t size, const device_t* device);
 int vkr_copy_to_host(void* host, const void* device_pointer, size_t size, const device_t* device);
 
+/*! textures.c: a material texture decoded to RGBA8, all mip levels one after the other */
+typedef struct vkr_host_texture_s {
+	uint32_t width, height, mip_count, srgb;
+	uint8_t* texels;
+	uint64_t texel_count;
+} vkr_host_texture_t;
+/*! 0 on success, 1 if the file is absent, 2 if it is invalid, 3 if its format is not decoded here */
+int vkr_load_texture_rgba8(vkr_host_texture_t* out, const char* path);
+void vkr_free_host_texture(vkr_host_texture_t* texture);
+void vkr_decode_bc1_block(const uint8_t block[8], uint8_t out_rgba[64], int has_alpha);
+void vkr_decode_bc5_block(const uint8_t block[16], uint8_t out_rgba[64]);
+
 /*! 4x4 inverse with the operation order of reference math_utilities.h:24-47 */
 void vkr_matrix_inverse(float inverse[4][4], const float matrix[4][4]);
 /*! reference math_utilities.h:50-57 */

@@ -39,6 +39,12 @@ struct shade_params {
 	const uint2* normals_and_tex_coords;
 	const uint8_t* material_indices;
 	const float* material_constants;
+	// textured scenes: 8 floats per pixel of the frame written by k_resolve_materials (else NULL),
+	// and the inputs of that kernel
+	const float* pixel_materials;
+	const uint32_t* texture_descriptors;
+	const uint32_t* texels;
+	const float* srgb_table;
 	// G-buffer in, radiance out
 	const uint32_t* visibility;
 	float4* out_radiance;
@@ -165,33 +171,161 @@ VKR_DEV f3 decode_normal(float ox, float oy) {
 	return normalize(n);
 }
 
-VKR_DEV shading_data get_shading_data(const shade_params& p, uint32_t primitive, f3 ray_direction) {
-	const uint8_t* c = p.constants;
-	f3 factor = load_f3(c, 0), summand = load_f3(c, 16), camera = load_f3(c, 144);
-	shading_data r;
+// the first half of get_shading_data (:723-752): vertex fetch and the barycentrics of the view ray
+struct triangle_hit {
 	f3 pos[3], nrm[3];
 	f2 uv[3];
+	f3 e0, e1, to0, ray_cross_e1, e0_cross_to0;
+	float rcp_det, b0, b1, b2;
+};
+
+VKR_DEV triangle_hit intersect_primitive(const shade_params& p, uint32_t primitive, f3 ray_direction) {
+	const uint8_t* c = p.constants;
+	f3 factor = load_f3(c, 0), summand = load_f3(c, 16), camera = load_f3(c, 144);
+	triangle_hit t;
 #pragma unroll
 	for (int i = 0; i < 3; ++i) {
 		size_t vi = (size_t) primitive * 3 + i;
-		pos[i] = decode_position(p.positions[vi], factor, summand);
+		t.pos[i] = decode_position(p.positions[vi], factor, summand);
 		uint2 q = p.normals_and_tex_coords[vi];
-		nrm[i] = decode_normal(unorm16(q.x & 0xFFFF), unorm16(q.x >> 16));
-		uv[i] = mk2(fmaf(unorm16(q.y & 0xFFFF), 8.0f, 0.0f), fmaf(unorm16(q.y >> 16), -8.0f, 1.0f));
+		t.nrm[i] = decode_normal(unorm16(q.x & 0xFFFF), unorm16(q.x >> 16));
+		t.uv[i] = mk2(fmaf(unorm16(q.y & 0xFFFF), 8.0f, 0.0f), fmaf(unorm16(q.y >> 16), -8.0f, 1.0f));
 	}
-	f3 e0 = pos[1] - pos[0], e1 = pos[2] - pos[0];
-	f3 ray_cross_e1 = cross(ray_direction, e1);
-	float rcp_det = rcp(dot(e0, ray_cross_e1));
-	f3 to0 = camera - pos[0];
-	float b1 = rcp_det * dot(to0, ray_cross_e1);
-	f3 e0_cross_to0 = cross(e0, to0);
-	float b2 = -rcp_det * dot(ray_direction, e0_cross_to0);
-	float b0 = 1.0f - (b1 + b2);
-	// screen-space derivatives (:754-777) only feed textureGrad; with constant
-	// material texels they are dead code
+	t.e0 = t.pos[1] - t.pos[0]; t.e1 = t.pos[2] - t.pos[0];
+	t.ray_cross_e1 = cross(ray_direction, t.e1);
+	t.rcp_det = rcp(dot(t.e0, t.ray_cross_e1));
+	t.to0 = camera - t.pos[0];
+	t.b1 = t.rcp_det * dot(t.to0, t.ray_cross_e1);
+	t.e0_cross_to0 = cross(t.e0, t.to0);
+	t.b2 = -t.rcp_det * dot(ray_direction, t.e0_cross_to0);
+	t.b0 = 1.0f - (t.b1 + t.b2);
+	return t;
+}
+
+// ---- material textures: the software sampler (oracle_sample_texture in oracle/oracle_shading.c) ----
+
+struct texture_view {
+	const uint32_t* texels;  // RGBA8, all mip levels, finest first
+	uint32_t width, height, mip_count;
+	bool srgb;
+};
+
+VKR_DEV float4 fetch_texel(const shade_params& p, const texture_view& t, const uint32_t* level, int width, int height, int x, int y) {
+	x = ((x % width) + width) % width;
+	y = ((y % height) + height) % height;
+	uint32_t texel = level[(size_t) y * (size_t) width + (size_t) x];
+	uint32_t r = texel & 255u, g = (texel >> 8) & 255u, b = (texel >> 16) & 255u, a = texel >> 24;
+	float4 out;
+	out.x = t.srgb ? p.srgb_table[r] : (float) r * (1.0f / 255.0f);
+	out.y = t.srgb ? p.srgb_table[g] : (float) g * (1.0f / 255.0f);
+	out.z = t.srgb ? p.srgb_table[b] : (float) b * (1.0f / 255.0f);
+	out.w = (float) a * (1.0f / 255.0f);
+	return out;
+}
+
+VKR_DEV float4 sample_level(const shade_params& p, const texture_view& t, uint32_t level, float u, float v) {
+	const uint32_t* texels = t.texels;
+	int width = (int) t.width, height = (int) t.height;
+	for (uint32_t l = 0; l != level; ++l) {
+		texels += (size_t) width * (size_t) height;
+		width = width > 1 ? width / 2 : 1;
+		height = height > 1 ? height / 2 : 1;
+	}
+	float x = u * (float) width - 0.5f, y = v * (float) height - 0.5f;
+	float x0 = floorf(x), y0 = floorf(y);
+	float fx = x - x0, fy = y - y0;
+	float4 t00 = fetch_texel(p, t, texels, width, height, (int) x0, (int) y0);
+	float4 t10 = fetch_texel(p, t, texels, width, height, (int) x0 + 1, (int) y0);
+	float4 t01 = fetch_texel(p, t, texels, width, height, (int) x0, (int) y0 + 1);
+	float4 t11 = fetch_texel(p, t, texels, width, height, (int) x0 + 1, (int) y0 + 1);
+	float4 out;
+	out.x = (t00.x * (1.0f - fx) + t10.x * fx) * (1.0f - fy) + (t01.x * (1.0f - fx) + t11.x * fx) * fy;
+	out.y = (t00.y * (1.0f - fx) + t10.y * fx) * (1.0f - fy) + (t01.y * (1.0f - fx) + t11.y * fx) * fy;
+	out.z = (t00.z * (1.0f - fx) + t10.z * fx) * (1.0f - fy) + (t01.z * (1.0f - fx) + t11.z * fx) * fy;
+	out.w = (t00.w * (1.0f - fx) + t10.w * fx) * (1.0f - fy) + (t01.w * (1.0f - fx) + t11.w * fx) * fy;
+	return out;
+}
+
+// textureGrad of this build: isotropic trilinear filtering with repeat addressing
+VKR_DEV float4 sample_texture(const shade_params& p, const texture_view& t, f2 uv, f2 duv_dx, f2 duv_dy) {
+	float w = (float) t.width, h = (float) t.height;
+	float ax = duv_dx.x * w, ay = duv_dx.y * h, bx = duv_dy.x * w, by = duv_dy.y * h;
+	float rho = gmax(square_root(ax * ax + ay * ay), square_root(bx * bx + by * by));
+	float max_level = (float) (t.mip_count - 1);
+	float lambda = (rho > 1.0f) ? gmin(log2_poly(rho), max_level) : 0.0f;
+	float level_0 = floorf(lambda);
+	float fraction = lambda - level_0;
+	uint32_t l0 = (uint32_t) level_0;
+	uint32_t l1 = (l0 + 1 < t.mip_count) ? l0 + 1 : l0;
+	float4 c0 = sample_level(p, t, l0, uv.x, uv.y), c1 = sample_level(p, t, l1, uv.x, uv.y);
+	return make_float4(c0.x * (1.0f - fraction) + c1.x * fraction, c0.y * (1.0f - fraction) + c1.y * fraction,
+		c0.z * (1.0f - fraction) + c1.z * fraction, c0.w * (1.0f - fraction) + c1.w * fraction);
+}
+
+// The texture reads of get_shading_data (:754-785) for one pixel: screen-space derivatives of the
+// barycentrics and of the texture coordinate, then base colour, specular and normal texture.
+// Writes the eight numbers that a constant material stores (see materials_t.host_constants).
+VKR_DEV void resolve_material(const shade_params& p, uint32_t primitive, f3 ray_direction, float (&out)[8]) {
+	triangle_hit t = intersect_primitive(p, primitive, ray_direction);
+	const uint8_t* c = p.constants;
+	f3 derivs[2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+		f3 ray_deriv = mk3(load_f(c, 96 + 4 * i), load_f(c, 112 + 4 * i), load_f(c, 128 + 4 * i));
+		f3 ray_cross_e1_deriv = cross(ray_deriv, t.e1);
+		float rcp_det_deriv = -dot(t.e0, ray_cross_e1_deriv) * t.rcp_det * t.rcp_det;
+		float det_0_dir_e1 = dot(t.to0, t.ray_cross_e1);
+		float det_0_dir_e1_deriv = dot(t.to0, ray_cross_e1_deriv);
+		derivs[i].y = rcp_det_deriv * det_0_dir_e1 + t.rcp_det * det_0_dir_e1_deriv;
+		float det_dir_e0_0 = dot(ray_direction, t.e0_cross_to0);
+		float det_dir_e0_0_deriv = dot(ray_deriv, t.e0_cross_to0);
+		derivs[i].z = -rcp_det_deriv * det_dir_e0_0 - t.rcp_det * det_dir_e0_0_deriv;
+		derivs[i].x = -(derivs[i].y + derivs[i].z);
+	}
+	f2 tex_coord = fma2(t.b0, t.uv[0], fma2(t.b1, t.uv[1], t.uv[2] * t.b2));
+	f2 tex_derivs[2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+		f2 sum = mk2(0.0f, 0.0f);
+		sum = sum + t.uv[0] * derivs[i].x;
+		sum = sum + t.uv[1] * derivs[i].y;
+		sum = sum + t.uv[2] * derivs[i].z;
+		tex_derivs[i] = sum;
+	}
+	uint32_t material = p.material_indices[primitive];
+	const float* constants = p.material_constants + 8 * (size_t) material;
+#pragma unroll
+	for (int type = 0; type < 3; ++type) {
+		const uint32_t* descriptor = p.texture_descriptors + 4 * (3 * (size_t) material + type);
+		float4 texel = make_float4(constants[3 * type], constants[3 * type + 1], type < 2 ? constants[3 * type + 2] : 0.0f, 1.0f);
+		if (descriptor[1] != 0) {
+			texture_view view;
+			view.texels = p.texels + descriptor[0];
+			view.width = descriptor[1]; view.height = descriptor[2];
+			view.mip_count = descriptor[3] & 0xFFFFu;
+			view.srgb = (descriptor[3] >> 16) != 0;
+			texel = sample_texture(p, view, tex_coord, tex_derivs[0], tex_derivs[1]);
+		}
+		out[3 * type] = texel.x;
+		out[3 * type + 1] = texel.y;
+		if (type < 2) out[3 * type + 2] = texel.z;
+	}
+}
+
+VKR_DEV shading_data get_shading_data(const shade_params& p, uint32_t primitive, f3 ray_direction, size_t pixel_index) {
+	const uint8_t* c = p.constants;
+	f3 camera = load_f3(c, 144);
+	shading_data r;
+	triangle_hit t = intersect_primitive(p, primitive, ray_direction);
+	const f3 (&pos)[3] = t.pos;
+	const f3 (&nrm)[3] = t.nrm;
+	const f2 (&uv)[3] = t.uv;
+	f3 e0 = t.e0, e1 = t.e1;
+	float b0 = t.b0, b1 = t.b1, b2 = t.b2;
 	r.position = fma3(b0, pos[0], fma3(b1, pos[1], pos[2] * b2));
 	f3 interpolated_normal = normalize(fma3(b0, nrm[0], fma3(b1, nrm[1], nrm[2] * b2)));
-	const float* mc = p.material_constants + 8 * (size_t) p.material_indices[primitive];
+	// constant material, or what the material resolve kernel sampled for this pixel
+	const float* mc = p.pixel_materials ? p.pixel_materials + 8 * pixel_index : p.material_constants + 8 * (size_t) p.material_indices[primitive];
 	f3 base_color = mk3(mc[0], mc[1], mc[2]);
 	float linear_roughness = mc[4], metalicity = mc[5];
 	f3 nt;
@@ -1027,7 +1161,7 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 		f3 end_xyz = ray;
 		float end_w = 0.0f;
 		if (primitive != 0xFFFFFFFFu) {
-			sd = get_shading_data(p, primitive, ray);
+			sd = get_shading_data(p, primitive, ray, (size_t) py * p.width + px);
 			end_xyz = sd.position;
 			end_w = 1.0f;
 		}

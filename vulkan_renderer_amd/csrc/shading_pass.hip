@@ -310,6 +310,7 @@ extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* devic
 	if (device && pass->wavefront) (void) wait_for_device(device);
 	destroy_constants_ring(pass, device);
 	if (pass->ray_counter) (void) hipFree(pass->ray_counter);
+	if (pass->pixel_materials) (void) hipFree(pass->pixel_materials);
 	destroy_wavefront(pass);
 	if (pass->timing_ring) {
 		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
@@ -450,6 +451,31 @@ extern "C" uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank
 	return (uint64_t) grid_blocks * 256;
 }
 
+// ---- material resolve (textured scenes) ----------------------------------------------
+
+// One lane per pixel of the frame: the three texture reads of get_shading_data
+// (shading_pass.frag.glsl:754-785) with their screen-space derivatives, written as the eight
+// numbers of a constant material so that the shading kernels stay as they are.
+__global__ void __launch_bounds__(256) k_resolve_materials(const shade_params p, float* pixel_materials) {
+	uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint32_t px = blockIdx.x * 16 + ((wave & 1) << 3) + (lane & 7);
+	uint32_t py = blockIdx.y * 16 + ((wave >> 1) << 3) + (lane >> 3);
+	if (px >= p.width || py >= p.height) return;
+	uint32_t primitive = p.visibility[(size_t) py * p.width + px];
+	if (primitive == 0xFFFFFFFFu) return;
+	const uint8_t* c = p.constants;
+	float fx = (float) (int32_t) px, fy = (float) (int32_t) py;
+	f3 ray = mk3(
+		(load_f(c, 96) * fx + load_f(c, 100) * fy) + load_f(c, 104) * 1.0f,
+		(load_f(c, 112) * fx + load_f(c, 116) * fy) + load_f(c, 120) * 1.0f,
+		(load_f(c, 128) * fx + load_f(c, 132) * fy) + load_f(c, 136) * 1.0f);
+	float values[8];
+	resolve_material(p, primitive, ray, values);
+	float4* out = (float4*) (pixel_materials + 8 * ((size_t) py * p.width + px));
+	out[0] = make_float4(values[0], values[1], values[2], values[3]);
+	out[1] = make_float4(values[4], values[5], values[6], values[7]);
+}
+
 extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	shading_pass_t* pass = &app->shading_pass;
 	const device_t* device = &app->device;
@@ -536,7 +562,8 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		if (!frames) return 1;
 		uint32_t thread_count = grid_blocks * 256u, max_terms = 2u * p.light_count * p.sample_count;
 		// two sets of buffers must fit comfortably into the 288 GB of HBM next to everything else
-		pipelined = pass->frames_in_flight >= 2 && device->frame_streams[0] && device->frame_streams[1]
+		// (a textured scene has one per-pixel material buffer: one frame at a time)
+		pipelined = pass->frames_in_flight >= 2 && device->frame_streams[0] && device->frame_streams[1] && !app->scene.materials.textured
 			&& 2.0 * wavefront_bytes(thread_count, max_terms, p.light_count) < 192.0e9;
 		if (!pipelined && finish_frames(app)) return 1;
 		uint32_t index = pipelined ? (frames->next++ & 1u) : 0u;
@@ -566,9 +593,30 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	}
 	else if (finish_frames(app)) return 1;
 	pass->last_frame_in_flight = pipelined ? 1u : 0u;
+	// textured scene: sample the material textures of every pixel first (same stream)
+	bool textured = app->scene.materials.textured && app->scene.materials.texture_descriptors;
+	if (textured) {
+		size_t needed = sizeof(float) * 8 * (size_t) p.width * p.height;
+		if (pass->pixel_materials_size != needed) {
+			if (wait_for_device(device)) return 1;
+			(void) hipFree(pass->pixel_materials);
+			pass->pixel_materials = NULL;
+			pass->pixel_materials_size = 0;
+			if (hip_failed(hipMalloc(&pass->pixel_materials, needed), "allocating the per-pixel materials")) return 1;
+			pass->pixel_materials_size = needed;
+		}
+		p.texture_descriptors = (const uint32_t*) app->scene.materials.texture_descriptors;
+		p.texels = (const uint32_t*) app->scene.materials.texels;
+		p.srgb_table = (const float*) app->scene.materials.srgb_table;
+	}
 	if (pass->use_ray_tracing && pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 	if (upload_constants(app, stream)) return 1;
 	p.constants = (const uint8_t*) pass->constants_device;
+	if (textured) {
+		dim3 resolve_grid((p.width + 15) / 16, (p.height + 15) / 16);
+		k_resolve_materials<<<resolve_grid, 256, 0, stream>>>(p, (float*) pass->pixel_materials);
+		p.pixel_materials = (const float*) pass->pixel_materials;
+	}
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(&app->render_settings);
 	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping || technique == kTechniquePsaArvo;

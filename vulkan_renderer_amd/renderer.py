@@ -144,6 +144,20 @@ class HostScene:
             "dequantization_factor": np.array(app.scene.mesh.dequantization_factor[:], np.float32),
             "dequantization_summand": np.array(app.scene.mesh.dequantization_summand[:], np.float32),
         }
+        materials = app.scene.materials
+        if materials.textured:
+            descriptors = np.ctypeslib.as_array(materials.host_texture_descriptors, (materials.material_count * 3, 4)).copy()
+            texels = np.ctypeslib.as_array(materials.host_texels, (materials.texel_count, 4)).copy()
+            textures = []
+            for first, width, height, packed in descriptors:
+                count = 0
+                w, h = int(width), int(height)
+                for _ in range(int(packed) & 0xFFFF):
+                    count += w * h
+                    w, h = max(w // 2, 1), max(h // 2, 1)
+                textures.append({"texels": texels[int(first):int(first) + count] if width else np.zeros((1, 4), np.uint8),
+                                 "width": int(width), "height": int(height), "mip_count": int(packed) & 0xFFFF, "srgb": int(packed) >> 16})
+            inputs["material_textures"] = textures
         if visibility is not None:
             inputs["visibility"] = np.ascontiguousarray(visibility, np.uint32)
         return inputs

@@ -165,6 +165,160 @@ def write_material_textures(directory, materials=None):
     return list(materials.keys())
 
 
+# ---- textured materials: *.vkt with 8-bit and block-compressed mip chains ------------------
+
+VK_FORMAT_R8G8B8A8_UNORM, VK_FORMAT_R8G8B8A8_SRGB = 37, 43
+VK_FORMAT_BC1_RGB_UNORM, VK_FORMAT_BC1_RGB_SRGB, VK_FORMAT_BC5_UNORM = 131, 132, 141
+
+
+def write_vkt(path, vk_format, extents, payloads):
+    """The container of reference src/textures.c:95-129: header, mip table, data, end marker."""
+    offsets, offset = [], 0
+    for data in payloads:
+        offsets.append(offset)
+        offset += len(data)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiiiii", 0xBC1BC1, 1, len(payloads), extents[0][0], extents[0][1], vk_format))
+        f.write(struct.pack("<Q", offset))
+        for (w, h), data, o in zip(extents, payloads, offsets):
+            f.write(struct.pack("<iiQQ", w, h, len(data), o))
+        for data in payloads:
+            f.write(data)
+        f.write(struct.pack("<I", 0xE0FE0F))
+
+
+def mip_chain(image):
+    """Box-filtered chain down to 1x1 (uint8, any channel count; extents halve and floor)."""
+    chain = [np.ascontiguousarray(image, np.uint8)]
+    while chain[-1].shape[0] > 1 or chain[-1].shape[1] > 1:
+        a = chain[-1].astype(np.float64)
+        h, w = max(a.shape[0] // 2, 1), max(a.shape[1] // 2, 1)
+        a = a[:2 * h if a.shape[0] > 1 else 1, :2 * w if a.shape[1] > 1 else 1]
+        if a.shape[0] > 1:
+            a = 0.5 * (a[0::2] + a[1::2])
+        if a.shape[1] > 1:
+            a = 0.5 * (a[:, 0::2] + a[:, 1::2])
+        chain.append(np.clip(np.rint(a), 0, 255).astype(np.uint8))
+    return chain
+
+
+def _pad_to_blocks(image):
+    h, w = image.shape[:2]
+    return np.pad(image, ((0, (-h) % 4), (0, (-w) % 4), (0, 0)), mode="edge")
+
+
+def _to_565(rgb):
+    return ((int(rgb[0]) >> 3) << 11) | ((int(rgb[1]) >> 2) << 5) | (int(rgb[2]) >> 3)
+
+
+def decode_bc1_block(block, has_alpha=False):
+    """Reference decoder for the tests: the format definition with endpoints expanded by bit
+    replication and interpolants rounded to nearest (the choice csrc/host/textures.c documents)."""
+    c0, c1, indices = struct.unpack("<HHI", block)
+    def expand(c):
+        r, g, b = c >> 11, (c >> 5) & 63, c & 31
+        return [(r << 3) | (r >> 2), (g << 2) | (g >> 4), (b << 3) | (b >> 2), 255]
+    colors = [expand(c0), expand(c1), None, None]
+    if c0 > c1:
+        colors[2] = [(2 * a + b + 1) // 3 for a, b in zip(colors[0][:3], colors[1][:3])] + [255]
+        colors[3] = [(a + 2 * b + 1) // 3 for a, b in zip(colors[0][:3], colors[1][:3])] + [255]
+    else:
+        colors[2] = [(a + b + 1) // 2 for a, b in zip(colors[0][:3], colors[1][:3])] + [255]
+        colors[3] = [0, 0, 0, 0 if has_alpha else 255]
+    return np.array([colors[(indices >> (2 * i)) & 3] for i in range(16)], np.uint8).reshape(4, 4, 4)
+
+
+def decode_bc4_block(block):
+    e0, e1 = block[0], block[1]
+    values = [e0, e1]
+    if e0 > e1:
+        values += [((7 - i) * e0 + i * e1 + 3) // 7 for i in range(1, 7)]
+    else:
+        values += [((5 - i) * e0 + i * e1 + 2) // 5 for i in range(1, 5)] + [0, 255]
+    indices = int.from_bytes(block[2:8], "little")
+    return np.array([values[(indices >> (3 * i)) & 7] for i in range(16)], np.uint8).reshape(4, 4)
+
+
+def encode_bc1(image):
+    """A simple BC1 encoder (endpoints = extreme colours of the block by luminance)."""
+    padded = _pad_to_blocks(image[..., :3])
+    out = bytearray()
+    for by in range(0, padded.shape[0], 4):
+        for bx in range(0, padded.shape[1], 4):
+            block = padded[by:by + 4, bx:bx + 4].reshape(16, 3).astype(np.int32)
+            luminance = block @ np.array([2, 5, 1])
+            c0, c1 = _to_565(block[luminance.argmax()]), _to_565(block[luminance.argmin()])
+            if c0 < c1:
+                c0, c1 = c1, c0
+            if c0 == c1:
+                out += struct.pack("<HHI", c0, c1, 0)
+                continue
+            palette = decode_bc1_block(struct.pack("<HHI", c0, c1, 0x1B))  # texels 0..3 use indices 3, 2, 1, 0
+            palette = {3: palette[0, 0, :3], 2: palette[0, 1, :3], 1: palette[0, 2, :3], 0: palette[0, 3, :3]}
+            indices = 0
+            for i, texel in enumerate(block):
+                best = min(range(4), key=lambda k: int(((palette[k].astype(np.int32) - texel) ** 2).sum()))
+                indices |= best << (2 * i)
+            out += struct.pack("<HHI", c0, c1, indices)
+    return bytes(out)
+
+
+def encode_bc4(channel):
+    padded = _pad_to_blocks(channel[..., None])[..., 0]
+    out = bytearray()
+    for by in range(0, padded.shape[0], 4):
+        for bx in range(0, padded.shape[1], 4):
+            block = padded[by:by + 4, bx:bx + 4].reshape(16).astype(np.int32)
+            e0, e1 = int(block.max()), int(block.min())
+            if e0 == e1:
+                out += bytes([e0, e1]) + bytes(6)
+                continue
+            values = decode_bc4_block(bytes([e0, e1]) + (0o76543210).to_bytes(3, "little") * 2)[0].astype(np.int32)  # texels 0..7 use indices 0..7
+            indices = 0
+            for i, texel in enumerate(block):
+                indices |= int(np.abs(values[:8] - texel).argmin()) << (3 * i)
+            out += bytes([e0, e1]) + indices.to_bytes(6, "little")
+    return bytes(out)
+
+
+def encode_bc5(image):
+    red, green = encode_bc4(image[..., 0]), encode_bc4(image[..., 1])
+    return b"".join(red[i:i + 8] + green[i:i + 8] for i in range(0, len(red), 8))
+
+
+def procedural_textures(size=64, seed=3):
+    """Base colour (sRGB), specular (occlusion, linear roughness, metalicity) and tangent-space
+    normal (xy in [0, 1]) images with features at several scales, so that every mip level matters."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:size, 0:size].astype(np.float64) / size
+    checker = ((np.floor(x * 8) + np.floor(y * 8)) % 2)
+    noise = rng.random((size, size))
+    base = np.stack([0.25 + 0.6 * checker, 0.3 + 0.5 * x, 0.2 + 0.6 * noise], -1)
+    specular = np.stack([np.ones_like(x), 0.25 + 0.5 * (0.5 + 0.5 * np.sin(12.0 * x) * np.cos(9.0 * y)), 0.3 * checker], -1)
+    normal = np.stack([0.5 + 0.12 * np.sin(20.0 * x), 0.5 + 0.12 * np.cos(16.0 * y), np.ones_like(x)], -1)
+    to8 = lambda a: np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
+    return to8(base), to8(specular), to8(normal)
+
+
+def write_textured_material_textures(directory, names, size=64, formats=("bc1_srgb", "rgba8", "bc5")):
+    """*.vkt files with real images for every material: BC1 sRGB base colour, RGBA8 specular,
+    BC5 normal by default (what the reference's converter produces); mip chains down to 1x1."""
+    os.makedirs(directory, exist_ok=True)
+    for index, name in enumerate(names):
+        base, specular, normal = procedural_textures(size, seed=3 + index)
+        for image, suffix, kind in ((base, "BaseColor", formats[0]), (specular, "Specular", formats[1]), (normal, "Normal", formats[2])):
+            rgba = np.concatenate([image, np.full(image.shape[:2] + (1,), 255, np.uint8)], -1)
+            chain = mip_chain(rgba)
+            extents = [(m.shape[1], m.shape[0]) for m in chain]
+            if kind.startswith("bc1"):
+                payloads, vk_format = [encode_bc1(m) for m in chain], (VK_FORMAT_BC1_RGB_SRGB if kind.endswith("srgb") else VK_FORMAT_BC1_RGB_UNORM)
+            elif kind == "bc5":
+                payloads, vk_format = [encode_bc5(m) for m in chain], VK_FORMAT_BC5_UNORM
+            else:
+                payloads, vk_format = [m.tobytes() for m in chain], (VK_FORMAT_R8G8B8A8_SRGB if kind.endswith("srgb") else VK_FORMAT_R8G8B8A8_UNORM)
+            write_vkt(os.path.join(directory, "%s_%s.vkt" % (name, suffix)), vk_format, extents, payloads)
+
+
 # ---- LTC fit files ------------------------------------------------------------------
 
 def write_ltc_fits(directory, resolution=32, fresnel_count=51):
@@ -253,10 +407,13 @@ CONFIG_SETTINGS = {
 }
 
 
-def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51):
-    """Writes scene.vks, textures/, ltc/ below `directory` and returns the paths."""
+def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51, textured=False, texture_size=64):
+    """Writes scene.vks, textures/, ltc/ below `directory` and returns the paths.  textured:
+    real images (BC1 / RGBA8 / BC5 with mip chains) instead of constant material textures."""
     os.makedirs(directory, exist_ok=True)
     names = write_material_textures(os.path.join(directory, "textures"))
+    if textured:
+        write_textured_material_textures(os.path.join(directory, "textures"), names, texture_size)
     positions, normals, uvs, mats = make_scene_geometry(grid, box_count, seed, materials=len(names))
     scene_path = os.path.join(directory, "scene.vks")
     write_vks(scene_path, positions, normals, uvs, mats, names)
