@@ -1,0 +1,194 @@
+"""SURVEY.md 8(f) rank 4, material textures: the *.vkt loader (RGBA8, BC1, BC5 with mip chains),
+the software sampler that stands in for the driver's, and textured frames against the reference
+shader (which calls the same sampler for textureGrad: everything around the filter is pinned)."""
+import ctypes as C
+import os
+import struct
+import tempfile
+
+import numpy as np
+import pytest
+
+import golden_cases
+import oracle
+from vulkan_renderer_amd import renderer, synthetic
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def textured_dataset(tmp_path_factory):
+    return synthetic.write_dataset(str(tmp_path_factory.mktemp("textured")), **golden_cases.TEXTURED_DATASET)
+
+
+def read_vkt(path):
+    data = open(path, "rb").read()
+    marker, version, mips, width, height, vk_format = struct.unpack_from("<iiiiii", data, 0)
+    size, = struct.unpack_from("<Q", data, 24)
+    table = [struct.unpack_from("<iiQQ", data, 32 + 24 * m) for m in range(mips)]
+    payload = data[32 + 24 * mips:32 + 24 * mips + size]
+    assert marker == 0xBC1BC1 and version == 1 and struct.unpack_from("<I", data, 32 + 24 * mips + size)[0] == 0xE0FE0F
+    return vk_format, [(w, h, payload[o:o + s]) for w, h, s, o in table]
+
+
+def decode_reference(vk_format, w, h, blob):
+    """Python decoders written from the format definitions (vulkan_renderer_amd/synthetic.py)"""
+    out = np.zeros((h, w, 4), np.uint8)
+    if vk_format in (37, 43):
+        return np.frombuffer(blob, np.uint8).reshape(h, w, 4)
+    blocks_x, block_bytes = (w + 3) // 4, 16 if vk_format == 141 else 8
+    for by in range((h + 3) // 4):
+        for bx in range(blocks_x):
+            block = blob[block_bytes * (by * blocks_x + bx):][:block_bytes]
+            if vk_format == 141:
+                texels = np.zeros((4, 4, 4), np.uint8)
+                texels[..., 0] = synthetic.decode_bc4_block(block[:8])
+                texels[..., 1] = synthetic.decode_bc4_block(block[8:])
+                texels[..., 3] = 255
+            else:
+                texels = synthetic.decode_bc1_block(block, has_alpha=vk_format in (133, 134))
+            region = out[4 * by:4 * by + 4, 4 * bx:4 * bx + 4]
+            region[...] = texels[:region.shape[0], :region.shape[1]]
+    return out
+
+
+def test_loader_decodes_every_mip_like_the_format_definitions(textured_dataset):
+    hs = renderer.HostScene()
+    hs.load_scene(textured_dataset["scene"], textured_dataset["textures"])
+    materials = hs.app.scene.materials
+    assert materials.textured == 1 and materials.material_count == 3
+    names = [materials.material_names[i].decode() for i in range(3)]
+    descriptors = np.ctypeslib.as_array(materials.host_texture_descriptors, (9, 4))
+    texels = np.ctypeslib.as_array(materials.host_texels, (materials.texel_count, 4))
+    for m, name in enumerate(names):
+        for t, (suffix, srgb) in enumerate((("BaseColor", 1), ("Specular", 0), ("Normal", 0))):
+            vk_format, mips = read_vkt(os.path.join(textured_dataset["textures"], "%s_%s.vkt" % (name, suffix)))
+            first, width, height, packed = (int(v) for v in descriptors[3 * m + t])
+            assert (width, height) == mips[0][:2] and packed & 0xFFFF == len(mips) == 6 and packed >> 16 == srgb
+            cursor = first
+            for w, h, blob in mips:
+                expected = decode_reference(vk_format, w, h, blob)
+                assert np.array_equal(texels[cursor:cursor + w * h].reshape(h, w, 4), expected), (name, suffix, w, h)
+                cursor += w * h
+    hs.close()
+
+
+def test_block_decoders_on_hand_made_blocks():
+    # BC1, four-colour mode: pure red and pure blue endpoints, one texel of each palette entry
+    block = struct.pack("<HHI", 0xF800, 0x001F, 0b11100100)
+    expected = synthetic.decode_bc1_block(block)
+    # decoders are internal (hidden visibility): exercised through files in the test above; here the
+    # Python definitions themselves are checked against the values of the specification
+    assert expected[0, 0].tolist() == [255, 0, 0, 255] and expected[0, 1].tolist() == [0, 0, 255, 255]
+    assert expected[0, 2].tolist() == [170, 0, 85, 255] and expected[0, 3].tolist() == [85, 0, 170, 255]
+    # three-colour mode with punch-through alpha
+    block = struct.pack("<HHI", 0x001F, 0xF800, 0b11100100)
+    expected = synthetic.decode_bc1_block(block, has_alpha=True)
+    assert expected[0, 2].tolist() == [128, 0, 128, 255] and expected[0, 3].tolist() == [0, 0, 0, 0]
+    # BC4: eight-value mode, endpoints 255 and 0 -> index 2 is 6/7 of the way
+    values = synthetic.decode_bc4_block(bytes([255, 0]) + (0o76543210).to_bytes(3, "little") * 2)
+    assert values[0].tolist() == [255, 0, 219, 182] and values[1].tolist() == [146, 109, 73, 36]
+    # six-value mode with the explicit 0 and 255
+    values = synthetic.decode_bc4_block(bytes([0, 255]) + (0o76543210).to_bytes(3, "little") * 2)
+    assert values[0].tolist() == [0, 255, 51, 102] and values[1].tolist() == [153, 204, 0, 255]
+
+
+def test_rejected_and_constant_formats(tmp_path, textured_dataset):
+    """half / float textures stay constants; a truncated file is refused"""
+    import shutil
+    textures = tmp_path / "textures"
+    shutil.copytree(textured_dataset["textures"], textures)
+    hs = renderer.HostScene()
+    name = "rough_grey"
+    synthetic.write_constant_vkt(str(textures / (name + "_Normal.vkt")), (0.5, 0.5, 1.0, 1.0))
+    hs.load_scene(textured_dataset["scene"], str(textures))
+    names = [hs.app.scene.materials.material_names[i].decode() for i in range(3)]
+    descriptors = np.ctypeslib.as_array(hs.app.scene.materials.host_texture_descriptors, (9, 4))
+    assert descriptors[3 * names.index(name) + 2, 1] == 0  # constant
+    assert descriptors[3 * names.index(name) + 0, 1] == 32
+    hs.close()
+    data = open(textures / (name + "_BaseColor.vkt"), "rb").read()
+    open(textures / (name + "_BaseColor.vkt"), "wb").write(data[:len(data) // 2])
+    hs = renderer.HostScene()
+    with pytest.raises(RuntimeError):
+        hs.load_scene(textured_dataset["scene"], str(textures))
+
+
+def sample(texture, uv, dx, dy):
+    L = oracle.lib()
+    t = oracle.Texture()
+    texels = np.ascontiguousarray(texture["texels"], np.uint8)
+    t.texels = texels.ctypes.data
+    t.width, t.height, t.mip_count, t.srgb = texture["width"], texture["height"], texture["mip_count"], texture["srgb"]
+    out = (C.c_float * 4)()
+    L.oracle_sample_texture.argtypes = [C.c_void_p, C.c_float * 2, C.c_float * 2, C.c_float * 2, C.c_float * 4]
+    L.oracle_sample_texture(C.byref(t), (C.c_float * 2)(*uv), (C.c_float * 2)(*dx), (C.c_float * 2)(*dy), out)
+    return np.array(out[:], np.float32)
+
+
+def test_sampler_levels_weights_and_wrapping():
+    # 4x4 texture with a 2x2 and a 1x1 level; every level a different constant except level 0
+    level0 = np.zeros((4, 4, 4), np.uint8)
+    level0[..., 0] = np.arange(16).reshape(4, 4) * 16
+    level0[..., 3] = 255
+    level1 = np.full((2, 2, 4), 100, np.uint8)
+    level2 = np.full((1, 1, 4), 200, np.uint8)
+    texture = {"texels": np.concatenate([level0.reshape(-1, 4), level1.reshape(-1, 4), level2.reshape(-1, 4)]), "width": 4, "height": 4, "mip_count": 3, "srgb": 0}
+    tiny = (1e-4, 0.0), (0.0, 1e-4)
+    # texel centres return the texel (magnification, level 0)
+    assert sample(texture, (0.375, 0.125), *tiny)[0] == np.float32(16 / 255)
+    # half way between two texel centres
+    assert abs(sample(texture, (0.5, 0.125), *tiny)[0] - (16 + 32) / 2 / 255) < 1e-6
+    # repeat addressing: one whole turn later, and across the border (texel 3 of the row blends with texel 0)
+    assert sample(texture, (1.375, 3.125), *tiny)[0] == sample(texture, (0.375, 0.125), *tiny)[0]
+    assert abs(sample(texture, (1.0, 0.125), *tiny)[0] - (48 + 0) / 2 / 255) < 1e-6
+    # footprint of two texels: level 1; of four: level 2; in between: the mix
+    assert abs(sample(texture, (0.3, 0.3), (0.5, 0.0), (0.0, 0.1))[0] - 100 / 255) < 1e-6
+    assert abs(sample(texture, (0.3, 0.3), (1.0, 0.0), (0.0, 0.1))[0] - 200 / 255) < 1e-6
+    between = sample(texture, (0.3, 0.3), (0.70710678, 0.0), (0.0, 0.1))[0]
+    assert abs(between - 150 / 255) < 2e-3
+    # far beyond the chain: the coarsest level
+    assert abs(sample(texture, (0.3, 0.3), (50.0, 0.0), (0.0, 9.0))[0] - 200 / 255) < 1e-6
+    # sRGB texels are decoded before filtering
+    texture["srgb"] = 1
+    value = sample(texture, (0.3, 0.3), (1.0, 0.0), (0.0, 0.1))
+    assert abs(value[0] - ((200 / 255 + 0.055) / 1.055) ** 2.4) < 1e-6 and abs(value[3] - 200 / 255) < 1e-6
+
+
+@pytest.mark.parametrize("case", golden_cases.TEXTURED_CASES, ids=[c["key"] for c in golden_cases.TEXTURED_CASES])
+def test_textured_frame_matches_reference_shader(case, textured_dataset):
+    expected = np.load(os.path.join(GOLDEN, "textured_frames.npz"))[case["key"]]
+    hs, frame, _ = golden_cases.build_frame(case, textured_dataset)
+    image = oracle.shade(frame)
+    hs.close()
+    assert np.array_equal(image.view(np.uint32), expected.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", golden_cases.TEXTURED_CASES, ids=[c["key"] for c in golden_cases.TEXTURED_CASES])
+def test_textured_frame_matches_reference_shader_live(case, textured_dataset):
+    from oracle import reference
+    if not reference.available():
+        pytest.skip("oracle/_ref has not been built (needs /root/reference)")
+    hs, frame, name = golden_cases.build_frame(case, textured_dataset)
+    ours, theirs = oracle.shade(frame), reference.shade(name, frame)
+    hs.close()
+    assert np.array_equal(ours.view(np.uint32), theirs.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", golden_cases.TEXTURED_CASES, ids=[c["key"] for c in golden_cases.TEXTURED_CASES])
+def test_textured_frame_on_the_gpu_equals_the_oracle(case, textured_dataset):
+    from helpers import compare, oracle_render
+    r = renderer.Renderer(frames_in_flight=2)
+    golden_cases.apply_case(r, case, textured_dataset, 96, 64)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.render()
+    r.render()
+    image = r.read_radiance()
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+    assert r.app.shading_pass.last_frame_in_flight == 0  # one per-pixel material buffer: one frame at a time
+    r.close()
+    stats = compare(image, cpu)
+    assert stats["bit_exact"], stats
