@@ -19,6 +19,7 @@ pixels per step.
 PyTorch is plumbing here: device selection, the stream, torch.distributed.
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -305,6 +306,11 @@ def main():
                   "rmse_without_those": math.sqrt(sq_without_flips / max(cnt, 1)),
                   "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
 
+    # the library reports like the reference does (printf): every rank flushes C stdio before rank 0
+    # prints, so that the JSON line is the last line of the job's output
+    ctypes.CDLL(None).fflush(None)
+    if distributed:
+        dist.barrier()
     if rank == 0:
         result = {
             "metric": "Msamples/s (pixels x spp / s), shading pass", "value": round(value, 3), "unit": "Msamples/s",
@@ -327,7 +333,7 @@ def main():
             result["speedup_vs_cpu"] = round(value / cpu_baseline["value"], 1)
         if parity:
             result["parity"] = parity
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     r.close()
     if distributed:
         dist.destroy_process_group()
