@@ -187,6 +187,22 @@ typedef struct shading_pass_s {
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
+/*! The textures of polygonal lights (reference: images_t light_textures, main.h:472, filled by
+	create_and_assign_light_textures main.c:371-417).  One entry per distinct
+	polygonal_light_t.texture_file_path; only the finest level is kept, as RGBA fp32, because the
+	shader reads light textures at level 0 (shading_pass.frag.glsl:182). */
+typedef struct light_textures_s {
+	uint32_t texture_count;
+	/*! per texture: index of its first texel, width, height, 0.  Width 0 means white (the
+		reference's data/white.vkt fallback is built in). */
+	uint32_t (*host_descriptors)[4];
+	float* host_texels;
+	uint64_t texel_count;
+	/*! device copies */
+	uint32_t* descriptors;
+	float* texels;
+} light_textures_t;
+
 typedef struct application_s {
 	device_t device;
 	swapchain_t swapchain;
@@ -199,6 +215,7 @@ typedef struct application_s {
 	screenshot_t screenshot;
 	shading_pass_t shading_pass;
 	tile_schedule_t tile_schedule;
+	light_textures_t light_textures;
 } application_t;
 
 /*! reference main.c:232-249 */
@@ -217,6 +234,14 @@ VKR_API void quick_load(scene_specification_t* scene, VkBool32* light_count_chan
 /*! reference create_render_targets main.c:259-327 / destroy main.c:253-257 */
 VKR_API int create_render_targets(render_targets_t* targets, const device_t* device, const swapchain_t* swapchain);
 VKR_API void destroy_render_targets(render_targets_t* targets, const device_t* device);
+
+/*! reference main.c:371-417 / :364-366.  Loads each distinct light texture once and writes
+	polygonal_light_t.texture_index of every light; absent files and lights without a path get the
+	built-in white texture.  light_textures may be NULL to update the indices only (that is what
+	write_constants() does each frame, reference main.c:2167).  Create (or re-create) it before
+	create_shading_pass() whenever a light uses a texturing technique other than none. */
+VKR_API int create_and_assign_light_textures(light_textures_t* light_textures, const device_t* device, scene_specification_t* scene_specification);
+VKR_API void destroy_light_textures(light_textures_t* light_textures, const device_t* device);
 
 /*! Size in bytes of what write_constants() writes: sizeof(per_frame_constants_t)
 	plus the packed light array (reference create_constant_buffers main.c:330-360) */

@@ -48,11 +48,16 @@ class Frame(C.Structure):
         ("bvh", C.c_void_p), ("brute_force_rays", C.c_int32),
         ("error_display", C.c_int32), ("error_index", C.c_int32),
         ("material_textures", C.c_void_p),
+        ("light_textures", C.c_void_p), ("light_texture_count", C.c_uint32),
     ]
 
 
 class Texture(C.Structure):
     _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("mip_count", C.c_uint32), ("srgb", C.c_uint32)]
+
+
+class LightTexture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
 _lib = None
@@ -231,6 +236,20 @@ def make_frame(inputs, settings, bvh=None):
             t.width, t.height, t.mip_count, t.srgb = int(entry["width"]), int(entry["height"]), int(entry["mip_count"]), int(entry["srgb"])
         keep["texture_array"] = array
         f.material_textures = C.cast(array, C.c_void_p)
+    # light textures: list of float32 arrays (height, width, 4), level 0 only; None = white
+    textures = inputs.get("light_textures")
+    if textures:
+        array = (LightTexture * len(textures))()
+        for index, (t, entry) in enumerate(zip(array, textures)):
+            if entry is None:
+                continue
+            texels = np.ascontiguousarray(entry, np.float32)
+            keep["light_texels_%d" % index] = texels
+            t.texels = texels.ctypes.data
+            t.height, t.width = texels.shape[:2]
+        keep["light_texture_array"] = array
+        f.light_textures = C.cast(array, C.c_void_p)
+        f.light_texture_count = len(textures)
     f._keep = keep
     f._bvh = bvh
     return f

@@ -40,6 +40,14 @@ typedef struct oracle_texture_s {
 	uint32_t srgb;
 } oracle_texture_t;
 
+/* One light texture (reference: g_light_textures[], shading_pass.frag.glsl:61, loaded by
+ * create_and_assign_light_textures main.c:371-417): level 0 only, because the shader reads it with
+ * textureLod(..., 0.0f) (:182); RGBA fp32 texels, rows top to bottom.  width 0 = white. */
+typedef struct oracle_light_texture_s {
+	const float* texels;
+	uint32_t width, height;
+} oracle_light_texture_t;
+
 /* Everything the per-pixel program reads.  Buffers are byte-identical to what
  * the product uploads to the GPU. */
 typedef struct oracle_frame_s {
@@ -82,12 +90,19 @@ typedef struct oracle_frame_s {
 	/* 3 textures per material (base colour, specular, normal) or NULL: then material_constants
 	 * stand for constant textures and the texture coordinate derivatives are not computed */
 	const oracle_texture_t* material_textures;
+	/* textures that polygonal_light_t.texture_index selects, or NULL (then every one is white) */
+	const oracle_light_texture_t* light_textures;
+	uint32_t light_texture_count;
 } oracle_frame_t;
 
 /* textureGrad() of this build: isotropic trilinear filtering, repeat addressing.  level of detail
  * = log2 of the longer of the two screen-space derivative vectors in texels, clamped to the mip
  * chain; bilinear weights in exact fp32, x first; sRGB texels are decoded before filtering. */
 void oracle_sample_texture(const oracle_texture_t* texture, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]);
+/* textureLod(g_light_textures[i], uv, 0) of this build (sampler of main.c:611-621: linear filter,
+ * u repeats, v clamps to the edge): bilinear in exact fp32, x first.  u is wrapped to [0,1) before
+ * scaling; non-finite coordinates read texel column / row 0. */
+void oracle_sample_light_texture(const oracle_light_texture_t* texture, const float uv[2], float out_rgba[4]);
 /* the sRGB -> linear table that the sampler uses (256 floats); the product uploads the same table */
 const float* oracle_srgb_table(void);
 

@@ -47,7 +47,7 @@ typedef struct {
 	v3 translation, surface_radiance;
 	float scaling_x, scaling_y, inv_scaling_x, inv_scaling_y;
 	v4 plane;
-	uint32_t vertex_count, texturing_technique;
+	uint32_t vertex_count, texturing_technique, texture_index;
 	v3 rotation_columns[3];
 	v3 vertices_world[O_CAP];
 	/* world-space area; per fan triangle (area of the triangle, area of the fan so far) */
@@ -100,6 +100,7 @@ static light_view_t read_light(const uint8_t* constants, uint32_t index, uint32_
 	l.plane.x = rd_f(p, 64); l.plane.y = rd_f(p, 68); l.plane.z = rd_f(p, 72); l.plane.w = rd_f(p, 76);
 	l.vertex_count = rd_u(p, 80);
 	l.texturing_technique = rd_u(p, 84);
+	l.texture_index = rd_u(p, 88);
 	/* the UBO is row_major, so GLSL column k is (row0[k], row1[k], row2[k]) */
 	for (int k = 0; k != 3; ++k)
 		l.rotation_columns[k] = mk3(rd_f(p, 96 + 4 * k), rd_f(p, 112 + 4 * k), rd_f(p, 128 + 4 * k));
@@ -344,6 +345,30 @@ void oracle_sample_texture(const oracle_texture_t* t, const float uv[2], const f
 	sample_level(t, l0, uv[0], uv[1], c0);
 	sample_level(t, l1, uv[0], uv[1], c1);
 	for (int c = 0; c != 4; ++c) out_rgba[c] = c0[c] * (1.0f - fraction) + c1[c] * fraction;
+}
+
+void oracle_sample_light_texture(const oracle_light_texture_t* t, const float uv[2], float out_rgba[4]) {
+	if (t->width == 0) {
+		out_rgba[0] = out_rgba[1] = out_rgba[2] = out_rgba[3] = 1.0f;
+		return;
+	}
+	float u = uv[0] - floorf(uv[0]), v = uv[1];
+	if (!(u >= 0.0f && u <= 1.0f)) u = 0.0f;
+	v = (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f;
+	int w = (int) t->width, h = (int) t->height;
+	float fx = u * (float) w - 0.5f, fy = v * (float) h - 0.5f;
+	float flx = floorf(fx), fly = floorf(fy);
+	float wx = fx - flx, wy = fy - fly;
+	int ix = (int) flx, iy = (int) fly;
+	int x0 = (ix < 0) ? w - 1 : ix, x1 = (ix + 1 >= w) ? 0 : ix + 1;
+	int y0 = (iy < 0) ? 0 : iy, y1 = (iy + 1 >= h) ? h - 1 : iy + 1;
+	const float* t00 = t->texels + 4 * ((size_t) y0 * w + x0), *t10 = t->texels + 4 * ((size_t) y0 * w + x1);
+	const float* t01 = t->texels + 4 * ((size_t) y1 * w + x0), *t11 = t->texels + 4 * ((size_t) y1 * w + x1);
+	for (int c = 0; c != 4; ++c) {
+		float top = t00[c] * (1.0f - wx) + t10[c] * wx;
+		float bottom = t01[c] * (1.0f - wx) + t11[c] * wx;
+		out_rgba[c] = top * (1.0f - wy) + bottom * wy;
+	}
 }
 
 static shading_data_t get_shading_data(const oracle_frame_t* f, const frame_constants_t* k, uint32_t primitive, v3 ray_direction) {
@@ -1013,8 +1038,38 @@ static int polygon_visibility(pixel_ctx_t* ctx, int visibility, v3 dir, v3 posit
 	return !oracle_bvh_any_hit(ctx->f->bvh, o, d, 1.0e-3f, max_t, ctx->f->brute_force_rays);
 }
 
-/* get_polygon_radiance, :151-185 with polygon_texturing_none (textures are out of scope) */
-static v3 polygon_radiance(const light_view_t* light) { return light->surface_radiance; }
+/* get_polygon_radiance, :151-185 */
+static v3 polygon_radiance(const oracle_frame_t* f, v3 dir, v3 position, const light_view_t* light) {
+	v3 radiance = light->surface_radiance;
+	uint32_t technique = light->texturing_technique;
+	if (technique != 0) {
+		float uv[2];
+		if (technique == 1) {
+			/* polygon_texturing_area: plane-space coordinates of the hit point */
+			float t = -dot4_point(position, light->plane) / dot3(dir, plane_normal(light->plane));
+			v3 x = sub3(add3(position, scale3(dir, t)), light->translation);
+			uv[0] = dot3(light->rotation_columns[0], x) * light->inv_scaling_x;
+			uv[1] = dot3(light->rotation_columns[1], x) * light->inv_scaling_y;
+		}
+		else {
+			v3 lookup;
+			if (technique == 3) {
+				/* polygon_texturing_ies_profile: plane space; the profile holds the cosine already */
+				lookup = mk3(dot3(light->rotation_columns[0], dir), dot3(light->rotation_columns[1], dir), dot3(light->rotation_columns[2], dir));
+				radiance = scale3(radiance, 1.0f / fabsf(lookup.z));
+			}
+			else
+				lookup = mk3(-dir.x, dir.y, dir.z);
+			uv[0] = o_atan2(lookup.y, lookup.x) * (0.5f * O_INV_PI);
+			uv[1] = o_acos(lookup.z) * O_INV_PI;
+		}
+		float texel[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+		if (f->light_textures && light->texture_index < f->light_texture_count)
+			oracle_sample_light_texture(&f->light_textures[light->texture_index], uv, texel);
+		radiance = mul3(radiance, mk3(texel[0], texel[1], texel[2]));
+	}
+	return radiance;
+}
 
 /* get_polygon_radiance_visibility_brdf_product, :203-231 */
 static v3 radiance_visibility_brdf(pixel_ctx_t* ctx, float* out_lambert, int* out_visibility, v3 dir, const shading_data_t* sd, const light_view_t* light, int diffuse, int specular) {
@@ -1023,7 +1078,7 @@ static v3 radiance_visibility_brdf(pixel_ctx_t* ctx, float* out_lambert, int* ou
 	visibility = polygon_visibility(ctx, visibility, dir, sd->position, light);
 	if (out_lambert) *out_lambert = lambert;
 	if (out_visibility) *out_visibility = visibility;
-	if (visibility) return mul3(polygon_radiance(light), evaluate_brdf(sd, dir, diffuse, specular));
+	if (visibility) return mul3(polygon_radiance(ctx->f, dir, sd->position, light), evaluate_brdf(sd, dir, diffuse, specular));
 	return mk3(0.0f, 0.0f, 0.0f);
 }
 
@@ -2024,11 +2079,12 @@ static void shade_pixel(pixel_ctx_t* ctx, uint32_t px, uint32_t py, float out[4]
 		end_w = 1.0f;
 	}
 	if (f->show_polygonal_lights) {
-		/* :841-850; get_polygon_radiance without textures is just the surface radiance */
+		/* :841-850 */
+		v3 view_dir = normalize3(ray);
 		for (uint32_t i = 0; i != f->light_count; ++i) {
 			light_view_t light = read_light(f->constants, i, f->max_light_vertex_count);
 			if (light_ray_intersection(&light, f->max_light_vertex_count, k->camera_position, end_xyz, end_w))
-				color = add3(color, polygon_radiance(&light));
+				color = add3(color, polygon_radiance(f, view_dir, k->camera_position, &light));
 		}
 	}
 	if (primitive != 0xFFFFFFFFu) {

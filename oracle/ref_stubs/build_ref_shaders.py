@@ -90,7 +90,7 @@ def variant_defines(v):
     vmax, vmin = v["max_light_vertices"], v.get("min_light_vertices", v["max_light_vertices"])
     d = {
         "MATERIAL_COUNT": v.get("materials", 3), "POLYGONAL_LIGHT_COUNT": v["lights"], "POLYGONAL_LIGHT_ARRAY_SIZE": max(v["lights"], 1),
-        "POLYGONAL_LIGHT_COUNT_CLAMPED": min(v["lights"], 33), "LIGHT_TEXTURE_COUNT": 1,
+        "POLYGONAL_LIGHT_COUNT_CLAMPED": min(v["lights"], 33), "LIGHT_TEXTURE_COUNT": 4,
         "MIN_POLYGON_VERTEX_COUNT_BEFORE_CLIPPING": vmin, "MAX_POLYGONAL_LIGHT_VERTEX_COUNT": vmax,
         "MAX_POLYGON_VERTEX_COUNT": vmax + (1 if clipped else 0),
         "SAMPLE_COUNT": v["samples"], "SAMPLE_COUNT_CLAMPED": min(v["samples"], 33),
@@ -138,6 +138,8 @@ VARIANTS = [
     dict(strategy=4, lights=3, min_light_vertices=3, max_light_vertices=6, samples=2),
     # 7-gon (largest polygon the generated clipper covers), lights visible
     dict(strategy=3, heuristic=3, lights=1, max_light_vertices=7, samples=1, show_lights=True),
+    # textured lights with the light display: every texturing technique of get_polygon_radiance
+    dict(strategy=3, heuristic=3, lights=3, min_light_vertices=3, max_light_vertices=6, samples=1, show_lights=True),
     # other techniques
     dict(strategy=0, technique="projected_solid_angle_biased", lights=1, max_light_vertices=4, samples=1),
     dict(strategy=0, technique="solid_angle", lights=1, max_light_vertices=4, samples=1),

@@ -237,7 +237,7 @@ struct texture2DArray { const uint16_t* data = nullptr; int width = 0, height = 
 struct sampler2DArray { const uint16_t* data = nullptr; int channels = 0, resolution = 0, layers = 0; };
 // a constant texel, or a view onto an oracle_texture_t that is filtered by the oracle's sampler
 // (texture filtering is the driver's in the reference; oracle.h documents the stand-in)
-struct sampler2D { vec4 constant; const void* texture = nullptr; };
+struct sampler2D { vec4 constant; const void* texture = nullptr; const void* light_texture = nullptr; };
 extern "C" void oracle_sample_texture(const void* texture, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]);
 struct usubpassInput { const uint32_t* data = nullptr; int width = 0; };
 struct accelerationStructureEXT { const void* bvh = nullptr; int brute_force = 0; };
@@ -266,7 +266,15 @@ inline vec4 textureGrad(const sampler2D& s, const vec2& uv, const vec2& dx, cons
 	oracle_sample_texture(s.texture, uv_, dx_, dy_, out);
 	return vec4(out[0], out[1], out[2], out[3]);
 }
-inline vec4 textureLod(const sampler2D& s, const vec2&, float) { return s.constant; }
+extern "C" void oracle_sample_light_texture(const void* texture, const float uv[2], float out_rgba[4]);
+// only the light textures are read with textureLod (level 0)
+inline vec4 textureLod(const sampler2D& s, const vec2& uv, float) {
+	if (!s.light_texture) return s.constant;
+	const float uv_[2] = {uv.x, uv.y};
+	float out[4];
+	oracle_sample_light_texture(s.light_texture, uv_, out);
+	return vec4(out[0], out[1], out[2], out[3]);
+}
 // VK_FILTER_LINEAR, clamp to edge, nearest array layer (round to nearest even);
 // weights in exact fp32, x filtered first (the oracle's documented choice)
 inline vec4 textureLod(const sampler2DArray& s, const vec3& coord, float) {

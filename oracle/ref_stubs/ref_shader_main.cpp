@@ -98,7 +98,10 @@ extern "C" void ref_shade_rows(const oracle_frame_t* f, float* out_rgba, uint32_
 		g_material_textures[3 * m + 2].constant = vec4(k[6], k[7], 1.0f, 1.0f);
 		for (int t = 0; t != 3; ++t) g_material_textures[3 * m + t].texture = f->material_textures ? (const void*) &f->material_textures[3 * m + t] : nullptr;
 	}
-	for (int t = 0; t != LIGHT_TEXTURE_COUNT; ++t) g_light_textures[t].constant = vec4(1.0f, 1.0f, 1.0f, 1.0f);
+	for (int t = 0; t != LIGHT_TEXTURE_COUNT; ++t) {
+		g_light_textures[t].constant = vec4(1.0f, 1.0f, 1.0f, 1.0f);
+		g_light_textures[t].light_texture = (f->light_textures && (uint32_t) t < f->light_texture_count) ? (const void*) &f->light_textures[t] : nullptr;
+	}
 	g_noise_table.data = f->noise; g_noise_table.width = (int) f->noise_width; g_noise_table.height = (int) f->noise_height; g_noise_table.depth = (int) f->noise_depth;
 	g_ltc_tables[0].data = f->ltc_rgba; g_ltc_tables[0].channels = 4;
 	g_ltc_tables[1].data = f->ltc_rg; g_ltc_tables[1].channels = 2;

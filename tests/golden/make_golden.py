@@ -55,6 +55,16 @@ def frames():
             print("%-28s %-60s mean %.5f" % (case["key"], name, image[..., :3].mean()))
             hs.close()
     np.savez_compressed(os.path.join(HERE, "textured_frames.npz"), **out)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        dataset = synthetic.write_dataset(d, **golden_cases.DATASET)
+        for case in golden_cases.LIGHT_TEXTURE_CASES:
+            hs, frame, name = golden_cases.build_frame(case, dataset)
+            image = reference.shade(name, frame)
+            out[case["key"]] = image
+            print("%-28s %-60s mean %.5f" % (case["key"], name, image[..., :3].mean()))
+            hs.close()
+    np.savez_compressed(os.path.join(HERE, "light_texture_frames.npz"), **out)
 
 
 def functions():

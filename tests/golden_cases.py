@@ -60,9 +60,30 @@ FRAME_CASES = [
 ]
 
 
+# Light textures: every texturing technique of
+# get_polygon_radiance, shading_pass.frag.glsl:151-185.  "texture" names a file of
+# synthetic.write_light_textures; the texel filter is this build's (unpinned by the reference, whose
+# driver filters), everything around it -- plane-space, probe and IES coordinates, the cosine
+# division, the light display -- goes through the reference's shader.
+def textured_light(light, technique, texture):
+    return dict(light, texturing_technique=technique, texture=texture)
+
+
+TEXTURED_MIXED = [textured_light(MIXED[0], "area", "area"), textured_light(MIXED[1], "portal", "portal"), textured_light(MIXED[2], "ies_profile", "ies")]
+LIGHT_TEXTURE_CASES = [
+    dict(key="light_textures_mis_show_lights", lights=TEXTURED_MIXED, strategy=3, heuristic=3, samples=1, show_lights=True),
+    dict(key="light_textures_mis_balance", lights=TEXTURED_MIXED, strategy=3, heuristic=0, samples=1),
+    dict(key="light_textures_ggx_rays", lights=[textured_light(PENTAGON[0], "area", "area")], strategy=1, heuristic=0, samples=1, rays=True),
+    dict(key="light_textures_probe_rgb16", strategy=0, heuristic=0, samples=1,
+         lights=[textured_light(TRIANGLE[0], "portal", "portal_rgb16")]),
+]
+
+
 def apply_case(scene, case, dataset, width=WIDTH, height=HEIGHT):
     """Loads the dataset into a HostScene / Renderer and applies the case."""
     rays = bool(case.get("rays", False))
+    if any("texture" in light for light in case["lights"]):
+        case = dict(case, lights=[dict(light, texture_file_path=dataset["light_textures"][light["texture"]]) if "texture" in light else light for light in case["lights"]])
     scene.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=True if scene._device else False)
     scene.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
     scene.load_noise_table("white")

@@ -192,3 +192,150 @@ def test_textured_frame_on_the_gpu_equals_the_oracle(case, textured_dataset):
     r.close()
     stats = compare(image, cpu)
     assert stats["bit_exact"], stats
+
+
+# ---- light textures (reference get_polygon_radiance, shading_pass.frag.glsl:151-185) -----------
+
+@pytest.fixture(scope="module")
+def plain_dataset(tmp_path_factory):
+    return synthetic.write_dataset(str(tmp_path_factory.mktemp("lights")), **golden_cases.DATASET)
+
+
+def test_light_texture_loader_formats_sharing_and_fallback(plain_dataset, capfd):
+    paths = plain_dataset["light_textures"]
+    hs = renderer.HostScene()
+    lights = [dict(golden_cases.MIXED[0], texturing_technique="portal", texture_file_path=paths["portal"]),
+              dict(golden_cases.MIXED[1]),  # no texture: white
+              dict(golden_cases.MIXED[2], texturing_technique="ies_profile", texture_file_path=paths["ies"]),
+              dict(golden_cases.MIXED[0], texturing_technique="portal", texture_file_path=paths["portal"]),  # shared
+              dict(golden_cases.MIXED[1], texturing_technique="area", texture_file_path=paths["area"]),
+              dict(golden_cases.MIXED[2], texturing_technique="portal", texture_file_path=paths["portal_rgb16"]),
+              dict(golden_cases.MIXED[2], texturing_technique="area", texture_file_path=os.path.join(os.path.dirname(paths["area"]), "absent.vkt"))]
+    hs.set_lights(lights)
+    spec, textures = hs.app.scene_specification, hs.app.light_textures
+    assert [spec.polygonal_lights[i].texture_index for i in range(7)] == [0, 1, 2, 0, 3, 4, 1]
+    C.CDLL(None).fflush(None)
+    assert "absent.vkt does not exist. Using a white texture instead." in capfd.readouterr().out
+    assert textures.texture_count == 5
+    descriptors = np.array([textures.host_descriptors[i][:] for i in range(5)])
+    assert descriptors[:, 1].tolist() == [64, 0, 48, 32, 40] and descriptors[:, 2].tolist() == [32, 0, 1, 32, 20]
+    loaded = hs.light_texture_arrays()
+    assert loaded[1] is None
+    # half floats: the image rounded to fp16; alpha 1
+    probe = synthetic.light_texture_image("portal", 64, 32)
+    assert np.array_equal(loaded[0][..., :3], probe.astype(np.float16).astype(np.float32)) and np.all(loaded[0][..., 3] == 1.0)
+    assert np.array_equal(loaded[4][..., :3], synthetic.light_texture_image("portal", 40, 20, seed=5).astype(np.float16).astype(np.float32))
+    assert np.array_equal(loaded[2][..., :3], synthetic.light_texture_image("ies", 48, 1).astype(np.float32))
+    # BC1 sRGB: block decode as in the material path, then the sRGB table
+    vk_format, mips = read_vkt(paths["area"])
+    texels = decode_reference(vk_format, *mips[0])
+    oracle.lib().oracle_srgb_table.restype = C.c_void_p
+    table = np.ctypeslib.as_array(C.cast(oracle.lib().oracle_srgb_table(), C.POINTER(C.c_float)), (256,))
+    assert np.array_equal(loaded[3][..., :3], table[texels[..., :3]])
+    # the constants carry technique and index (polygonal_light_utility.glsl:26-83, offsets 84 / 88)
+    constants = hs.constants()
+    stride = 160 + 16 * 6 * 2 + 16 * 4
+    words = constants[256:256 + 7 * stride].reshape(7, stride)[:, 84:92].copy().view(np.uint32)
+    assert words[:, 0].tolist() == [2, 0, 3, 2, 1, 2, 1] and words[:, 1].tolist() == [0, 1, 2, 0, 3, 4, 1]
+    # new lights replace the textures
+    hs.set_lights(golden_cases.TRIANGLE)
+    assert hs.app.light_textures.texture_count == 0
+    hs.close()
+
+
+def test_invalid_light_texture_is_refused(tmp_path, plain_dataset):
+    bad = tmp_path / "bad.vkt"
+    data = open(plain_dataset["light_textures"]["portal"], "rb").read()
+    bad.write_bytes(data[:len(data) - 40])
+    hs = renderer.HostScene()
+    with pytest.raises(RuntimeError):
+        hs.set_lights([dict(golden_cases.TRIANGLE[0], texturing_technique="portal", texture_file_path=str(bad))])
+    assert hs.app.light_textures.texture_count == 0 and not hs.app.light_textures.host_texels
+    hs.close()
+
+
+def sample_light(image, uv):
+    L = oracle.lib()
+    t = oracle.LightTexture()
+    texels = np.ascontiguousarray(image, np.float32)
+    t.texels, (t.height, t.width) = texels.ctypes.data, texels.shape[:2]
+    out = (C.c_float * 4)()
+    L.oracle_sample_light_texture(C.byref(t), (C.c_float * 2)(*uv), out)
+    return np.array(out[:], np.float32)
+
+
+def test_light_texture_sampler_addressing():
+    image = np.zeros((2, 4, 4), np.float32)
+    image[0, :, 0] = [1, 2, 3, 4]
+    image[1, :, 0] = [10, 20, 30, 40]
+    # texel centres
+    assert sample_light(image, (0.375, 0.25))[0] == 2.0 and sample_light(image, (0.625, 0.75))[0] == 30.0
+    # u repeats: across the seam texel 3 blends with texel 0, and whole turns change nothing
+    assert sample_light(image, (0.0, 0.25))[0] == 2.5 and sample_light(image, (-2.625, 0.25))[0] == 2.0
+    # v clamps to the edge
+    assert sample_light(image, (0.375, -3.0))[0] == 2.0 and sample_light(image, (0.375, 1.0))[0] == 20.0 and sample_light(image, (0.375, 7.0))[0] == 20.0
+    # bilinear in both directions
+    assert sample_light(image, (0.5, 0.5))[0] == np.float32(0.5 * (2.5 + 25.0))
+    # non-finite coordinates read the first column / row instead of trapping
+    assert np.isfinite(sample_light(image, (float("nan"), float("nan")))).all() and np.isfinite(sample_light(image, (float("inf"), float("-inf")))).all()
+    # width 0 is white
+    t = oracle.LightTexture()
+    out = (C.c_float * 4)()
+    oracle.lib().oracle_sample_light_texture(C.byref(t), (C.c_float * 2)(0.3, 0.3), out)
+    assert out[:] == [1.0, 1.0, 1.0, 1.0]
+
+
+@pytest.mark.parametrize("case", golden_cases.LIGHT_TEXTURE_CASES, ids=[c["key"] for c in golden_cases.LIGHT_TEXTURE_CASES])
+def test_light_textured_frame_matches_reference_shader(case, plain_dataset):
+    expected = np.load(os.path.join(GOLDEN, "light_texture_frames.npz"))[case["key"]]
+    hs, frame, name = golden_cases.build_frame(case, plain_dataset)
+    image = oracle.shade(frame)
+    assert np.array_equal(image.view(np.uint32), expected.view(np.uint32))
+    from oracle import reference
+    if reference.available():
+        assert np.array_equal(reference.shade(name, frame).view(np.uint32), expected.view(np.uint32))
+    # the texture matters: the same lights without it give another image
+    plain = dict(case, lights=[{k: v for k, v in light.items() if k not in ("texture", "texturing_technique")} for light in case["lights"]])
+    hs2, frame2, _ = golden_cases.build_frame(plain, plain_dataset)
+    assert np.abs(oracle.shade(frame2) - image).mean() > 1e-3
+    hs.close()
+    hs2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [False, True], ids=["exact", "fast"])
+@pytest.mark.parametrize("case", golden_cases.LIGHT_TEXTURE_CASES, ids=[c["key"] for c in golden_cases.LIGHT_TEXTURE_CASES])
+def test_light_textured_frame_on_the_gpu_equals_the_oracle(case, fast, plain_dataset):
+    from helpers import compare, oracle_render
+    r = renderer.Renderer(frames_in_flight=2, fast_math=fast)
+    golden_cases.apply_case(r, case, plain_dataset, 96, 64)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.render()
+    r.render()
+    image = r.read_radiance()
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=0 if fast else 1)
+    r.close()
+    stats = compare(image, cpu)
+    if fast:
+        assert stats["nan"] == 0 and stats["rmse"] < 2e-3, stats
+    else:
+        assert stats["bit_exact"], stats
+
+
+@pytest.mark.gpu
+def test_textured_light_without_created_textures_fails_loudly(plain_dataset, capfd):
+    r = renderer.Renderer()
+    golden_cases.apply_case(r, golden_cases.FRAME_CASES[0], plain_dataset, 64, 36)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.app.scene_specification.polygonal_lights[0].texturing_technique = 2
+    with pytest.raises(RuntimeError):
+        r.render()
+    C.CDLL(None).fflush(None)
+    assert "create_and_assign_light_textures" in capfd.readouterr().out
+    r.app.scene_specification.polygonal_lights[0].texturing_technique = 0
+    r.render()
+    r.close()

@@ -126,6 +126,11 @@ class TileSchedule(C.Structure):
     _fields_ = [("tile_size", C.c_uint32), ("rank", C.c_uint32), ("rank_count", C.c_uint32)]
 
 
+class LightTextures(C.Structure):
+    _fields_ = [("texture_count", C.c_uint32), ("host_descriptors", C.POINTER(C.c_uint32 * 4)), ("host_texels", C.POINTER(C.c_float)),
+                ("texel_count", C.c_uint64), ("descriptors", C.c_void_p), ("texels", C.c_void_p)]
+
+
 class ShadingPass(C.Structure):
     _fields_ = [("use_ray_tracing", C.c_uint32), ("variant", C.c_int32), ("max_polygon_vertex_count", C.c_uint32),
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t), ("constants_ring", C.c_void_p),
@@ -137,7 +142,7 @@ class Application(C.Structure):
     _fields_ = [("device", Device), ("swapchain", Swapchain), ("scene_specification", SceneSpecification),
                 ("render_settings", RenderSettings), ("scene", Scene), ("noise_table", NoiseTable),
                 ("ltc_table", LtcTable), ("render_targets", RenderTargets), ("screenshot", Screenshot),
-                ("shading_pass", ShadingPass), ("tile_schedule", TileSchedule)]
+                ("shading_pass", ShadingPass), ("tile_schedule", TileSchedule), ("light_textures", LightTextures)]
 
 
 class Experiment(C.Structure):
@@ -153,12 +158,14 @@ class ExperimentList(C.Structure):
 
 ABI_STRUCTS = [Device, PolygonalLight, Camera, LtcConstants, LtcTable, NoiseTable, Mesh, Materials,
                AccelerationStructure, Scene, SceneSpecification, RenderSettings, PerFrameConstants, Swapchain,
-               RenderTargets, Screenshot, TileSchedule, ShadingPass, Application, Experiment, ExperimentList]
+               RenderTargets, Screenshot, TileSchedule, LightTextures, ShadingPass, Application, Experiment, ExperimentList]
 
 # every symbol include/*.h declares, with (restype, argtypes)
 P = C.POINTER
 SIGNATURES = {
     "create_hip_device": (C.c_int, [P(Device), C.c_int32, C.c_void_p]),
+    "create_and_assign_light_textures": (C.c_int, [P(LightTextures), P(Device), P(SceneSpecification)]),
+    "destroy_light_textures": (None, [P(LightTextures), P(Device)]),
     "destroy_hip_device": (None, [P(Device)]),
     "wait_for_device": (C.c_int, [P(Device)]),
     "set_polygonal_light_vertex_count": (C.c_int, [P(PolygonalLight), C.c_uint32]),

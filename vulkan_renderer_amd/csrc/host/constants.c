@@ -222,6 +222,8 @@ void write_constants(void* data, application_t* app) {
 	/* packed light array (main.c:2159-2187) */
 	char* cursor = ((char*) data) + sizeof(per_frame_constants_t);
 	uint32_t vmax = get_max_polygonal_light_vertex_count(&app->scene_specification);
+	/* keeps texture_index of every light current (reference main.c:2167 does this per light) */
+	create_and_assign_light_textures(NULL, &app->device, &app->scene_specification);
 	for (uint32_t i = 0; i != app->scene_specification.polygonal_light_count; ++i) {
 		polygonal_light_t* light = &app->scene_specification.polygonal_lights[i];
 		update_polygonal_light(light);
@@ -255,7 +257,7 @@ VKR_API uint32_t get_abi_struct_sizes(uint64_t* sizes, uint32_t capacity) {
 		sizeof(device_t), sizeof(polygonal_light_t), sizeof(first_person_camera_t), sizeof(ltc_constants_t),
 		sizeof(ltc_table_t), sizeof(noise_table_t), sizeof(mesh_t), sizeof(materials_t), sizeof(acceleration_structure_t),
 		sizeof(scene_t), sizeof(scene_specification_t), sizeof(render_settings_t), sizeof(per_frame_constants_t),
-		sizeof(swapchain_t), sizeof(render_targets_t), sizeof(screenshot_t), sizeof(tile_schedule_t),
+		sizeof(swapchain_t), sizeof(render_targets_t), sizeof(screenshot_t), sizeof(tile_schedule_t), sizeof(light_textures_t),
 		sizeof(shading_pass_t), sizeof(application_t), sizeof(experiment_t), sizeof(experiment_list_t)};
 	uint32_t count = (uint32_t) VKR_COUNT_OF(all);
 	for (uint32_t i = 0; i != count && i != capacity; ++i) sizes[i] = all[i];

@@ -40,6 +40,8 @@ int vkr_load_texture_rgba8(vkr_host_texture_t* out, const char* path);
 void vkr_free_host_texture(vkr_host_texture_t* texture);
 void vkr_decode_bc1_block(const uint8_t block[8], uint8_t out_rgba[64], int has_alpha);
 void vkr_decode_bc5_block(const uint8_t block[16], uint8_t out_rgba[64]);
+/*! scene.c: the sRGB -> linear table of the texture samplers (identical to oracle_srgb_table) */
+void vkr_fill_srgb_table(float table[256]);
 
 /*! 4x4 inverse with the operation order of reference math_utilities.h:24-47 */
 void vkr_matrix_inverse(float inverse[4][4], const float matrix[4][4]);

@@ -45,6 +45,10 @@ struct shade_params {
 	const uint32_t* texture_descriptors;
 	const uint32_t* texels;
 	const float* srgb_table;
+	// light textures (include/vkr_shading_pass.h light_textures_t): (first texel, width, height, 0)
+	// per texture and RGBA fp32 texels; NULL when no light uses a texturing technique
+	const uint4* light_texture_descriptors;
+	const float4* light_texels;
 	// G-buffer in, radiance out
 	const uint32_t* visibility;
 	float4* out_radiance;
@@ -574,6 +578,65 @@ VKR_DEV bool light_ray_intersection(const light_ref& light, uint32_t vmax, f3 or
 	return result;
 }
 
+// textureLod(g_light_textures[i], uv, 0.0f) with the sampler of reference main.c:611-621 (linear,
+// u repeats, v clamps); same arithmetic as oracle_sample_light_texture
+VKR_DEV f3 sample_light_texture(const shade_params& p, uint32_t texture_index, f2 uv) {
+	uint4 d = p.light_texture_descriptors[texture_index];
+	if (d.y == 0) return mk3(1.0f, 1.0f, 1.0f);
+	float u = uv.x - floorf(uv.x), v = uv.y;
+	if (!(u >= 0.0f && u <= 1.0f)) u = 0.0f;
+	v = (v > 0.0f) ? ((v < 1.0f) ? v : 1.0f) : 0.0f;
+	int w = (int) d.y, h = (int) d.z;
+	float fx = u * (float) w - 0.5f, fy = v * (float) h - 0.5f;
+	float flx = floorf(fx), fly = floorf(fy);
+	float wx = fx - flx, wy = fy - fly;
+	int ix = (int) flx, iy = (int) fly;
+	int x0 = (ix < 0) ? w - 1 : ix, x1 = (ix + 1 >= w) ? 0 : ix + 1;
+	int y0 = (iy < 0) ? 0 : iy, y1 = (iy + 1 >= h) ? h - 1 : iy + 1;
+	const float4* texels = p.light_texels + d.x;
+	float4 t00 = texels[(size_t) y0 * w + x0], t10 = texels[(size_t) y0 * w + x1];
+	float4 t01 = texels[(size_t) y1 * w + x0], t11 = texels[(size_t) y1 * w + x1];
+	float one_minus_wx = 1.0f - wx, one_minus_wy = 1.0f - wy;
+	f3 top = mk3(t00.x * one_minus_wx + t10.x * wx, t00.y * one_minus_wx + t10.y * wx, t00.z * one_minus_wx + t10.z * wx);
+	f3 bottom = mk3(t01.x * one_minus_wx + t11.x * wx, t01.y * one_minus_wx + t11.y * wx, t01.z * one_minus_wx + t11.z * wx);
+	return mk3(top.x * one_minus_wy + bottom.x * wy, top.y * one_minus_wy + bottom.y * wy, top.z * one_minus_wy + bottom.z * wy);
+}
+
+// get_polygon_radiance, shading_pass.frag.glsl:151-185.  TEXTURED is a property of the kernel
+// variant (the host picks it when any light has a texturing technique): the extra live registers
+// would otherwise cost the untextured variants a wave of occupancy.
+template <bool TEXTURED>
+VKR_DEV f3 polygon_radiance(const shade_params& p, f3 dir, f3 position, const light_ref& light) {
+	f3 radiance = light_radiance(light);
+	if constexpr (!TEXTURED) return radiance;
+	uint32_t technique = load_u(light.base, 84);
+	if (technique != 0 && p.light_texture_descriptors) {
+		f2 uv;
+		if (technique == 1) {
+			// polygon_texturing_area: plane-space coordinates of the point that the ray hits
+			float t = divide(-plane_distance(light, position), dot(dir, plane_normal(light)));
+			f3 x = (position + dir * t) - light_translation(light);
+			uv.x = dot(light_rotation_column(light, 0), x) * load_f(light.base, 44);
+			uv.y = dot(light_rotation_column(light, 1), x) * load_f(light.base, 60);
+		}
+		else {
+			f3 lookup;
+			if (technique == 3) {
+				// polygon_texturing_ies_profile: plane space; the profile contains the cosine
+				lookup = mk3(dot(light_rotation_column(light, 0), dir), dot(light_rotation_column(light, 1), dir), dot(light_rotation_column(light, 2), dir));
+				radiance = radiance * divide(1.0f, fabsf(lookup.z));
+			}
+			else
+				// polygon_texturing_portal: light probe parametrisation
+				lookup = mk3(-dir.x, dir.y, dir.z);
+			uv.x = arctan2(lookup.y, lookup.x) * (0.5f * kInvPi);
+			uv.y = arccos(lookup.z) * kInvPi;
+		}
+		radiance = radiance * sample_light_texture(p, load_u(light.base, 88), uv);
+	}
+	return radiance;
+}
+
 struct pixel_context {
 	const shade_params& p;
 	uint32_t rays;
@@ -586,12 +649,12 @@ struct pixel_context {
 // get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231, without
 // the ray query: `candidate` is the visibility before tracing (n.l > 0), the return
 // value is radiance * BRDF under the assumption that the shadow ray reaches the light.
-template <bool DIFFUSE, bool SPECULAR>
-VKR_DEV f3 radiance_brdf(float& out_lambert, bool& out_candidate, f3 dir, const shading_data& sd, const light_ref& light) {
+template <bool DIFFUSE, bool SPECULAR, bool TEXTURED>
+VKR_DEV f3 radiance_brdf(const shade_params& p, float& out_lambert, bool& out_candidate, f3 dir, const shading_data& sd, const light_ref& light) {
 	float lambert = dot(sd.normal, dir);
 	out_lambert = lambert;
 	out_candidate = lambert > 0.0f;
-	if (out_candidate) return light_radiance(light) * evaluate_brdf<DIFFUSE, SPECULAR>(sd, dir);
+	if (out_candidate) return polygon_radiance<TEXTURED>(p, dir, sd.position, light) * evaluate_brdf<DIFFUSE, SPECULAR>(sd, dir);
 	return mk3(0.0f, 0.0f, 0.0f);
 }
 
@@ -685,11 +748,11 @@ VKR_DEV f3 mis_estimate(int heuristic, f3 integrand, f3 sw, float sd, f3 ow, flo
 }
 
 // get_polygonal_light_mis_estimate, shading_pass.frag.glsl:305-323
-template <int STRATEGY, int RAYS>
+template <int STRATEGY, int RAYS, bool TEXTURED>
 VKR_DEV void add_light_mis_estimate(pixel_context& ctx, f3& result, f3 dir, float density, const shading_data& sd, const light_ref& light) {
 	float lambert;
 	bool candidate;
-	f3 rb = radiance_brdf<true, true>(lambert, candidate, dir, sd, light);
+	f3 rb = radiance_brdf<true, true, TEXTURED>(ctx.p, lambert, candidate, dir, sd, light);
 	const f3 zero = mk3(0.0f, 0.0f, 0.0f);
 	f3 visible_term = zero, hidden_term = zero;
 	if (STRATEGY == kStrategyDiffuseOnly) {
@@ -706,7 +769,9 @@ VKR_DEV void add_light_mis_estimate(pixel_context& ctx, f3& result, f3 dir, floa
 	accumulate<RAYS>(ctx, result, candidate, visible_term, hidden_term, dir, sd, light);
 }
 
-enum { kErrorNone = 0, kErrorDiffuse = 1, kErrorSpecular = 2 };
+// kLightTextures is not an error display: it shares the template slot because the two never
+// combine usefully (an error display returns before any radiance is looked up)
+enum { kErrorNone = 0, kErrorDiffuse = 1, kErrorSpecular = 2, kLightTextures = 3 };
 
 // error_to_color, shading_pass.frag.glsl:80-114: tab20b colours (linear Rec. 709), four
 // shades per decade over five decades
@@ -743,6 +808,7 @@ VKR_DEV f3 display_sampling_error(const shade_params& p, const psa_polygon<V>& p
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
 VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_coefficients& ltc_in, const light_ref& light, noise_accessor& noise) {
 	const shade_params& p = ctx.p;
+	constexpr bool kTextured = ERROR == kLightTextures;
 	constexpr bool kBiased = TECHNIQUE == kTechniquePsaBiased;
 	constexpr bool kIsPsa = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased;
 	const uint32_t S = p.sample_count;
@@ -759,7 +825,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		for (uint32_t s = 0; s != S; ++s) {
 			f2 u = next_noise_2(p, noise);
 			f3 dir = normalize((corner_offset + r0 * u.x) + r1 * u.y);
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, 1.0f, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, 1.0f, sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueAreaTurk) {
@@ -789,7 +855,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			float distance_squared = dot(d, d);
 			f3 dir = d * rsqrt(distance_squared);
 			float projected_area = fabsf(dot(plane_normal(light), dir)) * light_area(light);
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, divide(distance_squared, projected_area), sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, divide(distance_squared, projected_area), sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueUrena) {
@@ -799,7 +865,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		density_factor = rcp(pd.solid_angle);
 		for (uint32_t s = 0; s != S; ++s) {
 			f3 dir = sample_urena(pd, next_noise_2(p, noise));
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueArvoSolidAngle) {
@@ -812,7 +878,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		density_factor = rcp(pd.solid_angle);
 		for (uint32_t s = 0; s != S; ++s) {
 			f3 dir = sample_arvo<V>(pd, next_noise_2(p, noise));
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueHartBilinear || TECHNIQUE == kTechniqueHartBilinearClipping
@@ -838,7 +904,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 				float density;
 				f3 dir = sample_hart_biquadratic<V>(density, pd, next_noise_2(p, noise));
 				dir = mul_transposed(world_to_shading, dir);
-				add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+				add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density, sd, light);
 			}
 		}
 		else {
@@ -848,7 +914,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 				float density;
 				f3 dir = sample_hart_bilinear<V>(density, pd, next_noise_2(p, noise));
 				dir = mul_transposed(world_to_shading, dir);
-				add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+				add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density, sd, light);
 			}
 		}
 	}
@@ -861,7 +927,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		density_factor = rcp(pd.solid_angle);
 		for (uint32_t s = 0; s != S; ++s) {
 			f3 dir = sample_sa<V>(pd, next_noise_2(p, noise));
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
 	else if constexpr (TECHNIQUE == kTechniqueClippedSolidAngle) {
@@ -877,7 +943,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		for (uint32_t s = 0; s != S; ++s) {
 			f3 dir = sample_sa<V>(pd, next_noise_2(p, noise));
 			dir = mul_transposed(world_to_shading, dir);
-			add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density_factor, sd, light);
+			add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density_factor, sd, light);
 		}
 	}
 	else {
@@ -917,7 +983,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					f3 dir = sample_psa_arvo<V>(pa, next_noise_2(p, noise), 3u);
 					float density = divide(dir.z, pa.total);
 					dir = mul_transposed(world_to_shading, dir);
-					add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+					add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density, sd, light);
 				}
 				density_factor = rcp(pa.total);
 			}
@@ -930,7 +996,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					f3 dir = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
 					float density = divide(dir.z, pd.total);
 					dir = mul_transposed(world_to_shading, dir);
-					add_light_mis_estimate<STRATEGY, RAYS>(ctx, result, dir, density, sd, light);
+					add_light_mis_estimate<STRATEGY, RAYS, kTextured>(ctx, result, dir, density, sd, light);
 				}
 				density_factor = rcp(pd.total);
 			}
@@ -970,14 +1036,14 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					dd = mul_transposed(world_to_shading, dd);
 					float lambert;
 					bool candidate;
-					f3 rb = radiance_brdf<true, false>(lambert, candidate, dd, sd, light);
+					f3 rb = radiance_brdf<true, false, kTextured>(p, lambert, candidate, dd, sd, light);
 					accumulate<RAYS>(ctx, result, candidate, rb * pd.total, zero * pd.total, dd, sd, light);
 					if (ps.total > 0.0f) {
 						f3 dc = sample_psa<V, kBiased>(ps, next_noise_2(p, noise));
 						f3 ds = normalize(cosine_to_shading(ltc_in, dc));
 						float ltc_density = evaluate_ltc_density(ltc_in, ds, 1.0f);
 						f3 dw = mul_transposed(world_to_shading, ds);
-						f3 rb2 = radiance_brdf<false, true>(lambert, candidate, dw, sd, light);
+						f3 rb2 = radiance_brdf<false, true, kTextured>(p, lambert, candidate, dw, sd, light);
 						if (!(ds.z <= 0.0f || dc.z <= 0.0f)) {
 							f3 t = (rb2 * ds.z) * ps.total;
 							f3 t0 = (zero * ds.z) * ps.total;
@@ -1021,7 +1087,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 						float lambert;
 						bool candidate;
 						f3 dw = mul_transposed(world_to_shading, ds);
-						f3 rb = radiance_brdf<true, true>(lambert, candidate, dw, sd, light);
+						f3 rb = radiance_brdf<true, true, kTextured>(p, lambert, candidate, dw, sd, light);
 						f3 integrand = rb * ds.z;
 						f3 dark = zero * ds.z;
 						f3 visible_term, hidden_term;
@@ -1059,7 +1125,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					float density = divide(dens_d + dens_s, diffuse_weight + specular_weight);
 					bool candidate;
 					f3 dw = mul_transposed(world_to_shading, ds);
-					f3 rb = radiance_brdf<true, true>(lambert, candidate, dw, sd, light);
+					f3 rb = radiance_brdf<true, true, kTextured>(p, lambert, candidate, dw, sd, light);
 					if (!(ds.z <= 0.0f)) {
 						f3 t = rb * ds.z;
 						f3 t0 = zero * ds.z;
@@ -1083,7 +1149,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			if (dg.z > 0.0f && light_ray_intersection(light, p.max_light_vertex_count, sd.position, dw, 0.0f)) {
 				float lambert;
 				bool candidate;
-				f3 rb = radiance_brdf<true, true>(lambert, candidate, dw, sd, light);
+				f3 rb = radiance_brdf<true, true, kTextured>(p, lambert, candidate, dw, sd, light);
 				float polygon_density = kIsPsa ? (lambert * density_factor) : density_factor;
 				float weight = mis_weight_over_density(p.mis_heuristic, ggx_density, polygon_density);
 				accumulate<RAYS>(ctx, result, candidate, (rb * lambert) * weight, (zero * lambert) * weight, dw, sd, light);
@@ -1167,10 +1233,11 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 		}
 		if (p.show_polygonal_lights) {
 			f3 camera = load_f3(c, 144);
+			f3 view_dir = normalize(ray);
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
 				if (light_ray_intersection(light, p.max_light_vertex_count, camera, end_xyz, end_w))
-					color = color + light_radiance(light);
+					color = color + polygon_radiance<ERROR != kErrorNone>(p, view_dir, camera, light);
 			}
 		}
 		if (primitive != 0xFFFFFFFFu) {

@@ -12,13 +12,18 @@ using namespace vkr;
 #define VKR_DECLARE_LAUNCH(mode, s) extern "C" int vkr_launch_shade_##mode##_##s(int technique, int capacity, int rays, const shade_params* p, unsigned int grid_x, void* stream);
 VKR_DECLARE_LAUNCH(exact, 0) VKR_DECLARE_LAUNCH(exact, 1) VKR_DECLARE_LAUNCH(exact, 2) VKR_DECLARE_LAUNCH(exact, 3) VKR_DECLARE_LAUNCH(exact, 4)
 VKR_DECLARE_LAUNCH(fast, 0) VKR_DECLARE_LAUNCH(fast, 1) VKR_DECLARE_LAUNCH(fast, 2) VKR_DECLARE_LAUNCH(fast, 3) VKR_DECLARE_LAUNCH(fast, 4)
+VKR_DECLARE_LAUNCH(textured_exact, 0) VKR_DECLARE_LAUNCH(textured_exact, 1) VKR_DECLARE_LAUNCH(textured_exact, 2) VKR_DECLARE_LAUNCH(textured_exact, 3) VKR_DECLARE_LAUNCH(textured_exact, 4)
+VKR_DECLARE_LAUNCH(textured_fast, 0) VKR_DECLARE_LAUNCH(textured_fast, 1) VKR_DECLARE_LAUNCH(textured_fast, 2) VKR_DECLARE_LAUNCH(textured_fast, 3) VKR_DECLARE_LAUNCH(textured_fast, 4)
 
 extern "C" int vkr_launch_error_display_exact(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
 extern "C" int vkr_launch_error_display_fast(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
 typedef int (*launch_function_t)(int, int, int, const shade_params*, unsigned int, void*);
-static const launch_function_t g_launchers[2][5] = {
+// [arithmetic mode + 2 * light textures][strategy]
+static const launch_function_t g_launchers[4][5] = {
 	{vkr_launch_shade_exact_0, vkr_launch_shade_exact_1, vkr_launch_shade_exact_2, vkr_launch_shade_exact_3, vkr_launch_shade_exact_4},
 	{vkr_launch_shade_fast_0, vkr_launch_shade_fast_1, vkr_launch_shade_fast_2, vkr_launch_shade_fast_3, vkr_launch_shade_fast_4},
+	{vkr_launch_shade_textured_exact_0, vkr_launch_shade_textured_exact_1, vkr_launch_shade_textured_exact_2, vkr_launch_shade_textured_exact_3, vkr_launch_shade_textured_exact_4},
+	{vkr_launch_shade_textured_fast_0, vkr_launch_shade_textured_fast_1, vkr_launch_shade_textured_fast_2, vkr_launch_shade_textured_fast_3, vkr_launch_shade_textured_fast_4},
 };
 
 static int hip_failed(hipError_t error, const char* what) {
@@ -378,8 +383,8 @@ static int validate_settings(const application_t* app) {
 			printf("Polygonal light %u has %u vertices; the clipping and sorting code covers 3 to 7.\n", i, light->vertex_count);
 			return 1;
 		}
-		if (light->texturing_technique != polygon_texturing_none) {
-			printf("Polygonal light %u uses a texture; light textures are not part of the shading pass.\n", i);
+		if (light->texturing_technique < 0 || light->texturing_technique >= polygon_texturing_count) {
+			printf("Polygonal light %u has the invalid texturing technique %d.\n", i, (int) light->texturing_technique);
 			return 1;
 		}
 	}
@@ -609,6 +614,17 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		p.texels = (const uint32_t*) app->scene.materials.texels;
 		p.srgb_table = (const float*) app->scene.materials.srgb_table;
 	}
+	// light textures: bound whenever a light asks for one (the technique lives in the constants)
+	for (uint32_t i = 0; i != app->scene_specification.polygonal_light_count; ++i) {
+		const polygonal_light_t* light = &app->scene_specification.polygonal_lights[i];
+		if (light->texturing_technique == polygon_texturing_none) continue;
+		if (!app->light_textures.descriptors || light->texture_index >= app->light_textures.texture_count) {
+			printf("Polygonal light %u uses a texture but the light textures have not been created for the current lights. Call create_and_assign_light_textures() first.\n", i);
+			return 1;
+		}
+		p.light_texture_descriptors = (const uint4*) app->light_textures.descriptors;
+		p.light_texels = (const float4*) app->light_textures.texels;
+	}
 	if (pass->use_ray_tracing && pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 	if (upload_constants(app, stream)) return 1;
 	p.constants = (const uint8_t*) pass->constants_device;
@@ -630,7 +646,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	if (timed) (void) hipEventRecord(ring[3 * slot], stream);
 	int status = error_mode != kErrorNone
 		? (pass->fast_math ? vkr_launch_error_display_fast : vkr_launch_error_display_exact)(strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
-		: g_launchers[pass->fast_math ? 1 : 0][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
+		: g_launchers[(pass->fast_math ? 1 : 0) + (p.light_texture_descriptors ? 2 : 0)][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
 	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
 	if (status == 0 && ray_mode == kRaysDeferred) {
 		// enough resident waves to fill the chip; each lane strides over the queue

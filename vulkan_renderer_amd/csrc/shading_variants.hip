@@ -8,21 +8,37 @@
 #error "define VKR_STRATEGY (0..4)"
 #endif
 
+// VKR_LIGHT_TEXTURES=1 builds the same matrix once more with light textures compiled in
+// (get_polygon_radiance of the reference with a texturing technique, shading_pass.frag.glsl:151-185)
+#ifndef VKR_LIGHT_TEXTURES
+#define VKR_LIGHT_TEXTURES 0
+#endif
+
 #define VKR_CAT2(a, b, c, d) a##b##c##d
 #define VKR_CAT(a, b, c, d) VKR_CAT2(a, b, c, d)
+#if VKR_LIGHT_TEXTURES
+#define VKR_MODE kLightTextures
+#if VKR_FAST_MATH
+#define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_fast_, VKR_STRATEGY, , )
+#else
+#define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_exact_, VKR_STRATEGY, , )
+#endif
+#else
+#define VKR_MODE kErrorNone
 #if VKR_FAST_MATH
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_fast_, VKR_STRATEGY, , )
 #else
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_exact_, VKR_STRATEGY, , )
+#endif
 #endif
 
 using namespace vkr;
 
 template <int TECHNIQUE, int V>
 static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
-	if (rays == kRaysDeferred) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferred><<<grid, 256, 0, stream>>>(p);
-	else if (rays == kRaysInline) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysInline><<<grid, 256, 0, stream>>>(p);
-	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysNone><<<grid, 256, 0, stream>>>(p);
+	if (rays == kRaysDeferred) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferred, VKR_MODE><<<grid, 256, 0, stream>>>(p);
+	else if (rays == kRaysInline) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysInline, VKR_MODE><<<grid, 256, 0, stream>>>(p);
+	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysNone, VKR_MODE><<<grid, 256, 0, stream>>>(p);
 	return hipGetLastError() != hipSuccess;
 }
 

@@ -82,10 +82,28 @@ class HostScene:
             for j in range(len(v)):
                 light.vertices_plane_space[4 * j + 0] = float(v[j, 0])
                 light.vertices_plane_space[4 * j + 1] = float(v[j, 1])
+            light.texturing_technique = {"none": 0, "area": 1, "portal": 2, "ies_profile": 3}.get(l.get("texturing_technique", 0), l.get("texturing_technique", 0))
+            if l.get("texture_file_path"):
+                # the library frees the path with free(): hand it a malloc'ed copy
+                encoded = l["texture_file_path"].encode() + b"\0"
+                libc = C.CDLL(None)
+                libc.malloc.restype = C.c_void_p
+                copy = libc.malloc(len(encoded))
+                C.memmove(copy, encoded, len(encoded))
+                light.texture_file_path = copy
             self.lib.update_polygonal_light(C.byref(light))
         self._lights_keepalive = array
         spec.polygonal_lights = C.cast(array, C.POINTER(capi.PolygonalLight))
         spec.polygonal_light_count = len(lights)
+        # like the reference's update rules (main.c:1831, 1854, 1879): new lights, new light textures
+        if self.app.light_textures.texture_count:
+            self.lib.destroy_light_textures(C.byref(self.app.light_textures), self._dev())
+        if any(l.get("texturing_technique") for l in lights):
+            self.create_light_textures()
+
+    def create_light_textures(self):
+        if self.lib.create_and_assign_light_textures(C.byref(self.app.light_textures), self._dev(), C.byref(self.app.scene_specification)):
+            raise RuntimeError("create_and_assign_light_textures failed")
 
     def set_settings(self, **kw):
         s = self.app.render_settings
@@ -158,9 +176,20 @@ class HostScene:
                 textures.append({"texels": texels[int(first):int(first) + count] if width else np.zeros((1, 4), np.uint8),
                                  "width": int(width), "height": int(height), "mip_count": int(packed) & 0xFFFF, "srgb": int(packed) >> 16})
             inputs["material_textures"] = textures
+        if app.light_textures.texture_count:
+            inputs["light_textures"] = self.light_texture_arrays()
         if visibility is not None:
             inputs["visibility"] = np.ascontiguousarray(visibility, np.uint32)
         return inputs
+
+    def light_texture_arrays(self):
+        """The loaded light textures as float32 arrays (height, width, 4); None for white."""
+        lights = self.app.light_textures
+        textures = []
+        for i in range(lights.texture_count):
+            first, width, height, _ = (int(v) for v in lights.host_descriptors[i])
+            textures.append(np.ctypeslib.as_array(lights.host_texels, (lights.texel_count * 4,))[4 * first:4 * (first + width * height)].reshape(height, width, 4).copy() if width else None)
+        return textures
 
     def oracle_settings(self):
         s = self.app.render_settings
@@ -176,6 +205,7 @@ class HostScene:
             self.lib.destroy_shading_pass(C.byref(app.shading_pass), dev)
         if app.render_targets.radiance:
             self.lib.destroy_render_targets(C.byref(app.render_targets), dev)
+        self.lib.destroy_light_textures(C.byref(app.light_textures), dev)
         self.lib.destroy_scene(C.byref(app.scene), dev)
         self.lib.destroy_ltc_table(C.byref(app.ltc_table), dev)
         self.lib.destroy_noise_table(C.byref(app.noise_table), dev)

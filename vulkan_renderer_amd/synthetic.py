@@ -319,6 +319,50 @@ def write_textured_material_textures(directory, names, size=64, formats=("bc1_sr
             write_vkt(os.path.join(directory, "%s_%s.vkt" % (name, suffix)), vk_format, extents, payloads)
 
 
+# ---- light textures: half / float *.vkt as the reference's converter writes for probes and IES ----
+
+VK_FORMAT_R16G16B16_SFLOAT, VK_FORMAT_R16G16B16A16_SFLOAT = 90, 97
+VK_FORMAT_R32G32B32_SFLOAT, VK_FORMAT_R32G32B32A32_SFLOAT = 106, 109
+
+
+def light_texture_image(kind, width=64, height=32, seed=11):
+    """float64 RGB image (height, width, 3): "area" a tiled emblem, "portal" a sky-like probe with a
+    hot spot (values above 1), "ies" a one-row intensity profile."""
+    rng = np.random.default_rng(seed)
+    if kind == "ies":
+        height = 1
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    u, v = (x + 0.5) / width, (y + 0.5) / height
+    if kind == "area":
+        checker = (np.floor(u * 6) + np.floor(v * 4)) % 2
+        return np.stack([0.2 + 0.8 * checker, 0.3 + 0.7 * u, 0.4 + 0.6 * (1.0 - v)], -1) * (0.6 + 0.4 * rng.random((height, width, 1)))
+    if kind == "portal":
+        sun = 6.0 * np.exp(-((u - 0.3) ** 2 + (v - 0.35) ** 2) * 90.0)
+        sky = np.stack([0.3 + 0.2 * v, 0.4 + 0.3 * v, 0.9 - 0.4 * v], -1)
+        return sky * (0.8 + 0.2 * np.sin(14.0 * np.pi * u)[..., None]) + sun[..., None]
+    profile = (0.15 + np.cos(0.5 * np.pi * u) ** 2 * (1.0 + 0.5 * np.sin(9.0 * np.pi * u))) * 1.5
+    return np.stack([profile, profile, profile], -1)
+
+
+def write_light_texture(path, image, vk_format=VK_FORMAT_R16G16B16A16_SFLOAT, mips=2):
+    """Writes image (float, (h, w, 3)) as a half / float *.vkt with `mips` box-filtered levels."""
+    levels = [np.asarray(image, np.float64)]
+    for _ in range(mips - 1):
+        a = levels[-1]
+        if a.shape[0] > 1:
+            a = 0.5 * (a[0:2 * (a.shape[0] // 2):2] + a[1::2])
+        if a.shape[1] > 1:
+            a = 0.5 * (a[:, 0:2 * (a.shape[1] // 2):2] + a[:, 1::2])
+        levels.append(a)
+    dtype = np.float16 if vk_format in (VK_FORMAT_R16G16B16_SFLOAT, VK_FORMAT_R16G16B16A16_SFLOAT) else np.float32
+    payloads = []
+    for a in levels:
+        if vk_format in (VK_FORMAT_R16G16B16A16_SFLOAT, VK_FORMAT_R32G32B32A32_SFLOAT):
+            a = np.concatenate([a, np.ones(a.shape[:2] + (1,))], -1)
+        payloads.append(np.ascontiguousarray(a, dtype).tobytes())
+    write_vkt(path, vk_format, [(a.shape[1], a.shape[0]) for a in levels], payloads)
+
+
 # ---- LTC fit files ------------------------------------------------------------------
 
 def write_ltc_fits(directory, resolution=32, fresnel_count=51):
@@ -419,4 +463,20 @@ def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=3
     write_vks(scene_path, positions, normals, uvs, mats, names)
     ltc_dir = os.path.join(directory, "ltc")
     write_ltc_fits(ltc_dir, ltc_resolution, fresnel_count)
-    return {"scene": scene_path, "textures": os.path.join(directory, "textures"), "ltc": ltc_dir, "fresnel_count": fresnel_count}
+    return {"scene": scene_path, "textures": os.path.join(directory, "textures"), "ltc": ltc_dir, "fresnel_count": fresnel_count,
+            "light_textures": write_light_textures(os.path.join(directory, "light_textures"))}
+
+
+def write_light_textures(directory):
+    """One texture per texturing technique of the reference (polygonal_light.h:75-90), in the
+    formats its converter produces: an sRGB BC1 emblem with a mip chain, a half-float probe,
+    a one-row fp32 IES profile, and the probe once more as three-channel half floats."""
+    os.makedirs(directory, exist_ok=True)
+    paths = {name: os.path.join(directory, name + ".vkt") for name in ("area", "portal", "ies", "portal_rgb16")}
+    emblem = np.clip(np.rint(light_texture_image("area", 32, 32) * 255.0), 0, 255).astype(np.uint8)
+    chain = mip_chain(np.concatenate([emblem, np.full(emblem.shape[:2] + (1,), 255, np.uint8)], -1))
+    write_vkt(paths["area"], VK_FORMAT_BC1_RGB_SRGB, [(m.shape[1], m.shape[0]) for m in chain], [encode_bc1(m) for m in chain])
+    write_light_texture(paths["portal"], light_texture_image("portal", 64, 32), VK_FORMAT_R16G16B16A16_SFLOAT, mips=3)
+    write_light_texture(paths["ies"], light_texture_image("ies", 48, 1), VK_FORMAT_R32G32B32_SFLOAT, mips=1)
+    write_light_texture(paths["portal_rgb16"], light_texture_image("portal", 40, 20, seed=5), VK_FORMAT_R16G16B16_SFLOAT, mips=2)
+    return paths
