@@ -234,6 +234,25 @@ static inline float o_acos(float x) {
 	if (!g_oracle_math_mode) return acosf(x);
 	return (x < 0.0f) ? (O_PI - vkr_acosf_unit(-x)) : vkr_acosf_unit(x);
 }
+/* atan(n / d) + (n / d < 0 ? pi : 0), i.e. positive_atan(n / d) of polygon_sampling.glsl:104-111.
+ * Mode 0 evaluates exactly that with libm.  Mode 1 is the fused form shared with the GPU: the
+ * range reduction divides the smaller by the larger magnitude directly, ONE division instead of
+ * the quotient followed by a reciprocal; same special cases (0 / 0 = NaN, x / 0 -> pi / 2, a
+ * quotient of -0 gives +0).  arctan_ratio in csrc/device_math.h mirrors it operation by operation. */
+static inline float o_positive_atan_ratio(float n, float d) {
+	if (!g_oracle_math_mode) {
+		float tangent = n / d;
+		return atanf(tangent) + ((tangent < 0.0f) ? O_PI : 0.0f);
+	}
+	float a = fabsf(n), b = fabsf(d);
+	int big = a > b;
+	float z = (big ? b : a) / (big ? a : b);
+	float r = poly_atan_core(z);
+	r = big ? (O_HALF_PI - r) : r;
+	int differs = ((f2u(n) ^ f2u(d)) >> 31) != 0;
+	int negative = differs && (big || z > 0.0f);
+	return (differs ? -r : r) + (negative ? O_PI : 0.0f);
+}
 static inline float o_acos_unit(float x) { return g_oracle_math_mode ? vkr_acosf_unit(x) : acosf(x); }
 static inline void o_sincos(float x, float* s, float* c) {
 	if (g_oracle_math_mode) vkr_sincosf(x, s, c);

@@ -685,9 +685,16 @@ static float ell_factor_unit(v2 e, v2 d) {
 }
 
 /* get_area_between_ellipses_in_sector_from_tangents, :377-382 */
-static float area_from_tangents(float in_rs, float in_tan, float out_rs, float out_tan, int biased) {
-	float in_area = in_rs * positive_atan(in_tan, biased);
-	float r = fmaf(out_rs, positive_atan(out_tan, biased), -in_area);
+/* positive_atan(n / d); the unbiased form goes through the fused evaluation of mode 1 (oracle_math.h) */
+static float positive_atan_ratio(float n, float d, int biased) {
+	if (biased) return fast_positive_atan(n / d);
+	return o_positive_atan_ratio(n, d);
+}
+
+/* the tangents arrive as numerator / denominator pairs */
+static float area_from_tangents(float in_rs, float in_n, float in_d, float out_rs, float out_n, float out_d, int biased) {
+	float in_area = in_rs * positive_atan_ratio(in_n, in_d, biased);
+	float r = fmaf(out_rs, positive_atan_ratio(out_n, out_d, biased), -in_area);
 	return (r > 0.0f) ? (0.5f * r) : 0.0f;
 }
 
@@ -696,7 +703,7 @@ static float area_between(v2 ein, float in_rs, v2 eout, float out_rs, v2 d0, v2 
 	float det_dirs = positive_part(dot2(d1, rot90(d0)));
 	float in_dot = in_rs * dot2(d0, ell_transform(ein, d1));
 	float out_dot = out_rs * dot2(d0, ell_transform(eout, d1));
-	return area_from_tangents(in_rs, det_dirs / in_dot, out_rs, det_dirs / out_dot, biased);
+	return area_from_tangents(in_rs, det_dirs, in_dot, out_rs, det_dirs, out_dot, biased);
 }
 
 /* get_ellipse_area_in_sector, :405-412 */
@@ -704,7 +711,7 @@ static float area_in_sector(v2 e, v2 d0, v2 d1, int biased) {
 	float rs = ell_rsqrt_det(e);
 	float det_dirs = positive_part(dot2(d1, rot90(d0)));
 	float ed = rs * dot2(d0, ell_transform(e, d1));
-	float area = 0.5f * rs * positive_atan(det_dirs / ed, biased);
+	float area = 0.5f * rs * positive_atan_ratio(det_dirs, ed, biased);
 	return (rs > 0.0f) ? area : 0.0f;
 }
 
@@ -852,7 +859,7 @@ static v2 sample_between_ellipses(v2 u, float target_area, v2 ein, v2 eout, v2 d
 			cur = normalize_approx_and_flip(cur, q1);
 			v2 ind = ell_transform(ein, cur), outd = ell_transform(eout, cur);
 			float det_dirs = positive_part(dot2(cur, rot90(q0)));
-			float error = target_area - area_from_tangents(in_rs, det_dirs / (in_rs * dot2(q0, ind)), out_rs, det_dirs / (out_rs * dot2(q0, outd)), biased);
+			float error = target_area - area_from_tangents(in_rs, det_dirs, in_rs * dot2(q0, ind), out_rs, det_dirs, out_rs * dot2(q0, outd), biased);
 			v2 c = sub2(ind, outd), rc = rot90(cur);
 			v2 c2 = scale2(ind, 2.0f * error);
 			cur = solve_quadratic(c.x * rc.x - c2.x * outd.x, c.y * rc.x - c2.y * outd.x, c.x * rc.y - c2.x * outd.y, c.y * rc.y - c2.y * outd.y);

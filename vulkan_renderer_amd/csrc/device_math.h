@@ -163,6 +163,21 @@ VKR_DEV float arctan(float t) {
 	return copysignf(r, t);
 }
 
+// atan(n / d) + (n / d < 0 ? pi : 0), positive_atan(n / d) of polygon_sampling.glsl:104-111 with
+// ONE division: the range reduction divides the smaller by the larger magnitude directly
+// instead of forming the quotient and then its reciprocal.  Operation by operation the mode-1
+// o_positive_atan_ratio of oracle/oracle_math.h (which documents the special cases).
+VKR_DEV float arctan_ratio_positive(float n, float d) {
+	float a = fabsf(n), b = fabsf(d);
+	bool big = a > b;
+	float z = divide(big ? b : a, big ? a : b);
+	float r = atan_unit(z);
+	r = big ? (kHalfPi - r) : r;
+	bool differs = ((__float_as_uint(n) ^ __float_as_uint(d)) >> 31) != 0;
+	bool negative = differs && (big || z > 0.0f);
+	return (differs ? -r : r) + (negative ? kPi : 0.0f);
+}
+
 VKR_DEV float asin_tail(float z, float s) {
 	float r = 3.392100707e-02f;
 	r = fmaf(r, s, 1.700583287e-02f);
