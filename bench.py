@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2), help="2: consecutive frames overlap on the device's two frame streams (like the reference's frame queue)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame with HIP events for the kernel time (roofline)")
     ap.add_argument("--exchange", choices=("rgba8", "rgba32f"), default="rgba8", help="what the ranks all-gather: the encoded frame (default) or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
@@ -139,7 +139,7 @@ def main():
         # The frames run on the device's two frame streams, not on torch's stream.  Before a
         # frame overwrites buffer set b, those streams wait for the last reader of that set
         # (the encode kernel resp. the collective), via an event recorded on torch's stream.
-        frame_streams = [torch.cuda.ExternalStream(int(r.app.device.frame_streams[i])) for i in range(2)] if args.frames_in_flight >= 2 else []
+        frame_streams = [torch.cuda.ExternalStream(int(r.app.device.frame_streams[i])) for i in range(args.frames_in_flight)] if args.frames_in_flight >= 2 else []
         readers_done = [None, None]
 
         def finish(b):
@@ -252,7 +252,7 @@ def main():
                 "kernel_ms": round(kernel_avg_ms, 4), "pass_ms": round(pass_ms, 4),
                 "achieved_over_pass": round(bytes_per_launch / (pass_ms * 1e-3) / 1e9, 3),
                 "pass_latency_ms": round(float(np.mean(launch_ms)), 4) if launch_ms else None,
-                "frames_in_flight": 2 if pipelined else 1, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "frames_in_flight": int(r.app.shading_pass.last_frame_in_flight) if pipelined else 1, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count,
                                                                    int(r.app.shading_pass.use_ray_tracing), args.mode),
                 "note": "kernel_ms = shade_pixels alone (dominant kernel), pass_ms = shade + trace + resolve per frame; "

@@ -29,6 +29,9 @@ typedef struct VkExtent2D { uint32_t width, height; } VkExtent2D;
 typedef struct VkExtent3D { uint32_t width, height, depth; } VkExtent3D;
 
 /*! Replaces device_t of the reference (src/vulkan_basics.h:30-75). */
+/*! Deepest frame pipeline of a shading pass (shading_pass_t.frames_in_flight) */
+#define VKR_MAX_FRAMES_IN_FLIGHT 4
+
 typedef struct device_s {
 	/*! HIP device ordinal (LOCAL_RANK in multi-process runs) */
 	int32_t hip_device;
@@ -41,11 +44,11 @@ typedef struct device_s {
 	/*! Compute units and architecture name reported by HIP, for logs */
 	int32_t compute_unit_count;
 	char architecture[64];
-	/*! Two internal hipStream_t on which consecutive frames of a shading pass with
-		frames_in_flight = 2 run, so that the ray tracing of one frame overlaps the
-		shading of the next (the analogue of the reference's frame queue,
+	/*! Internal hipStream_t on which consecutive frames of a shading pass with
+		frames_in_flight >= 2 run in turn, so that the ray tracing of one frame overlaps the
+		shading of the next ones (the analogue of the reference's frame queue,
 		main.h:353-390).  Owned by the device. */
-	void* frame_streams[2];
+	void* frame_streams[VKR_MAX_FRAMES_IN_FLIGHT];
 } device_t;
 
 /*! Replaces create_vulkan_device (reference src/vulkan_basics.h:270): selects

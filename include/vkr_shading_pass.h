@@ -154,9 +154,10 @@ typedef struct shading_pass_s {
 		ordered resolve; default), 1 = every lane walks the BVH inside the shading
 		kernel.  Both give identical results. */
 	int32_t inline_rays;
-	/*! 0 or 1: render_shading_pass orders everything on device->stream.  2: frames with
-		wavefront shadow rays alternate between the device's two frame streams and overlap
-		(trace of frame k with shading of frame k + 1); their output is complete for work
+	/*! 0 or 1: render_shading_pass orders everything on device->stream.  n = 2 ...
+		VKR_MAX_FRAMES_IN_FLIGHT: frames with wavefront shadow rays take turns on n of the
+		device's frame streams and overlap (trace of frame k with shading of frames
+		k + 1 ...); they still complete in order; their output is complete for work
 		on device->stream only after finish_frames() or one of the entry points that read
 		or post-process the targets (read_back_*, encode_*, assemble_*, take_screenshot,
 		render_visibility_pass, wait_for_device).  Set before create_shading_pass. */
@@ -165,8 +166,9 @@ typedef struct shading_pass_s {
 		(render_visibility_pass, upload_visibility) and by mark_inputs_changed(): the
 		next frame in flight waits for device->stream once */
 	uint32_t inputs_changed;
-	/*! 1 if the last render_shading_pass ran on a frame stream (it falls back to
-		device->stream without wavefront rays or when two sets of buffers would not fit) */
+	/*! pipeline depth (>= 2) if the last render_shading_pass ran on a frame stream, else 0 (it
+		falls back to device->stream without wavefront rays, for textured scenes, and uses
+		fewer frames when the sets of buffers would not fit) */
 	uint32_t last_frame_in_flight;
 	/*! per frame in flight: buffers of the wavefront ray path (ray queues, term
 		streams, base colour), completion events */
@@ -267,7 +269,7 @@ VKR_API int render_visibility_pass(application_t* app);
 	rank_count == 1, slab layout otherwise). */
 VKR_API int render_shading_pass(application_t* app, void* out_radiance);
 /*! Makes device->stream wait (on the device, the host does not block) for the frames
-	that are still in flight; a no-op without frames_in_flight = 2 */
+	that are still in flight; a no-op without frames_in_flight >= 2 */
 VKR_API int finish_frames(application_t* app);
 /*! Tell a pass with frames in flight that work queued on device->stream by someone else
 	(not through this library) has changed its inputs - visibility buffer, mesh, tables */

@@ -188,7 +188,7 @@ def test_missing_variant_and_bad_settings_fail_loudly(golden_dataset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("frames_in_flight", [1, 2])
+@pytest.mark.parametrize("frames_in_flight", [1, 2, 3, 4])
 def test_frames_in_flight_keep_their_own_constants(golden_dataset, frames_in_flight):
     """The host records frames without waiting for the device; every frame must see the
     constants that write_constants produced for it (ring of constant buffers), and a

@@ -14,7 +14,7 @@ c_float_p = C.POINTER(C.c_float)
 
 class Device(C.Structure):
     _fields_ = [("hip_device", C.c_int32), ("stream", C.c_void_p), ("ray_tracing_supported", C.c_uint32),
-                ("compute_unit_count", C.c_int32), ("architecture", C.c_char * 64), ("frame_streams", C.c_void_p * 2)]
+                ("compute_unit_count", C.c_int32), ("architecture", C.c_char * 64), ("frame_streams", C.c_void_p * 4)]
 
 
 class PolygonalLight(C.Structure):

@@ -30,7 +30,7 @@ int create_hip_device(device_t* device, int32_t hip_device, void* existing_strea
 	strncpy(device->architecture, properties.gcnArchName, sizeof(device->architecture) - 1);
 	if (strncmp(device->architecture, "gfx950", 6) != 0)
 		printf("Warning: the kernels are built for gfx950 but device %d is %s.\n", hip_device, device->architecture);
-	for (int i = 0; i != 2; ++i) {
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i) {
 		hipStream_t stream = NULL;
 		if (check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "creating a frame stream")) {
 			destroy_hip_device(device);
@@ -42,7 +42,7 @@ int create_hip_device(device_t* device, int32_t hip_device, void* existing_strea
 }
 
 void destroy_hip_device(device_t* device) {
-	for (int i = 0; i != 2; ++i)
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i)
 		if (device->frame_streams[i]) {
 			(void) hipStreamSynchronize((hipStream_t) device->frame_streams[i]);
 			(void) hipStreamDestroy((hipStream_t) device->frame_streams[i]);
@@ -52,7 +52,7 @@ void destroy_hip_device(device_t* device) {
 
 int wait_for_device(const device_t* device) {
 	int failed = 0;
-	for (int i = 0; i != 2; ++i)
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i)
 		if (device->frame_streams[i]) failed |= check(hipStreamSynchronize((hipStream_t) device->frame_streams[i]), "waiting for a frame stream");
 	return failed | check(hipStreamSynchronize((hipStream_t) device->stream), "waiting for the stream");
 }

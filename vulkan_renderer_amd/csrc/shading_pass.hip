@@ -122,19 +122,20 @@ static void free_wavefront_buffers(wavefront_buffers* w) {
 	memset(w, 0, sizeof(*w));
 }
 
-// What a frame in flight owns.  With frames_in_flight = 2 consecutive frames alternate
-// between the two contexts (and the device's two frame streams); otherwise only context 0
-// is used, on device->stream.
+// What a frame in flight owns.  With frames_in_flight = n >= 2 consecutive frames take turns
+// on n contexts (and n of the device's frame streams); otherwise only context 0 is used, on
+// device->stream.
 struct frame_context {
 	wavefront_buffers buffers;
 	hipEvent_t done;  // recorded behind the last kernel of the frame
 	bool pending;     // device->stream has not been made to wait for `done` yet
 };
 struct frame_pipeline {
-	frame_context contexts[2];
+	frame_context contexts[VKR_MAX_FRAMES_IN_FLIGHT];
 	hipEvent_t inputs_ready;  // marks what device->stream had submitted when a frame started
-	uint32_t next;            // frames started in pipelined mode
+	uint32_t next;            // context of the next pipelined frame
 	uint32_t last;            // context of the most recent frame
+	uint32_t depth;           // frames in flight of the most recent pipelined frame
 };
 
 static void destroy_wavefront(shading_pass_t* pass) {
@@ -155,7 +156,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames = (frame_pipeline*) calloc(1, sizeof(frame_pipeline));
 	pass->wavefront = frames;
 	bool failed = !frames || hipEventCreateWithFlags(&frames->inputs_ready, hipEventDisableTiming) != hipSuccess;
-	for (int i = 0; i != 2 && !failed; ++i) failed = hipEventCreateWithFlags(&frames->contexts[i].done, hipEventDisableTiming) != hipSuccess;
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++i) failed = hipEventCreateWithFlags(&frames->contexts[i].done, hipEventDisableTiming) != hipSuccess;
 	if (failed) {
 		printf("Failed to create the events of the frame pipeline.\n");
 		destroy_wavefront(pass);
@@ -220,14 +221,15 @@ extern "C" int finish_frames(application_t* app) {
 // A frame whose constants are byte-identical to the previous frame's reuses the slot
 // that is already on the device (static camera and lights: no upload at all, like the
 // reference's host-coherent uniform buffer, which costs no GPU time either).
-constexpr uint32_t kConstantSlots = 4;
+constexpr uint32_t kConstantSlots = VKR_MAX_FRAMES_IN_FLIGHT + 2;
+constexpr int kConstantReaders = 1 + VKR_MAX_FRAMES_IN_FLIGHT;
 struct constants_ring {
 	void* host[kConstantSlots];
 	void* device[kConstantSlots];
-	// a slot may be read from device->stream and from the two frame streams
-	hipEvent_t consumed[kConstantSlots][3];
+	// a slot may be read from device->stream and from the frame streams
+	hipEvent_t consumed[kConstantSlots][kConstantReaders];
 	hipEvent_t uploaded[kConstantSlots];
-	// bit i: readers[i] (device->stream, frame stream 0, frame stream 1) is ordered behind the upload
+	// bit i: readers[i] (device->stream, then the frame streams) is ordered behind the upload
 	uint32_t ordered[kConstantSlots];
 	bool in_flight[kConstantSlots];
 	void* scratch;    // write_constants target before it is known whether anything changed
@@ -275,18 +277,19 @@ static int create_constants_ring(shading_pass_t* pass, const device_t* device) {
 static int upload_constants(application_t* app, hipStream_t stream) {
 	shading_pass_t* pass = &app->shading_pass;
 	constants_ring* ring = (constants_ring*) pass->constants_ring;
-	hipStream_t readers[3] = {(hipStream_t) app->device.stream, (hipStream_t) app->device.frame_streams[0], (hipStream_t) app->device.frame_streams[1]};
+	hipStream_t readers[kConstantReaders] = {(hipStream_t) app->device.stream};
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i) readers[1 + i] = (hipStream_t) app->device.frame_streams[i];
 	write_constants(ring->scratch, app);
 	if (!ring->valid || memcmp(ring->scratch, ring->host[ring->current], pass->constants_size) != 0) {
 		uint32_t slot = ring->valid ? (ring->current + 1) % kConstantSlots : 0;
-		// everything launched so far may read the old slot: it is free again once all three
+		// everything launched so far may read the old slot: it is free again once all
 		// streams have passed this point
 		if (ring->valid) {
-			for (int i = 0; i != 3; ++i) (void) hipEventRecord(ring->consumed[ring->current][i], readers[i]);
+			for (int i = 0; i != kConstantReaders; ++i) (void) hipEventRecord(ring->consumed[ring->current][i], readers[i]);
 			ring->in_flight[ring->current] = true;
 		}
 		if (ring->in_flight[slot])
-			for (int i = 0; i != 3; ++i)
+			for (int i = 0; i != kConstantReaders; ++i)
 				if (hip_failed(hipEventSynchronize(ring->consumed[slot][i]), "waiting for a free constant buffer")) return 1;
 		ring->in_flight[slot] = false;
 		memcpy(ring->host[slot], ring->scratch, pass->constants_size);
@@ -294,7 +297,7 @@ static int upload_constants(application_t* app, hipStream_t stream) {
 			|| hip_failed(hipEventRecord(ring->uploaded[slot], stream), "recording the upload"))
 			return 1;
 		ring->ordered[slot] = 0;
-		for (int i = 0; i != 3; ++i) if (readers[i] == stream) ring->ordered[slot] |= 1u << i;
+		for (int i = 0; i != kConstantReaders; ++i) if (readers[i] == stream) ring->ordered[slot] |= 1u << i;
 		ring->current = slot;
 		ring->valid = true;
 		pass->constants_device = ring->device[slot];
@@ -302,7 +305,7 @@ static int upload_constants(application_t* app, hipStream_t stream) {
 		return 0;
 	}
 	// unchanged constants that another stream uploaded: order this stream behind that upload
-	for (int i = 0; i != 3; ++i)
+	for (int i = 0; i != kConstantReaders; ++i)
 		if (readers[i] == stream) {
 			if (ring->ordered[ring->current] & (1u << i)) return 0;
 			ring->ordered[ring->current] |= 1u << i;
@@ -556,9 +559,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
 		p.ray_counter = (unsigned long long*) pass->ray_counter;
 	}
-	// Frames with wavefront rays may run two at a time: frame k on frame stream k mod 2 with
+	// Frames with wavefront rays may run n at a time: frame k on frame stream k mod n with
 	// its own buffers, so that the (latency-bound) tracing of one frame overlaps the
-	// (VALU-bound) shading of the next.  Everything else runs on device->stream, behind
+	// (VALU-bound) shading of the next ones.  Everything else runs on device->stream, behind
 	// any frame that is still in flight.
 	frame_context* frame = NULL;
 	bool pipelined = false;
@@ -566,12 +569,23 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		frame_pipeline* frames = ensure_frames(pass);
 		if (!frames) return 1;
 		uint32_t thread_count = grid_blocks * 256u, max_terms = 2u * p.light_count * p.sample_count;
-		// two sets of buffers must fit comfortably into the 288 GB of HBM next to everything else
+		// the sets of buffers must fit comfortably into the 288 GB of HBM next to everything else
 		// (a textured scene has one per-pixel material buffer: one frame at a time)
-		pipelined = pass->frames_in_flight >= 2 && device->frame_streams[0] && device->frame_streams[1] && !app->scene.materials.textured
-			&& 2.0 * wavefront_bytes(thread_count, max_terms, p.light_count) < 192.0e9;
+		uint32_t depth = pass->frames_in_flight < VKR_MAX_FRAMES_IN_FLIGHT ? pass->frames_in_flight : VKR_MAX_FRAMES_IN_FLIGHT;
+		while (depth >= 2 && (!device->frame_streams[depth - 1] || depth * wavefront_bytes(thread_count, max_terms, p.light_count) >= 192.0e9)) --depth;
+		pipelined = depth >= 2 && !app->scene.materials.textured;
 		if (!pipelined && finish_frames(app)) return 1;
-		uint32_t index = pipelined ? (frames->next++ & 1u) : 0u;
+		if (pipelined && frames->depth != depth) {
+			// another pipeline depth: contexts and streams pair up differently, start afresh
+			if (frames->depth && wait_for_device(device)) return 1;
+			frames->depth = depth;
+			frames->next = 0;
+		}
+		uint32_t index = 0;
+		if (pipelined) {
+			index = frames->next;
+			frames->next = (index + 1) % depth;
+		}
 		frame = &frames->contexts[index];
 		frames->last = index;
 		if (pipelined) {
@@ -580,10 +594,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 			// streams wait for them once.  Frames do not wait for anything else on
 			// device->stream - if they did, a consumer of frame k there would hold back frame k + 1.
 			if (pass->inputs_changed) {
-				if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")
-					|| hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[0], frames->inputs_ready, 0), "waiting for the inputs")
-					|| hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[1], frames->inputs_ready, 0), "waiting for the inputs"))
-					return 1;
+				if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")) return 1;
+				for (uint32_t i = 0; i != depth; ++i)
+					if (hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[i], frames->inputs_ready, 0), "waiting for the inputs")) return 1;
 				pass->inputs_changed = 0;
 			}
 		}
@@ -597,7 +610,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
 	}
 	else if (finish_frames(app)) return 1;
-	pass->last_frame_in_flight = pipelined ? 1u : 0u;
+	pass->last_frame_in_flight = pipelined ? ((frame_pipeline*) pass->wavefront)->depth : 0u;
 	// textured scene: sample the material textures of every pixel first (same stream)
 	bool textured = app->scene.materials.textured && app->scene.materials.texture_descriptors;
 	if (textured) {
@@ -655,7 +668,9 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
 		if (pipelined) {
 			// both frames in flight may write the same target: keep the frame order there
-			frame_context* previous = &((frame_pipeline*) pass->wavefront)->contexts[1u - ((frame_pipeline*) pass->wavefront)->last];
+			// (the frame before this one ran in the context before this one)
+			frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
+			frame_context* previous = &frames->contexts[(frames->last + frames->depth - 1u) % frames->depth];
 			if (previous->pending) (void) hipStreamWaitEvent(stream, previous->done, 0);
 		}
 		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
