@@ -51,8 +51,8 @@ def algorithmic_bytes_per_pixel(light_count, sample_count, techniques):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 2000 / 2000 / 500 / 100 for configs 1-4); a few hundred are needed before the clocks and the frame pipeline are in steady state (config 2: 100 frames are 14 ms)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames first (default: a tenth of the steps)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4])
     ap.add_argument("--mode", default="exact", choices=["fast", "exact"],
                     help="exact: IEEE arithmetic, bit-identical to the CPU oracle (default; it is as fast); fast: approximate reciprocals + contraction")
@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--exchange", choices=("rgba8", "rgba32f"), default="rgba8", help="what the ranks all-gather: the encoded frame (default) or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {1: 2000, 2: 2000, 3: 500, 4: 100}[args.config]
+    if args.warmup is None:
+        args.warmup = max(args.steps // 10, 1)
     if args.steps < 4 * args.timing_stride:
         args.timing_stride = 1  # short runs: time every frame
 
