@@ -60,6 +60,14 @@ def main():
             for row in stats[:8]:
                 lines.append("| `%s` | %s | %.1f | %.1f | %.1f | %s |" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3, row["Percentage"]))
             lines.append("")
+        serial = kernel_stats(os.path.join(base, "cfg%d_serial" % cfg))
+        serial_us = {}
+        if serial:
+            lines += ["The same with `--frames-in-flight 1` (every kernel alone on the GPU):", "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+            for row in serial[:3]:
+                lines.append("| `%s` | %s | %.1f | %.1f | %.1f |" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
+                serial_us[row["Name"].split("(")[0]] = float(row["AverageNs"]) / 1e3
+            lines.append("")
         merged, meta = {}, {}
         for p in (1, 2, 3, 4):
             c, m = counters(os.path.join(base, "cfg%d_pmc%d" % (cfg, p)))
@@ -81,6 +89,16 @@ def main():
                               100 * 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (simds * cycles), 100 * c.get("SQ_THREAD_CYCLES_VALU", 0) / max(64 * c.get("SQ_ACTIVE_INST_VALU", 1), 1)),
                           "- wave time: %.1f %% issuing, %.1f %% waiting on memory (s_waitcnt), %.1f %% issue stalls" % (
                               100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"])]
+            if "SQ_ACTIVE_INST_VALU" in c:
+                # a wave64 VALU instruction occupies its SIMD for one quad-cycle (4 clocks): the
+                # kernel cannot finish before all of them have issued on the 1024 SIMDs
+                floor_us = 4 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / 2400.0
+                alone = serial_us.get(kernel)
+                lines.append("- VALU issue floor at 2.4 GHz: %.3g wave instructions on 1024 SIMDs = %.1f us%s" % (
+                    c.get("SQ_INSTS_VALU", c["SQ_ACTIVE_INST_VALU"]), floor_us, (" = %.0f %% of the %.1f us the kernel takes alone (un-profiled)" % (100 * floor_us / alone, alone)) if alone else ""))
+                if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel:
+                    valu_floor = traffic.setdefault("config%d_exact_valu_floor_us" % cfg, {})
+                    valu_floor[kernel.split("::")[-1].split("<")[0]] = round(floor_us, 2)
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
                 lines += ["- HBM traffic per dispatch: FETCH_SIZE %.1f MiB (x2 correction: %.1f MiB) + WRITE_SIZE %.1f MiB = %.1f MB raw" % (
