@@ -236,12 +236,15 @@ def main():
     bytes_per_launch = shaded * algorithmic_bytes_per_pixel(light_count, sample_count, techniques) + background * 20
     achieved = bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9
     traffic = None
+    valu_floor_us = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            entry = json.load(open(pmc_path)).get("config%d_%s" % (config, args.mode))
+            table = json.load(open(pmc_path))
+            entry = table.get("config%d_%s" % (config, args.mode))
             if entry and world == 1 and width == entry.get("width") and height == entry.get("height"):
                 traffic = entry["hbm_bytes_per_launch"]
+                valu_floor_us = table.get("config%d_%s_valu_floor_us" % (config, args.mode))
         except Exception:
             traffic = None
     rays = r.last_ray_count()
@@ -261,6 +264,15 @@ def main():
                                                                    int(r.app.shading_pass.use_ray_tracing), args.mode),
                 "note": "kernel_ms = shade_pixels alone (dominant kernel), pass_ms = shade + trace + resolve per frame; "
                         "compute-bound pass: FP32 VALU issue and BVH latency limit it, not HBM (SURVEY.md 8d)"}
+
+    if valu_floor_us:
+        # the bound that actually holds: wave64 VALU instructions counted by the PMC
+        # pass in profiles/ x 4 clocks / 1024 SIMDs / 2.4 GHz, per kernel of the pass, against the
+        # live frame period
+        floor_ms = sum(valu_floor_us.values()) * 1e-3
+        roofline["valu_issue"] = {"floor_ms_per_pass": round(floor_ms, 4), "frac": round(floor_ms / pass_ms, 4),
+                                  "shade_pixels_floor_ms": round(valu_floor_us.get("shade_pixels", 0.0) * 1e-3, 4),
+                                  "source": "profiles/pmc_traffic.json (instruction counts from rocprofv3 --pmc), time live"}
 
     # ---- CPU baseline and parity on a bounded sample (rank 0, N = 1 only) ------------------------
     cpu_baseline = None

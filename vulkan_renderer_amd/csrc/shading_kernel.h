@@ -78,6 +78,9 @@ struct shade_params {
 	uint32_t* ray_queue_size;
 	uint32_t ray_queue_capacity;
 	uint32_t thread_count, max_terms, max_codes;
+	// slots a wave reserves in its queue per atomic (0: exactly as many as it needs, one atomic per
+	// push; used when a lane queues only a ray or two).  Unused slots are left as null rays.
+	uint32_t ray_block;
 	// tuning knobs (host: environment, see shading_pass.hip)
 	uint32_t refill_threshold;
 	// error display (ERROR_INDEX of the reference; the two constants of error_to_color
@@ -88,7 +91,9 @@ struct shade_params {
 
 constexpr uint32_t kRayQueueCount = 512;  // 8 XCDs x 64 (one queue per lane when scanning sizes)
 constexpr uint32_t kCursorStride = 32;    // one 128-byte line per XCD work cursor
-constexpr uint32_t kRayCounterCount = kRayQueueCount + 8 * kCursorStride;  // queue sizes, then cursors
+constexpr uint32_t kRayCounterCount = kRayQueueCount + 16 * kCursorStride;  // queue sizes, then per-XCD cursors, then per-XCD ray counts
+constexpr uint32_t kRayCountOffset = kRayQueueCount + 8 * kCursorStride;  // real rays queued from XCD x: counter kRayCountOffset + x * kCursorStride
+constexpr uint32_t kNullRay = 0xFFFFFFFFu;  // code index of a queue slot that was reserved but not used
 constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic in trace_shadow_rays
 
 // How shadow rays are traced (template parameter RAYS):
@@ -97,7 +102,9 @@ constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic 
 //   kRaysDeferred  wavefront: the shading kernel appends rays to a queue compacted
 //                  with wave ballots, a lean high-occupancy kernel traces them, a
 //                  resolve kernel replays the per-pixel sums in the original order
-enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2 };
+//   kRaysDeferredBlocks  the same with queue slots reserved a block at a time (push_ray)
+enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2, kRaysDeferredBlocks = 3 };
+constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == kRaysDeferredBlocks; }
 // codes of the per-thread term stream written in deferred mode
 enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5 };
 
@@ -660,17 +667,66 @@ VKR_DEV f3 radiance_brdf(const shade_params& p, float& out_lambert, bool& out_ca
 
 VKR_DEV bool all_zero(f3 v) { return ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z)) & 0x7FFFFFFFu) == 0; }
 
-// Appends one shadow ray to the global queue.  Lanes of the wave that arrive here
-// together reserve their slots with ONE atomic: ballot -> popcount -> lane prefix.
+// The block of queue slots that a wave has reserved and not used up yet: (first free slot,
+// slots left, real rays written so far, unused).  Wave-uniform state that lanes update while
+// the wave is diverged, hence in LDS (one entry per wave of the workgroup) and volatile.
+VKR_DEV volatile uint32_t* ray_block_state() {
+	__shared__ uint32_t state[4 * 4];
+	return state + 4 * (threadIdx.x >> 6);
+}
+
+// Appends one shadow ray to the queue of this wave.  Lanes of the wave that arrive here
+// together take their slots with one ballot -> popcount -> lane prefix.  Without BLOCKS every
+// push reserves exactly its slots with an atomic, whose round trip stalls the wave; a wave that
+// queues many rays (config 3: 14 per lane) reserves p.ray_block slots at a time and hands them
+// out from LDS, one atomic per block.  (A kernel variant, not a run-time switch: the block
+// bookkeeping costs 7 VGPRs, which is a wave of occupancy for config 2's kernel.)
+template <bool BLOCKS>
 VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 origin, f3 dir, float t_max, uint32_t code_index) {
 	uint64_t mask = __ballot(1);
 	uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-	uint32_t base = 0;
-	if (prefix == 0) base = atomicAdd(p.ray_queue_size + queue, (uint32_t) __popcll(mask));
-	base = __builtin_amdgcn_readfirstlane(base);
-	size_t slot = (size_t) queue * p.ray_queue_capacity + base + prefix;
+	uint32_t count = (uint32_t) __popcll(mask);
+	uint32_t slot_in_queue;
+	if constexpr (!BLOCKS) {
+		uint32_t base = 0;
+		if (prefix == 0) base = atomicAdd(p.ray_queue_size + queue, count);
+		slot_in_queue = __builtin_amdgcn_readfirstlane(base) + prefix;
+	}
+	else {
+		volatile uint32_t* state = ray_block_state();
+		uint32_t old_base = __builtin_amdgcn_readfirstlane(state[0]), left = __builtin_amdgcn_readfirstlane(state[1]);
+		uint32_t new_base = 0;
+		if (count > left) {
+			// the rest of the old block is used up first, then a new block is opened
+			if (prefix == 0) new_base = atomicAdd(p.ray_queue_size + queue, p.ray_block);
+			new_base = __builtin_amdgcn_readfirstlane(new_base);
+		}
+		slot_in_queue = (prefix < left) ? old_base + prefix : new_base + (prefix - left);
+		if (prefix == 0) {
+			state[0] = (count > left) ? new_base + (count - left) : old_base + count;
+			state[1] = (count > left) ? p.ray_block - (count - left) : left - count;
+			state[2] = state[2] + count;
+		}
+	}
+	size_t slot = (size_t) queue * p.ray_queue_capacity + slot_in_queue;
 	p.ray_queue[2 * slot] = make_float4(origin.x, origin.y, origin.z, t_max);
 	p.ray_queue[2 * slot + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(code_index));
+}
+
+// At the end of a shading wave: slots of its last block that no ray took become null rays (the
+// tracing kernel skips them), and the wave's ray count goes to its XCD's counter.
+VKR_DEV void close_ray_block(const shade_params& p, uint32_t queue) {
+	volatile uint32_t* state = ray_block_state();
+	uint64_t mask = __ballot(1);
+	uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+	uint32_t lanes = (uint32_t) __popcll(mask);
+	uint32_t base = __builtin_amdgcn_readfirstlane(state[0]), left = __builtin_amdgcn_readfirstlane(state[1]), rays = __builtin_amdgcn_readfirstlane(state[2]);
+	for (uint32_t i = rank; i < left; i += lanes) {
+		size_t slot = (size_t) queue * p.ray_queue_capacity + base + i;
+		p.ray_queue[2 * slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+		p.ray_queue[2 * slot + 1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNullRay));
+	}
+	if (rank == 0 && rays) atomicAdd(p.ray_queue_size + kRayCountOffset + (queue >> 6) * kCursorStride, rays);
 }
 
 // Adds one estimator term to the per-light sum.  `visible_term` is the value of the
@@ -707,7 +763,7 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 			}
 			if (needs_ray) {
 				float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
-				push_ray(p, ctx.queue, sd.position, dir, max_t, (uint32_t) code_index);
+				push_ray<RAYS == kRaysDeferredBlocks>(p, ctx.queue, sd.position, dir, max_t, (uint32_t) code_index);
 			}
 			++ctx.code_cursor;
 			++ctx.term_cursor;
@@ -1156,7 +1212,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			}
 		}
 	}
-	if constexpr (RAYS == kRaysDeferred) {
+	if constexpr (is_deferred(RAYS)) {
 		// close this light's run of terms; the resolve kernel scales by 1 / S and adds it
 		if (ctx.light_has_terms && ctx.code_cursor + 1 < p.max_codes) {
 			p.codes[(size_t) ctx.code_cursor * p.thread_count + ctx.tid] = (uint8_t) kCodeEndOfLight;
@@ -1214,6 +1270,11 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 	// of that XCD, so a queue counter's cache line is only ever touched from one L2
 	uint32_t queue = (blockIdx.x & 7u) * 64u + (((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)) & 63u);
 	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false, queue};
+	if constexpr (RAYS == kRaysDeferredBlocks) {
+		// (the waves of a workgroup never touch each other's entry: no barrier)
+		volatile uint32_t* state = ray_block_state();
+		if ((threadIdx.x & 63u) == 0) { state[0] = 0; state[1] = 0; state[2] = 0; }
+	}
 	if (inside) {
 		const uint8_t* c = p.constants;
 		uint32_t primitive = p.visibility[(size_t) py * p.width + px];
@@ -1251,7 +1312,7 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);
 			}
 		}
-		if constexpr (RAYS == kRaysDeferred) {
+		if constexpr (is_deferred(RAYS)) {
 			// hand over to trace_shadow_rays / resolve_shadow_terms: the colour so far
 			// (light display) and the terminated term stream
 			p.base_color[ctx.tid] = make_float4(color.x, color.y, color.z, 0.0f);
@@ -1260,6 +1321,7 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 		else
 			store_final_color(p, out_index, color);
 	}
+	if constexpr (RAYS == kRaysDeferredBlocks) close_ray_block(p, queue);
 	if (RAYS == kRaysInline && p.ray_counter) {
 		// one atomic per wave
 		uint32_t rays = ctx.rays;
@@ -1345,8 +1407,9 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 				node = 0;
 				active = true;
 				if (!(t_max >= 1.0e-3f)) {
-					// empty interval: nothing can block the ray (same rule as any_hit)
-					codes[code_index] = (uint8_t) kCodeVisible;
+					// empty interval: nothing can block the ray (same rule as any_hit); or a
+					// slot that the shading wave reserved and did not need
+					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
 					active = false;
 				}
 			}

@@ -165,6 +165,10 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	return frames;
 }
 
+// Slots a shading wave reserves per atomic (shade_params.ray_block): pays off when a lane
+// queues many rays; with one or two per lane the unused slots would outnumber the rays.
+static uint32_t ray_block_size(uint32_t max_terms) { return max_terms >= 8 ? 256u : 0u; }
+
 static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
 	uint32_t max_codes = max_terms + light_count + 2;
 	if (w->codes && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
@@ -177,7 +181,7 @@ static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_
 	}
 	// a queue sees every 512th wave (8 XCDs x 64 queues, waves dealt round-robin), every
 	// lane of which may emit max_terms rays
-	w->queue_capacity = ((thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * 64u * max_terms;
+	w->queue_capacity = ((thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * (64u * max_terms + ray_block_size(max_terms));
 	if (hipMalloc(&w->codes, (size_t) max_codes * thread_count) != hipSuccess
 		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
 		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
@@ -195,7 +199,7 @@ static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_
 
 // bytes that ensure_wavefront() would allocate
 static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
-	double queue_capacity = ((double) (thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * 64.0 * max_terms;
+	double queue_capacity = ((double) (thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * (64.0 * max_terms + ray_block_size(max_terms));
 	return (double) max_terms * thread_count * 24.0 + (double) (max_terms + light_count + 2) * thread_count + 16.0 * thread_count + queue_capacity * kRayQueueCount * 32.0;
 }
 
@@ -566,6 +570,11 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	frame_context* frame = NULL;
 	bool pipelined = false;
 	if (ray_mode == kRaysDeferred) {
+		uint32_t max_rays_per_lane = 2u * p.light_count * p.sample_count;
+		if ((int) app->render_settings.sampling_strategies >= (int) sampling_strategies_diffuse_specular_separately && ray_block_size(max_rays_per_lane))
+			ray_mode = kRaysDeferredBlocks;
+	}
+	if (is_deferred(ray_mode)) {
 		frame_pipeline* frames = ensure_frames(pass);
 		if (!frames) return 1;
 		uint32_t thread_count = grid_blocks * 256u, max_terms = 2u * p.light_count * p.sample_count;
@@ -606,6 +615,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
 		p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
 		p.ray_queue_capacity = w->queue_capacity;
+		p.ray_block = ray_mode == kRaysDeferredBlocks ? ray_block_size(max_terms) : 0u;
 		const char* knob = getenv("VKR_REFILL_THRESHOLD");
 		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
 	}
@@ -661,7 +671,7 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		? (pass->fast_math ? vkr_launch_error_display_fast : vkr_launch_error_display_exact)(strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
 		: g_launchers[(pass->fast_math ? 1 : 0) + (p.light_texture_descriptors ? 2 : 0)][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
 	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
-	if (status == 0 && ray_mode == kRaysDeferred) {
+	if (status == 0 && is_deferred(ray_mode)) {
 		// enough resident waves to fill the chip; each lane strides over the queue
 		// persistent: 8 waves per SIMD on every CU
 		uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
@@ -759,8 +769,8 @@ __global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, cons
 	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ((size + 63u) & ~63u); i += gridDim.x * 256u) {
 		uint32_t my_visits = 0;
-		if (i < size) {
-			const float4* r = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + i);
+		const float4* r = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + i);
+		if (i < size && __float_as_uint(r[1].w) != kNullRay) {
 			float4 a = r[0], b = r[1];
 			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
 			float t_max = a.w;
@@ -819,9 +829,14 @@ extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	if (!app->shading_pass.inline_rays) {
 		const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 		const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
-		uint32_t queued[kRayQueueCount];
-		if (!w || !w->ray_queue_size || finish_frames((application_t*) app) || vkr_copy_to_host(queued, w->ray_queue_size + kRayCounterCount, sizeof(queued), &app->device)) return 0;
-		for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += queued[q];
+		// (the queue sizes include the null rays of partly used blocks: the shading waves count)
+		// (with block-wise reservation the queue sizes include the null rays of partly used
+		// blocks; the shading waves count their rays then, otherwise those counters stay 0)
+		uint32_t counters[kRayCounterCount];
+		if (!w || !w->ray_queue_size || finish_frames((application_t*) app) || vkr_copy_to_host(counters, w->ray_queue_size + kRayCounterCount, sizeof(counters), &app->device)) return 0;
+		for (uint32_t x = 0; x != 8; ++x) rays += counters[kRayCountOffset + x * kCursorStride];
+		if (rays == 0)
+			for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += counters[q];
 		return rays;
 	}
 	if (vkr_copy_to_host(&rays, app->shading_pass.ray_counter, sizeof(rays), &app->device)) return 0;
