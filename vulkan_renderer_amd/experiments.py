@@ -79,6 +79,9 @@ def run_experiment(index, data_root, frames=32, warmup=4, synthetic_inputs=False
             os.chdir(data_root)  # noise tables are addressed relative to the working directory (noise_table.c)
             try:
                 r.load_noise_table(int(settings.noise_type))
+                # the quicksave may hold textured lights (reference update_application, main.c:1879);
+                # their paths are relative to the working directory too
+                r.create_light_textures()
             finally:
                 os.chdir(cwd)
             r.create_targets()
