@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame with HIP events for the kernel time (roofline)")
-    ap.add_argument("--exchange", choices=("rgba8", "rgba32f"), default="rgba8", help="what the ranks all-gather: the encoded frame (default) or float radiance")
+    ap.add_argument("--exchange", choices=("rgb8", "rgba8", "rgba32f"), default="rgb8", help="what the ranks all-gather: the encoded frame as packed RGB8 (default: 3 bytes per pixel, its alpha is constant), as RGBA8, or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
     if args.steps is None:
@@ -128,28 +128,36 @@ def main():
         # while frame k + 1 is shaded (two sets of buffers); a frame counts as done when it
         # has been reassembled, and the timed region ends only after the last one has.
         slab_pixels = r.slab_pixel_count(0)
-        # two of everything: frame k + 1 is shaded while frame k is encoded and exchanged
-        slab = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-        if args.exchange == "rgba8":
-            send = [torch.zeros(slab_pixels, dtype=torch.int32, device="cuda") for _ in range(2)]
-            gathered = [torch.zeros(world * slab_pixels, dtype=torch.int32, device="cuda") for _ in range(2)]
+        # one set of buffers per frame in flight (at least two): frame k + 1 is shaded while frame k
+        # is encoded and exchanged
+        sets = max(2, args.frames_in_flight)
+        slab = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
+        if args.exchange == "rgb8":
+            send = [torch.zeros(3 * slab_pixels, dtype=torch.uint8, device="cuda") for _ in range(sets)]
+            gathered = [torch.zeros(world * 3 * slab_pixels, dtype=torch.uint8, device="cuda") for _ in range(sets)]
+            frame = torch.zeros((height, width), dtype=torch.int32, device="cuda")
+        elif args.exchange == "rgba8":
+            send = [torch.zeros(slab_pixels, dtype=torch.int32, device="cuda") for _ in range(sets)]
+            gathered = [torch.zeros(world * slab_pixels, dtype=torch.int32, device="cuda") for _ in range(sets)]
             frame = torch.zeros((height, width), dtype=torch.int32, device="cuda")
         else:
-            send = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-            gathered = [torch.zeros((world * slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            send = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
+            gathered = [torch.zeros((world * slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
             frame = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
-        pending = [None, None]
+        pending = [None] * sets
         frame_counter = [0]
-        # The frames run on the device's two frame streams, not on torch's stream.  Before a
-        # frame overwrites buffer set b, those streams wait for the last reader of that set
-        # (the encode kernel resp. the collective), via an event recorded on torch's stream.
+        # The frames run on the device's frame streams, not on torch's stream.  Before a frame
+        # overwrites buffer set b, those streams wait for the last reader of that set (the encode
+        # kernel resp. the collective), via an event recorded on torch's stream.
         frame_streams = [torch.cuda.ExternalStream(int(r.app.device.frame_streams[i])) for i in range(args.frames_in_flight)] if args.frames_in_flight >= 2 else []
-        readers_done = [None, None]
+        readers_done = [None] * sets
 
         def finish(b):
             if pending[b] is not None:
                 pending[b].wait()  # the compute stream waits for the collective, not the host
-                if args.exchange == "rgba8":
+                if args.exchange == "rgb8":
+                    r.assemble_rgb8(gathered[b].data_ptr(), frame.data_ptr())
+                elif args.exchange == "rgba8":
                     r.assemble_encoded(gathered[b].data_ptr(), frame.data_ptr())
                 else:
                     r.assemble(gathered[b].data_ptr(), frame.data_ptr())
@@ -158,15 +166,18 @@ def main():
                 pending[b] = None
 
         def step():
-            b = frame_counter[0] & 1
+            b = frame_counter[0] % sets
             frame_counter[0] += 1
-            finish(b)  # frame k - 2 is complete, its buffers are free again
+            finish(b)  # frame k - sets is complete, its buffers are free again
             if readers_done[b] is not None:
                 for s in frame_streams:
                     s.wait_event(readers_done[b])
-            if args.exchange == "rgba8":
+            if args.exchange in ("rgb8", "rgba8"):
                 r.render(slab[b].data_ptr())
-                r.encode_slab(slab[b].data_ptr(), send[b].data_ptr(), slab_pixels)
+                if args.exchange == "rgb8":
+                    r.encode_slab_rgb8(slab[b].data_ptr(), send[b].data_ptr(), slab_pixels)
+                else:
+                    r.encode_slab(slab[b].data_ptr(), send[b].data_ptr(), slab_pixels)
                 readers_done[b] = torch.cuda.Event()
                 readers_done[b].record()
             else:
@@ -175,8 +186,8 @@ def main():
             pending[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
 
         def drain():
-            finish(frame_counter[0] & 1)
-            finish((frame_counter[0] + 1) & 1)
+            for i in range(sets):
+                finish((frame_counter[0] + i) % sets)
     else:
         def step():
             r.render()

@@ -268,6 +268,15 @@ VKR_API int render_visibility_pass(application_t* app);
 	`out_radiance` NULL writes app->render_targets.radiance (full frame layout when
 	rank_count == 1, slab layout otherwise). */
 VKR_API int render_shading_pass(application_t* app, void* out_radiance);
+/*! render_shading_pass() followed, on the same stream (the frame's own stream when frames are
+	in flight), by the output encoding of the frame or slab as packed RGB8 (encode_slab_rgb8): the
+	form in which ranks exchange their slabs.  Keeps the encoding out of device->stream, where
+	it would sit behind the waits for earlier frames' collectives. */
+VKR_API int render_shading_pass_encoded(application_t* app, void* out_radiance, void* out_rgb8);
+/*! The hipStream_t on which the next render_shading_pass() will run if it is a frame in flight
+	like the last one (else device->stream): for callers that chain their own work (a collective,
+	a consumer) behind one frame without involving device->stream */
+VKR_API void* get_next_frame_stream(const application_t* app);
 /*! Makes device->stream wait (on the device, the host does not block) for the frames
 	that are still in flight; a no-op without frames_in_flight >= 2 */
 VKR_API int finish_frames(application_t* app);
@@ -289,6 +298,12 @@ VKR_API int assemble_encoded_frame_from_slabs(application_t* app, const void* ga
 /*! Output encoding (as encode_output) of `pixel_count` pixels of a slab or any other
 	RGBA32F device buffer into an RGBA8 device buffer */
 VKR_API int encode_slab(application_t* app, const void* slab_radiance, void* slab_encoded, uint64_t pixel_count, VkBool32 output_linear_rgb);
+/*! The same as packed RGB8, three bytes per pixel (the alpha of the encoded output is always
+	255): the smallest lossless form of the pass's output, for the exchange between GPUs.
+	pixel_count must be a multiple of 4 (slabs are multiples of 256). */
+VKR_API int encode_slab_rgb8(application_t* app, const void* slab_radiance, void* slab_rgb8, uint64_t pixel_count, VkBool32 output_linear_rgb);
+/*! Scatters all-gathered RGB8 slabs into the RGBA8 frame (out_encoded NULL: render_targets.encoded) */
+VKR_API int assemble_rgb8_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded);
 /*! Output encoding of shading_pass.frag.glsl:871-892 into render_targets.encoded */
 VKR_API int encode_output(application_t* app, VkBool32 output_linear_rgb);
 /*! Synchronous copies to host memory (implement_screenshot, main.c:1601-1631) */

@@ -161,7 +161,24 @@ def test_tiles_of_virtual_ranks_reassemble_bit_exactly(golden_dataset):
         r.assemble_encoded(all_slabs8.ptr.value, frame8.ptr.value)
         r.sync()
         assert np.array_equal(frame8.download((120, 200, 4), np.uint8), encoded_full), (tile_size, ranks)
-        for b in (dev, all_slabs, frame, slab8, all_slabs8, frame8):
+        # and as packed RGB8 (what bench.py exchanges by default): the same bytes without the constant alpha
+        gathered3 = np.zeros((ranks, slab_pixels, 3), np.uint8)
+        slab3 = DeviceBuffer(slab_pixels * 3)
+        for rank in range(ranks):
+            r.set_tiles(tile_size, rank, ranks)
+            dev.upload(gathered[rank])
+            r.encode_slab_rgb8(dev.ptr.value, slab3.ptr.value, slab_pixels)
+            r.sync()
+            gathered3[rank] = slab3.download((slab_pixels, 3), np.uint8)
+            assert np.array_equal(gathered3[rank], gathered8[rank].view(np.uint8).reshape(-1, 4)[:, :3])
+        all_slabs3 = DeviceBuffer(gathered3.nbytes)
+        all_slabs3.upload(gathered3)
+        frame8.zero()
+        r.set_tiles(tile_size, 0, ranks)
+        r.assemble_rgb8(all_slabs3.ptr.value, frame8.ptr.value)
+        r.sync()
+        assert np.array_equal(frame8.download((120, 200, 4), np.uint8), encoded_full), (tile_size, ranks)
+        for b in (dev, all_slabs, frame, slab8, all_slabs8, frame8, slab3, all_slabs3):
             b.free()
     r.set_tiles(16, 0, 1)
     r.close()
@@ -219,5 +236,27 @@ def test_frames_in_flight_keep_their_own_constants(golden_dataset, frames_in_fli
     for e, b in zip(exposures, buffers):
         got = b.download((120, 200, 4), np.float32)
         assert np.array_equal(got.view(np.uint32), expected[e].view(np.uint32)), e
+        b.free()
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames_in_flight", [1, 2])
+def test_render_encoded_equals_render_then_encode(golden_dataset, frames_in_flight):
+    """render_shading_pass_encoded(): the frame and, on the same stream, its packed RGB8 form"""
+    case = golden_cases.FRAME_CASES[3]
+    r, full = render_case(case, golden_dataset, False, 200, 120, frames_in_flight)
+    radiance, packed, expected = DeviceBuffer(200 * 120 * 16), DeviceBuffer(200 * 120 * 3), DeviceBuffer(200 * 120 * 3)
+    next_stream = r.next_frame_stream()
+    assert (next_stream in [int(r.app.device.frame_streams[i]) for i in range(4)]) == (frames_in_flight > 1)
+    r.render_encoded(radiance.ptr.value, packed.ptr.value)
+    r.sync()
+    assert np.array_equal(radiance.download((120, 200, 4), np.float32).view(np.uint32), full.view(np.uint32))
+    r.encode_slab_rgb8(radiance.ptr.value, expected.ptr.value, 200 * 120)
+    r.sync()
+    rgb = packed.download((120, 200, 3), np.uint8)
+    assert np.array_equal(rgb, expected.download((120, 200, 3), np.uint8))
+    assert np.array_equal(rgb, r.read_encoded(False, 0)[..., :3])
+    for b in (radiance, packed, expected):
         b.free()
     r.close()

@@ -210,6 +210,10 @@ SIGNATURES = {
     "get_last_ray_count": (C.c_uint64, [P(Application)]),
     "assemble_encoded_frame_from_slabs": (C.c_int, [P(Application), C.c_void_p, C.c_void_p]),
     "encode_slab": (C.c_int, [P(Application), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "get_next_frame_stream": (C.c_void_p, [P(Application)]),
+    "render_shading_pass_encoded": (C.c_int, [P(Application), C.c_void_p, C.c_void_p]),
+    "encode_slab_rgb8": (C.c_int, [P(Application), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "assemble_rgb8_frame_from_slabs": (C.c_int, [P(Application), C.c_void_p, C.c_void_p]),
     "get_traversal_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_shading_kernel_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),

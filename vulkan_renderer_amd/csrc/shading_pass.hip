@@ -207,6 +207,14 @@ extern "C" void mark_inputs_changed(application_t* app) {
 	app->shading_pass.inputs_changed = 1;
 }
 
+// The stream the next render_shading_pass() will run on if it is pipelined the way the last
+// frame was (frame stream `next` of the pipeline), else device->stream
+extern "C" void* get_next_frame_stream(const application_t* app) {
+	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
+	if (!frames || !app->shading_pass.last_frame_in_flight || !frames->depth) return app->device.stream;
+	return app->device.frame_streams[frames->next % frames->depth];
+}
+
 extern "C" int finish_frames(application_t* app) {
 	frame_pipeline* frames = (frame_pipeline*) app->shading_pass.wavefront;
 	if (!frames) return 0;
@@ -488,7 +496,25 @@ __global__ void __launch_bounds__(256) k_resolve_materials(const shade_params p,
 	out[1] = make_float4(values[4], values[5], values[6], values[7]);
 }
 
+__global__ void k_encode_output_rgb8(const float4* radiance, uint32_t* packed, uint64_t quad_count, uint32_t frame_bits, int output_linear_rgb);
+static int ensure_srgb_code_thresholds(const device_t* device, hipStream_t stream);
+
+static int render_pass(application_t* app, void* out_radiance, void* out_rgb8);
+
 extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
+	return render_pass(app, out_radiance, NULL);
+}
+
+extern "C" int render_shading_pass_encoded(application_t* app, void* out_radiance, void* out_rgb8) {
+	if (!out_rgb8) {
+		printf("render_shading_pass_encoded() needs a target for the encoded pixels.\n");
+		return 1;
+	}
+	return render_pass(app, out_radiance, out_rgb8);
+}
+
+// out_rgb8: the frame (or slab) is also encoded as packed RGB8 on the stream it was rendered on
+static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	shading_pass_t* pass = &app->shading_pass;
 	const device_t* device = &app->device;
 	if (pass->variant < 0 || !pass->constants_device) {
@@ -685,10 +711,22 @@ extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 		}
 		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
 		status = hipGetLastError() != hipSuccess;
-		if (pipelined) {
-			(void) hipEventRecord(frame->done, stream);
-			frame->pending = true;
+	}
+	if (status == 0 && out_rgb8) {
+		// slab layout: every thread of the grid owns a slot; full-frame layout: the pixels
+		uint64_t pixels = p.rank_count > 1 ? (uint64_t) grid_blocks * 256u : (uint64_t) p.width * p.height;
+		if (pixels % 4 != 0 || ensure_srgb_code_thresholds(device, stream)) {
+			printf("The frame cannot be encoded as packed RGB8 (its pixel count has to be a multiple of four).\n");
+			status = 1;
 		}
+		else {
+			k_encode_output_rgb8<<<(uint32_t) ((pixels / 4 + 255) / 256), 256, 0, stream>>>((const float4*) p.out_radiance, (uint32_t*) out_rgb8, pixels / 4, app->screenshot.frame_bits, 0);
+			status = hipGetLastError() != hipSuccess;
+		}
+	}
+	if (status == 0 && pipelined) {
+		(void) hipEventRecord(frame->done, stream);
+		frame->pending = true;
 	}
 	if (timed) {
 		(void) hipEventRecord(ring[3 * slot + 2], stream);
@@ -882,6 +920,44 @@ extern "C" int assemble_encoded_frame_from_slabs(application_t* app, const void*
 	return assemble_slabs<uint32_t>(app, gathered_slabs, out_encoded ? out_encoded : app->render_targets.encoded);
 }
 
+// slabs of packed RGB8 (encode_slab_rgb8) -> RGBA8 frame; alpha of the encoded output is always
+// 255.  A thread moves four pixels of one tile row: twelve bytes = three aligned dwords in
+// (tile sizes are multiples of four), four pixels out.
+__global__ void __launch_bounds__(256) k_assemble_frame_rgb8(const uint32_t* slabs, uint32_t* frame, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tiles_x, uint32_t rank_count, uint64_t slab_stride) {
+	uint32_t px = 4u * (blockIdx.x * 64u + (threadIdx.x & 63u)), py = blockIdx.y * 4u + (threadIdx.x >> 6);
+	if (px >= width || py >= height) return;
+	uint32_t tx = px / tile_size, ty = py / tile_size;
+	uint32_t tile = ty * tiles_x + tx;
+	uint32_t rank = tile % rank_count, local_tile = tile / rank_count;
+	uint32_t ix = px - tx * tile_size, iy = py - ty * tile_size;
+	size_t pixel = rank * slab_stride + (size_t) local_tile * tile_size * tile_size + (size_t) iy * tile_size + ix;
+	const uint32_t* source = slabs + 3 * (pixel / 4);
+	uint32_t d0 = source[0], d1 = source[1], d2 = source[2];
+	uint32_t out[4] = {d0 | 0xFF000000u, (d0 >> 24) | (d1 << 8) | 0xFF000000u, (d1 >> 16) | (d2 << 16) | 0xFF000000u, (d2 >> 8) | 0xFF000000u};
+	uint32_t* target = frame + (size_t) py * width + px;
+	for (uint32_t i = 0; i != 4 && px + i < width; ++i) target[i] = out[i];
+}
+
+extern "C" int assemble_rgb8_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded) {
+	if (finish_frames(app)) return 1;
+	shade_params p;
+	memset(&p, 0, sizeof(p));
+	p.width = app->swapchain.extent.width;
+	p.height = app->swapchain.extent.height;
+	uint32_t grid_blocks = 0;
+	application_t first = *app;
+	first.tile_schedule.rank = 0;
+	fill_tile_schedule(p, &first, grid_blocks);
+	if (p.tile_size % 4 != 0) {
+		printf("assemble_rgb8_frame_from_slabs() needs a tile size that is a multiple of four.\n");
+		return 1;
+	}
+	dim3 grid((p.width + 255) / 256, (p.height + 3) / 4);
+	k_assemble_frame_rgb8<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const uint32_t*) gathered_slabs, (uint32_t*) (out_encoded ? out_encoded : app->render_targets.encoded),
+		p.width, p.height, p.tile_size, p.tiles_x, p.rank_count, (uint64_t) grid_blocks * 256);
+	return hip_failed(hipGetLastError(), "assembling the frame");
+}
+
 // ---- output encoding (shading_pass.frag.glsl:871-892, srgb_utility.glsl) --------------
 
 __device__ __forceinline__ float linear_to_srgb(float v) {
@@ -897,14 +973,47 @@ __device__ __forceinline__ uint32_t to_unorm8(float v) {
 	return (uint32_t) (v * 255.0f + 0.5f);
 }
 
-__global__ void __launch_bounds__(256) k_encode_output(const float4* radiance, uint32_t* encoded, uint64_t pixel_count, uint32_t frame_bits, int output_linear_rgb) {
-	uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= pixel_count) return;
-	float4 c = radiance[i];
+// to_unorm8(linear_to_srgb(v)) without the pow: the code is the number of thresholds
+// T[c] = srgb_to_linear((c - 0.5) / 255), c = 1 ... 255, that v has reached.  A hardware
+// log2 / exp2 estimate is off by less than one code; the two neighbouring thresholds settle it.
+// (Three powf per pixel made the encode kernel as expensive as tracing config 2's shadow rays.)
+__device__ float g_srgb_code_thresholds[257];
+
+__global__ void k_fill_srgb_code_thresholds() {
+	uint32_t c = threadIdx.x;
+	double x = ((double) c - 0.5) / 255.0;
+	double linear = (x <= 0.04045) ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4);
+	float t = (float) linear;
+	if ((double) t < linear) t = __uint_as_float(__float_as_uint(t) + 1u);
+	g_srgb_code_thresholds[c] = (c == 0) ? 0.0f : t;
+	if (c == 0) g_srgb_code_thresholds[256] = __builtin_inff();
+}
+
+static int ensure_srgb_code_thresholds(const device_t* device, hipStream_t stream) {
+	static bool filled[64];
+	int index = device->hip_device;
+	if (index < 0 || index >= 64) index = 63;
+	if (filled[index]) return 0;
+	k_fill_srgb_code_thresholds<<<1, 256, 0, stream>>>();
+	if (hip_failed(hipGetLastError(), "filling the sRGB thresholds")) return 1;
+	filled[index] = true;
+	return 0;
+}
+
+__device__ __forceinline__ uint32_t srgb_code(float v) {
+	v = gclamp(v, 0.0f, 1.0f);  // (NaN -> 0 like to_unorm8(linear_to_srgb(NaN)))
+	float estimate = (v <= 0.0031308f) ? (12.92f * v) : fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)), -0.055f);
+	uint32_t c = (uint32_t) fmaf(gclamp(estimate, 0.0f, 1.0f), 255.0f, 0.5f);
+	c = (v < g_srgb_code_thresholds[c]) ? c - 1u : c;
+	c = (v >= g_srgb_code_thresholds[c + 1u]) ? c + 1u : c;
+	return c;
+}
+
+__device__ __forceinline__ uint32_t encode_pixel(float4 c, uint32_t frame_bits, int output_linear_rgb) {
 	uint32_t r, g, b, a;
 	if (frame_bits == 0) {
 		// an *_SRGB target encodes in hardware, any other gets the transfer function in the shader
-		r = to_unorm8(linear_to_srgb(c.x)); g = to_unorm8(linear_to_srgb(c.y)); b = to_unorm8(linear_to_srgb(c.z));
+		r = srgb_code(c.x); g = srgb_code(c.y); b = srgb_code(c.z);
 		a = to_unorm8(c.w);
 	}
 	else {
@@ -920,13 +1029,30 @@ __global__ void __launch_bounds__(256) k_encode_output(const float4* radiance, u
 		r = out[0]; g = out[1]; b = out[2];
 		a = 255;
 	}
-	encoded[i] = r | (g << 8) | (b << 16) | (a << 24);
+	return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+__global__ void __launch_bounds__(256) k_encode_output(const float4* radiance, uint32_t* encoded, uint64_t pixel_count, uint32_t frame_bits, int output_linear_rgb) {
+	uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= pixel_count) return;
+	encoded[i] = encode_pixel(radiance[i], frame_bits, output_linear_rgb);
+}
+
+// four pixels per thread: twelve bytes of packed RGB as three dwords
+__global__ void __launch_bounds__(256) k_encode_output_rgb8(const float4* radiance, uint32_t* packed, uint64_t quad_count, uint32_t frame_bits, int output_linear_rgb) {
+	uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= quad_count) return;
+	uint32_t p0 = encode_pixel(radiance[4 * i], frame_bits, output_linear_rgb) & 0xFFFFFFu, p1 = encode_pixel(radiance[4 * i + 1], frame_bits, output_linear_rgb) & 0xFFFFFFu;
+	uint32_t p2 = encode_pixel(radiance[4 * i + 2], frame_bits, output_linear_rgb) & 0xFFFFFFu, p3 = encode_pixel(radiance[4 * i + 3], frame_bits, output_linear_rgb) & 0xFFFFFFu;
+	packed[3 * i] = p0 | (p1 << 24);
+	packed[3 * i + 1] = (p1 >> 8) | (p2 << 16);
+	packed[3 * i + 2] = (p2 >> 16) | (p3 << 8);
 }
 
 extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 	if (finish_frames(app)) return 1;
 	uint64_t pixels = (uint64_t) app->swapchain.extent.width * app->swapchain.extent.height;
-	if (!app->render_targets.radiance || !app->render_targets.encoded) return 1;
+	if (!app->render_targets.radiance || !app->render_targets.encoded || ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
 	k_encode_output<<<(uint32_t) ((pixels + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) app->render_targets.radiance, (uint32_t*) app->render_targets.encoded,
 		pixels, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
 	return hip_failed(hipGetLastError(), "encoding the output");
@@ -934,9 +1060,21 @@ extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 
 extern "C" int encode_slab(application_t* app, const void* slab_radiance, void* slab_encoded, uint64_t pixel_count, VkBool32 output_linear_rgb) {
 	if (finish_frames(app)) return 1;
-	if (!slab_radiance || !slab_encoded) return 1;
+	if (!slab_radiance || !slab_encoded || ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
 	k_encode_output<<<(uint32_t) ((pixel_count + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_encoded,
 		pixel_count, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
+	return hip_failed(hipGetLastError(), "encoding the slab");
+}
+
+extern "C" int encode_slab_rgb8(application_t* app, const void* slab_radiance, void* slab_rgb8, uint64_t pixel_count, VkBool32 output_linear_rgb) {
+	if (finish_frames(app)) return 1;
+	if (!slab_radiance || !slab_rgb8 || pixel_count % 4 != 0) {
+		printf("encode_slab_rgb8() needs buffers and a pixel count that is a multiple of four (slabs are).\n");
+		return 1;
+	}
+	if (ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
+	k_encode_output_rgb8<<<(uint32_t) ((pixel_count / 4 + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_rgb8,
+		pixel_count / 4, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
 	return hip_failed(hipGetLastError(), "encoding the slab");
 }
 

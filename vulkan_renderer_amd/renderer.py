@@ -266,6 +266,13 @@ class Renderer(HostScene):
         if self.lib.render_shading_pass(C.byref(self.app), out_pointer):
             raise RuntimeError("render_shading_pass failed")
 
+    def next_frame_stream(self):
+        return int(self.lib.get_next_frame_stream(C.byref(self.app)) or 0)
+
+    def render_encoded(self, out_pointer, rgb8_pointer):
+        if self.lib.render_shading_pass_encoded(C.byref(self.app), out_pointer, rgb8_pointer):
+            raise RuntimeError("render_shading_pass_encoded failed")
+
     def last_ms(self):
         return float(self.lib.get_last_dispatch_milliseconds(C.byref(self.app)))
 
@@ -333,6 +340,14 @@ class Renderer(HostScene):
     def encode_slab(self, slab_pointer, encoded_pointer, pixel_count, output_linear_rgb=False):
         if self.lib.encode_slab(C.byref(self.app), slab_pointer, encoded_pointer, pixel_count, int(output_linear_rgb)):
             raise RuntimeError("encode_slab failed")
+
+    def encode_slab_rgb8(self, slab_pointer, packed_pointer, pixel_count, output_linear_rgb=False):
+        if self.lib.encode_slab_rgb8(C.byref(self.app), slab_pointer, packed_pointer, pixel_count, int(output_linear_rgb)):
+            raise RuntimeError("encode_slab_rgb8 failed")
+
+    def assemble_rgb8(self, gathered_pointer, out_pointer=None):
+        if self.lib.assemble_rgb8_frame_from_slabs(C.byref(self.app), gathered_pointer, out_pointer):
+            raise RuntimeError("assemble_rgb8_frame_from_slabs failed")
 
     def assemble_encoded(self, gathered_pointer, out_pointer=None):
         if self.lib.assemble_encoded_frame_from_slabs(C.byref(self.app), gathered_pointer, out_pointer):
