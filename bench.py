@@ -4,9 +4,8 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one pass of the shading kernel over one frame: write_constants ->
-upload -> one launch over the rank's tiles (+ for N > 1 an RCCL all-gather of the
-tile slabs over xGMI and the scatter back into a frame).  Inputs (scene, LBVH,
+A step is one pass of the shading kernels over one frame: write_constants ->
+upload -> shade / trace / resolve over the rank's tiles.  Inputs (scene, LBVH,
 LTC and noise tables, visibility buffer) are resident in HBM before the timed
 region; data is synthetic (seeded generators, vulkan_renderer_amd/synthetic.py).
 
@@ -14,7 +13,11 @@ N = 1 runs BASELINE config 2 (1920x1080, 1 spp, one pentagon light, GGX MIS with
 projected-solid-angle sampling, LBVH shadow rays) unless --config says otherwise.
 For N > 1 the scaling is weak: the frame grows to 1920 x (1080 N) pixels, tiles
 are dealt round-robin to the ranks, so every GPU shades one 1080p frame worth of
-pixels per step.
+pixels per step into its slab of the frame, which stays resident in its HBM like the
+frame does at N = 1: pixels are independent, the pass has no exchange step, hence no
+data-path collective (--exchange none, the default).  --exchange rgb8 | rgba8 | rgba32f
+adds what a consumer of whole frames on every GPU would need: an RCCL all-gather of the
+(encoded) slabs per frame, overlapped with the next frame, and the scatter into a frame.
 
 PyTorch is plumbing here: device selection, the stream, torch.distributed.
 """
@@ -66,7 +69,7 @@ def main():
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame with HIP events for the kernel time (roofline)")
-    ap.add_argument("--exchange", choices=("rgb8", "rgba8", "rgba32f"), default="rgb8", help="what the ranks all-gather: the encoded frame as packed RGB8 (default: 3 bytes per pixel, its alpha is constant), as RGBA8, or float radiance")
+    ap.add_argument("--exchange", choices=("none", "rgb8", "rgba8", "rgba32f"), default="none", help="N > 1: none (default) leaves every rank's slab of the frame in its HBM; the others all-gather the slabs per frame and reassemble the frame on every rank: the encoded frame as packed RGB8 (3 bytes per pixel), as RGBA8, or float radiance")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
     args = ap.parse_args()
     if args.steps is None:
@@ -132,7 +135,9 @@ def main():
         # is encoded and exchanged
         sets = max(2, args.frames_in_flight)
         slab = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
-        if args.exchange == "rgb8":
+        if args.exchange == "none":
+            send = gathered = frame = None
+        elif args.exchange == "rgb8":
             send = [torch.zeros(3 * slab_pixels, dtype=torch.uint8, device="cuda") for _ in range(sets)]
             gathered = [torch.zeros(world * 3 * slab_pixels, dtype=torch.uint8, device="cuda") for _ in range(sets)]
             frame = torch.zeros((height, width), dtype=torch.int32, device="cuda")
@@ -166,6 +171,8 @@ def main():
                 pending[b] = None
 
         def step():
+            if args.exchange == "none":
+                return r.render(slab[0].data_ptr())
             b = frame_counter[0] % sets
             frame_counter[0] += 1
             finish(b)  # frame k - sets is complete, its buffers are free again
@@ -347,7 +354,7 @@ def main():
                                    % (config, width, height, sample_count, light_count, settings["sampling_strategies"],
                                       settings["polygon_technique"], "LBVH shadow rays" if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
                        "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
-                       "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, " + RCCL all-gather of %s slabs overlapped with the next frame" % args.exchange if distributed else ""),
+                       "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, (", every rank keeps its slab of the frame (no data-path collective)" if args.exchange == "none" else " + RCCL all-gather of %s slabs overlapped with the next frame" % args.exchange) if distributed else ""),
                        "scene_triangles": int(r.app.scene.mesh.triangle_count)},
             "host_issue_ms_per_step": round(issue_seconds / args.steps * 1e3, 4),
             "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (pass_ms * 1e-3) / 1e6, 2) if rays else 0.0,
