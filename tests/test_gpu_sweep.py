@@ -4,6 +4,7 @@ display, roughness factor, camera) is drawn from a seeded generator and the exac
 frame must equal the oracle's polynomial-mode frame bit for bit.  Plus the edge cases of
 the domain: no lights, lights below the horizon of every pixel, grazing and huge lights,
 many lights, many samples, a frame smaller than a workgroup."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -145,3 +146,44 @@ def test_many_lights_and_many_samples(dataset):
 def test_frames_smaller_than_a_workgroup(size, dataset):
     stats, image, _ = render_and_compare(dict(lights=golden_cases.QUAD, strategy=1, heuristic=0, rays=True), dataset, size[0], size[1])
     assert image.shape == (size[1], size[0], 4) and stats["bit_exact"], stats
+
+
+@pytest.fixture(scope="module")
+def textured_dataset(tmp_path_factory):
+    return synthetic.write_dataset(str(tmp_path_factory.mktemp("sweep_textured")), **golden_cases.TEXTURED_DATASET)
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_random_configuration_with_textures_is_bit_exact(seed, dataset, textured_dataset):
+    """The sweep once more with a random texturing technique per light (area, light probe, IES
+    profile or none) and, for every second seed, textured materials."""
+    rng = np.random.default_rng(seed)
+    data = textured_dataset if seed % 2 else dataset
+    case = random_case(seed)
+    names = {"area": "area", "portal": "portal", "ies_profile": "ies"}
+    for light in case["lights"]:
+        technique = ["none", "area", "portal", "ies_profile"][int(rng.integers(0, 4))]
+        if technique != "none":
+            light["texturing_technique"] = technique
+            light["texture_file_path"] = data["light_textures"][names[technique] if rng.random() < 0.8 else "portal_rgb16"]
+    stats, image, _ = render_and_compare(case, data, frames_in_flight=1 + seed % 3)
+    summary = {k: case[k] for k in ("strategy", "technique", "heuristic", "samples", "rays", "show_lights", "error_display")}
+    summary["texturing"] = [l.get("texturing_technique", "none") for l in case["lights"]]
+    assert stats["nan"] == 0 and stats["bit_exact"], (summary, stats)
+
+
+def test_block_wise_ray_queue_counts_the_rays_it_traces(dataset):
+    """Eight rays per lane and more switch the two-technique strategies to block-wise slot
+    reservation (null rays pad the blocks): the count that is reported must be the real rays,
+    i.e. what a walk over the queues finds when it skips the null rays."""
+    for samples, lights in ((2, golden_cases.QUADS), (1, golden_cases.QUADS[:1])):  # 16 rays per lane: blocks; 2: exact
+        r = renderer.Renderer()
+        golden_cases.apply_case(r, dict(lights=lights, strategy=3, heuristic=3, samples=samples, rays=True), dataset, 160, 96)
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        r.render()
+        reported = r.last_ray_count()
+        walked = r.traversal_statistics()
+        r.close()
+        assert reported > 0 and walked["rays"] == reported, (samples, reported, walked)
