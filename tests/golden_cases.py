@@ -74,6 +74,8 @@ LIGHT_TEXTURE_CASES = [
     dict(key="light_textures_mis_show_lights", lights=TEXTURED_MIXED, strategy=3, heuristic=3, samples=1, show_lights=True),
     dict(key="light_textures_mis_balance", lights=TEXTURED_MIXED, strategy=3, heuristic=0, samples=1),
     dict(key="light_textures_ggx_rays", lights=[textured_light(PENTAGON[0], "area", "area")], strategy=1, heuristic=0, samples=1, rays=True),
+    dict(key="light_textures_separately", lights=TEXTURED_MIXED, strategy=2, heuristic=0, samples=1),
+    dict(key="light_textures_random", lights=TEXTURED_MIXED, strategy=4, heuristic=0, samples=2),
     dict(key="light_textures_probe_rgb16", strategy=0, heuristic=0, samples=1,
          lights=[textured_light(TRIANGLE[0], "portal", "portal_rgb16")]),
 ]
