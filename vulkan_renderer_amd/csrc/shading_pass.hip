@@ -26,6 +26,11 @@ static const launch_function_t g_launchers[4][5] = {
 	{vkr_launch_shade_textured_fast_0, vkr_launch_shade_textured_fast_1, vkr_launch_shade_textured_fast_2, vkr_launch_shade_textured_fast_3, vkr_launch_shade_textured_fast_4},
 };
 
+// Events that order streams of one device: a device-scope release is all they need.  The default
+// (system-scope fence: L2 write-back and invalidation at every record) is paid by whatever runs
+// next on the device, and a frame records several.
+constexpr unsigned kSyncEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+
 static int hip_failed(hipError_t error, const char* what) {
 	if (error == hipSuccess) return 0;
 	printf("HIP error while %s: %s\n", what, hipGetErrorString(error));
@@ -155,8 +160,8 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	if (frames) return frames;
 	frames = (frame_pipeline*) calloc(1, sizeof(frame_pipeline));
 	pass->wavefront = frames;
-	bool failed = !frames || hipEventCreateWithFlags(&frames->inputs_ready, hipEventDisableTiming) != hipSuccess;
-	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++i) failed = hipEventCreateWithFlags(&frames->contexts[i].done, hipEventDisableTiming) != hipSuccess;
+	bool failed = !frames || hipEventCreateWithFlags(&frames->inputs_ready, kSyncEventFlags) != hipSuccess;
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++i) failed = hipEventCreateWithFlags(&frames->contexts[i].done, kSyncEventFlags) != hipSuccess;
 	if (failed) {
 		printf("Failed to create the events of the frame pipeline.\n");
 		destroy_wavefront(pass);
@@ -273,10 +278,10 @@ static int create_constants_ring(shading_pass_t* pass, const device_t* device) {
 	for (uint32_t i = 0; i != kConstantSlots; ++i) {
 		if (vkr_device_alloc(&ring->device[i], device, pass->constants_size, "the constant buffer")
 			|| vkr_host_alloc_pinned(&ring->host[i], pass->constants_size)
-			|| hip_failed(hipEventCreateWithFlags(&ring->uploaded[i], hipEventDisableTiming), "creating upload events"))
+			|| hip_failed(hipEventCreateWithFlags(&ring->uploaded[i], kSyncEventFlags), "creating upload events"))
 			return 1;
 		for (hipEvent_t& event : ring->consumed[i])
-			if (hip_failed(hipEventCreateWithFlags(&event, hipEventDisableTiming), "creating upload events")) return 1;
+			if (hip_failed(hipEventCreateWithFlags(&event, kSyncEventFlags), "creating upload events")) return 1;
 		memset(ring->host[i], 0, pass->constants_size);
 	}
 	pass->constants_device = ring->device[0];
@@ -412,7 +417,7 @@ static int create_timing_ring(shading_pass_t* pass) {
 	hipEvent_t* ring = (hipEvent_t*) calloc(3 * pass->timing_ring_size, sizeof(hipEvent_t));
 	pass->timing_ring = ring;
 	for (uint32_t i = 0; i != 3 * pass->timing_ring_size; ++i)
-		if (hip_failed(hipEventCreate(&ring[i]), "creating timing events")) return 1;
+		if (hip_failed(hipEventCreateWithFlags(&ring[i], hipEventReleaseToDevice), "creating timing events")) return 1;
 	return 0;
 }
 
