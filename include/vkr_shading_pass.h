@@ -222,6 +222,8 @@ typedef struct application_s {
 
 /*! reference main.c:232-249 */
 VKR_API void specify_default_render_settings(render_settings_t* settings);
+/*! reference main.c:134-168: default scene, camera and light, then quick_load() */
+VKR_API void specify_default_scene(scene_specification_t* scene);
 /*! reference main.c:173-216 */
 VKR_API uint32_t get_min_polygonal_light_vertex_count(const scene_specification_t* scene_specification);
 VKR_API uint32_t get_max_polygonal_light_vertex_count(const scene_specification_t* scene_specification);

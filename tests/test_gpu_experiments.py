@@ -67,3 +67,37 @@ def test_experiment_from_the_table_runs_end_to_end(tmp_path):
     result = experiments.run_experiment(49, root, frames=2, warmup=1, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
     assert os.path.basename(result["screenshot"]).startswith("cornell_box_projected_solid_angle_arvo_1spp_")
     assert decode_png(open(result["screenshot"], "rb").read()).max() > 0
+
+
+def test_c_program_on_the_c_abi_reproduces_the_python_runner(tmp_path):
+    """vkr_experiment (csrc/examples/vkr_experiment.c): the reference's -e<N> run as a plain C
+    program on libvkr_shading.so.  Same experiment, same generated data root (with a quicksave
+    so that both load the same camera and lights), same number of frames: same screenshot."""
+    import subprocess
+    from vulkan_renderer_amd import renderer
+    binary = os.path.join(os.path.dirname(renderer.__file__), "vkr_experiment")
+    assert os.path.exists(binary), "run make -C vulkan_renderer_amd/csrc (build() does)"
+    root = str(tmp_path / "root")
+    made = experiments.write_synthetic_data_root(root, grid=64, box_count=16)
+    table = experiments.experiment_table()
+    index = next(i for i in range(table.count) if table.experiments[i].screenshot_path == b"data/experiments/mis_plane_clamped_optimal_ours_2spp_%.3f.png")
+    # a quicksave in the place where the experiment looks for it (reference quick_save, main.c:49-80)
+    hs = renderer.HostScene()
+    hs.set_lights(golden_cases.QUADS[:2])
+    cam = synthetic.DEFAULT_CAMERA
+    hs.set_camera(cam["position"], cam["rotation_x"], cam["rotation_z"], cam["vertical_fov"], cam["near"], cam["far"])
+    save = C.create_string_buffer(os.path.join(root, "data", "quicksaves", "mis_plane.save").encode())
+    hs.app.scene_specification.quick_save_path = C.cast(save, C.c_void_p)
+    hs.lib.quick_save(C.byref(hs.app.scene_specification))
+    hs.app.scene_specification.quick_save_path = None
+    hs.close()
+    result = experiments.run_experiment(index, root, frames=16, warmup=8, synthetic_inputs=True, fresnel_count=made["fresnel_count"], verbose=False)
+    expected = decode_png(open(result["screenshot"], "rb").read())
+    os.remove(result["screenshot"])
+    done = subprocess.run([binary, "-e%d" % index, "--frames", "16", "--white-noise", "--fresnel", str(made["fresnel_count"]), root], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stdout + done.stderr
+    files = glob.glob(os.path.join(root, "data", "experiments", "mis_plane_clamped_optimal_ours_2spp_*.png"))
+    assert len(files) == 1 and "Msamples/s" in done.stdout
+    image = decode_png(open(files[0], "rb").read())
+    assert image.shape == expected.shape and image.max() > 0
+    assert np.array_equal(image, expected)

@@ -164,6 +164,7 @@ ABI_STRUCTS = [Device, PolygonalLight, Camera, LtcConstants, LtcTable, NoiseTabl
 P = C.POINTER
 SIGNATURES = {
     "create_hip_device": (C.c_int, [P(Device), C.c_int32, C.c_void_p]),
+    "specify_default_scene": (None, [P(SceneSpecification)]),
     "create_and_assign_light_textures": (C.c_int, [P(LightTextures), P(Device), P(SceneSpecification)]),
     "destroy_light_textures": (None, [P(LightTextures), P(Device)]),
     "destroy_hip_device": (None, [P(Device)]),

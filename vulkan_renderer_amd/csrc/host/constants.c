@@ -45,6 +45,37 @@ void specify_default_render_settings(render_settings_t* settings) {
 	settings->show_gui = VK_TRUE;
 }
 
+/* The attic scene, the camera of the reference's start-up and one unit square light of unit flux
+   that faces sideways; a quicksave, if there is one, replaces camera and lights. */
+void specify_default_scene(scene_specification_t* scene) {
+	memset(scene, 0, sizeof(*scene));
+	scene->file_path = vkr_copy_string(g_scene_paths[scene_attic][1]);
+	scene->texture_path = vkr_copy_string(g_scene_paths[scene_attic][2]);
+	scene->quick_save_path = vkr_copy_string(g_scene_paths[scene_attic][3]);
+	scene->camera.near = 0.05f;
+	scene->camera.far = 1.0e3f;
+	scene->camera.vertical_fov = 0.33f * VKR_PI_F;
+	scene->camera.rotation_x = 0.43f * VKR_PI_F;
+	scene->camera.rotation_z = 1.3f * VKR_PI_F;
+	scene->camera.position_world_space[0] = -3.0f;
+	scene->camera.position_world_space[1] = -2.0f;
+	scene->camera.position_world_space[2] = 1.65f;
+	scene->camera.speed = 2.0f;
+	scene->polygonal_lights = (polygonal_light_t*) calloc(1, sizeof(polygonal_light_t));
+	scene->polygonal_light_count = 1;
+	polygonal_light_t* light = &scene->polygonal_lights[0];
+	light->rotation_angles[0] = 0.5f * VKR_PI_F;
+	light->scaling_x = light->scaling_y = 1.0f;
+	for (uint32_t i = 0; i != 3; ++i) light->radiant_flux[i] = 1.0f;
+	set_polygonal_light_vertex_count(light, 4);
+	const float corners[4][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}, {0.0f, 1.0f}};
+	for (uint32_t i = 0; i != 4; ++i) {
+		light->vertices_plane_space[4 * i] = corners[i][0];
+		light->vertices_plane_space[4 * i + 1] = corners[i][1];
+	}
+	quick_load(scene, NULL);
+}
+
 uint32_t get_min_polygonal_light_vertex_count(const scene_specification_t* spec) {
 	if (!spec->polygonal_light_count) return 3;
 	uint32_t minimum = 0x7FFFFFFF;
