@@ -51,6 +51,33 @@ def algorithmic_bytes_per_pixel(light_count, sample_count, techniques):
     return 4 + 49 + 48 + 8 * noise_fetches + 16
 
 
+def available_cpus():
+    """Host threads this process may really use: affinity mask and the cgroup's CPU quota (a
+    container sees all cores of the machine in os.cpu_count() but is throttled to its quota:
+    256 threads on a quota of a few cores ran in bursts of 100 ms periods)."""
+    count = os.cpu_count() or 1
+    try:
+        count = min(count, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        fields = open("/sys/fs/cgroup/cpu.max").read().split()  # cgroup v2: "<quota|max> <period>"
+        if fields and fields[0] != "max":
+            quota = float(fields[0]) / float(fields[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        count = max(1, min(count, int(math.ceil(quota))))
+    return count
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,18 +328,21 @@ def main():
         inputs = r.host_inputs(visibility)
         bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
         frame_o = oracle.make_frame(inputs, r.oracle_settings(), bvh)
-        cores = os.cpu_count() or 1
-        # calibrate on 8 rows in the middle, then spread bands over the frame for ~12 s of CPU time
-        mid = height // 2
+        cores = available_cpus()
+        # The oracle deals 64-pixel chunks to all host threads; bands of at least `cores` rows keep
+        # the per-call overhead (256 threads waking up) small next to the work.  Calibrate on one
+        # band in the middle (after a call that starts the thread pool), then spread bands over
+        # the frame for ~12 s of CPU time.
+        band = int(min(height, max(24, cores)))
+        mid = max(0, height // 2 - band // 2)
         # exact mode is compared with the oracle's matching polynomial math (bit-comparable),
         # fast mode with the libm oracle
         oracle.set_math_mode(1 if args.mode == "exact" else 0)
-        oracle.shade(frame_o, mid, mid + 24)
+        oracle.shade(frame_o, mid, mid + band, cores)
         t = time.perf_counter()
-        oracle.shade(frame_o, mid, mid + 24)
-        per_row = max((time.perf_counter() - t) / 24, 1e-6)
-        rows_budget = int(min(height, max(16, 12.0 / per_row)))
-        band = 24
+        oracle.shade(frame_o, mid, mid + band, cores)
+        per_row = max((time.perf_counter() - t) / band, 1e-7)
+        rows_budget = int(min(height, max(band, 12.0 / per_row)))
         bands = max(1, rows_budget // band)
         starts = [int(i * (height - band) / max(bands - 1, 1)) for i in range(bands)]
         starts = sorted(set(starts))
@@ -321,7 +351,7 @@ def main():
         flipped, sq_without_flips, mismatched = 0, 0.0, 0
         for y0 in starts:
             t = time.perf_counter()
-            cpu = oracle.shade(frame_o, y0, y0 + band)
+            cpu = oracle.shade(frame_o, y0, y0 + band, cores)
             cpu_time += time.perf_counter() - t
             d = gpu_image[y0:y0 + band, :, :3].astype(np.float64) - cpu[y0:y0 + band, :, :3]
             sq += float((d ** 2).sum())
@@ -332,8 +362,16 @@ def main():
             mismatched += int((per_pixel > 0).sum())
             sq_without_flips += float((d[per_pixel <= 1e-2] ** 2).sum())
         sample_pixels = len(starts) * band * width
-        cpu_baseline = {"value": round(sample_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores,
-                        "kind": "port", "sample": "%d bands of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP, libm)" % (len(starts), band, sample_pixels, total_pixels)}
+        # cheap configurations: repeat the sample until about ten seconds of CPU work are timed
+        passes = 1
+        while cpu_time < 10.0 and passes < 4096:
+            t = time.perf_counter()
+            for y0 in starts:
+                oracle.shade(frame_o, y0, y0 + band, cores)
+            cpu_time += time.perf_counter() - t
+            passes += 1
+        cpu_baseline = {"value": round(passes * sample_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                        "kind": "port", "seconds": round(cpu_time, 2), "sample": "%d pass(es) over %d band(s) of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP over 64-pixel chunks, %s)" % (passes, len(starts), band, sample_pixels, total_pixels, "deterministic polynomial math" if args.mode == "exact" else "libm")}
         oracle.set_math_mode(0)
         parity = {"rmse_vs_oracle": math.sqrt(sq / max(cnt, 1)), "max_abs": worst, "nan": nan, "tolerance_rmse": 1e-4,
                   "sample_pixels": sample_pixels, "pixels_differing": mismatched, "pixels_over_1e-2": flipped,
