@@ -1373,15 +1373,16 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 	const float4* chunk_rays = ray_queue;
 	uint32_t chunk_count = 0, chunk_next = 0;
 	bool chunks_left = true;
-	// per-lane ray
-	bool active = false;
+	// per-lane ray; a lane without a ray has the cursor kIdle (the walk and the ballots test the
+	// cursor itself: a separate flag costs two more instructions per step)
+	constexpr uint32_t kIdle = 0xFFFFFFFFu;
 	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
 	grid_ray ray = {o, o};
 	float t_max = 0.0f;
-	uint32_t node = 0, code_index = 0;
+	uint32_t node = kIdle, code_index = 0;
 	while (true) {
 		// ---- hand new rays to idle lanes ------------------------------------------------
-		uint64_t idle = __ballot(!active);
+		uint64_t idle = __ballot(node == kIdle);
 		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
 			if (chunk_next >= chunk_count) {
 				uint32_t chunk = 0;
@@ -1399,29 +1400,28 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 			}
 			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
 			uint32_t index = chunk_next + rank;
-			if (!active && index < chunk_count) {
+			if (node == kIdle && index < chunk_count) {
 				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
 				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
 				code_index = __float_as_uint(b.w);
 				ray = make_grid_ray(bvh, o, d);
 				node = 0;
-				active = true;
 				if (!(t_max >= 1.0e-3f)) {
 					// empty interval: nothing can block the ray (same rule as any_hit); or a
 					// slot that the shading wave reserved and did not need
 					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
-					active = false;
+					node = kIdle;
 				}
 			}
 			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
-			idle = __ballot(!active);
+			idle = __ballot(node == kIdle);
 		}
-		uint64_t busy = __ballot(active);
+		uint64_t busy = __ballot(node != kIdle);
 		if (busy == 0) break;
 		// ---- walk until too many lanes have run dry (then refill) -------------------------
 		bool may_refill = chunk_next < chunk_count || chunks_left;
 		do {
-			if (active) {
+			if (node != kIdle) {
 				uint4 n = bvh.nodes[node];
 				bool is_leaf = (n.w & kLeafBit) != 0;
 				bool hit = ray_box(n, ray, 1.0e-3f, t_max);
@@ -1432,13 +1432,10 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
 				}
 				node = (hit || is_leaf) ? node + 1 : n.w;
-				if (blocked) active = false;
-				else if (node >= end) {
-					codes[code_index] = (uint8_t) kCodeVisible;
-					active = false;
-				}
+				if (!blocked && node >= end) codes[code_index] = (uint8_t) kCodeVisible;
+				if (blocked || node >= end) node = kIdle;
 			}
-			busy = __ballot(active);
+			busy = __ballot(node != kIdle);
 		} while (busy != 0 && (!may_refill || __popcll((unsigned long long) busy) > refill_threshold));
 	}
 }
