@@ -4,22 +4,28 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one pass of the shading kernels over one frame: write_constants ->
-upload -> shade / trace / resolve over the rank's tiles.  Inputs (scene, LBVH,
-LTC and noise tables, visibility buffer) are resident in HBM before the timed
-region; data is synthetic (seeded generators, vulkan_renderer_amd/synthetic.py).
+A step is one pass of the shading kernels over one frame: write_constants -> upload ->
+shade / trace / resolve over the rank's tiles [-> all-gather of the tile slabs -> scatter
+into the frame].  Inputs (scene, BVH, LTC and noise tables, visibility buffer) are resident
+in HBM before the timed region; data is synthetic (seeded generators,
+vulkan_renderer_amd/synthetic.py).
 
-N = 1 runs BASELINE config 2 (1920x1080, 1 spp, one pentagon light, GGX MIS with
-projected-solid-angle sampling, LBVH shadow rays) unless --config says otherwise.
-For N > 1 the scaling is weak: the frame grows to 1920 x (1080 N) pixels, tiles
-are dealt round-robin to the ranks, so every GPU shades one 1080p frame worth of
-pixels per step into its slab of the frame, which stays resident in its HBM like the
-frame does at N = 1: pixels are independent, the pass has no exchange step, hence no
-data-path collective (--exchange none, the default).  --exchange rgb8 | rgba8 | rgba32f
-adds what a consumer of whole frames on every GPU would need: an RCCL all-gather of the
-(encoded) slabs per frame, overlapped with the next frame, and the scatter into a frame.
+Workload.  N = 1 runs BASELINE config 3 (1920x1080, 4 spp per technique, 4 polygonal lights,
+diffuse + specular MIS with the clamped optimal heuristic, shadow rays), the heaviest 1080p
+configuration; --config 1 | 2 | 4 | target select the others (target = north_star's
+"1920x1080, 4 spp, 1 light").  N > 1 scales STRONGLY: the same fixed frame is cut into tiles,
+tile t goes to rank t mod N, every rank shades its tiles into a dense slab, one RCCL
+all-gather (ncclAllGather called from C behind the C-ABI, include/vkr_slab_exchange.h) per
+frame delivers all slabs to all ranks and a scatter kernel reassembles the frame - all inside
+the timed region, overlapped with the shading of the next frame.  The value at N = 1 is the
+plain single-GPU pass (no exchange), so the per-N values of one workload are comparable.
+Every run also measures BASELINE config 4 (3840x2160, 8 spp, 8 lights: the configuration
+BASELINE.json tiles over 8 GPUs) as a second workload and attaches it as "secondary" to the
+JSON line (--no-secondary to skip).  --scaling weak / --exchange none keep the round-1 mode
+(frame height x N, slabs stay where they are) as an option.
 
-PyTorch is plumbing here: device selection, the stream, torch.distributed.
+PyTorch is plumbing here: device selection, the stream, the process group used for the
+rendezvous token, barriers and the max over ranks of the timing.
 """
 import argparse
 import ctypes
@@ -27,9 +33,9 @@ import json
 import math
 import os
 
-# The two frame streams of the shading pass need hardware queues of their own next to torch's and
-# RCCL's streams; the HIP runtime multiplexes all streams onto 4 queues unless told otherwise.
-# Must be set before the runtime initialises (i.e. before torch is imported).
+# The frame streams of the shading pass and the exchange stream need hardware queues of their own
+# next to torch's and RCCL's streams; the HIP runtime multiplexes all streams onto 4 queues unless
+# told otherwise.  Must be set before the runtime initialises (i.e. before torch is imported).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import tempfile
@@ -78,200 +84,196 @@ def available_cpus():
     return count
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 2000 / 2000 / 500 / 100 for configs 1-4); a few hundred are needed before the clocks and the frame pipeline are in steady state (config 2: 100 frames are 14 ms)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed frames first (default: a tenth of the steps)")
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4])
-    ap.add_argument("--mode", default="exact", choices=["fast", "exact"],
-                    help="exact: IEEE arithmetic, bit-identical to the CPU oracle (default; it is as fast); fast: approximate reciprocals + contraction")
-    ap.add_argument("--tile-size", type=int, default=32)
-    ap.add_argument("--width", type=int, default=None)
-    ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--spp", type=int, default=None)
-    ap.add_argument("--no-rays", action="store_true", help="disable shadow rays (TRACE_SHADOW_RAYS=0) for experiments")
-    ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters (diagnostics)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
-    ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame with HIP events for the kernel time (roofline)")
-    ap.add_argument("--exchange", choices=("none", "rgb8", "rgba8", "rgba32f"), default="none", help="N > 1: none (default) leaves every rank's slab of the frame in its HBM; the others all-gather the slabs per frame and reassemble the frame on every rank: the encoded frame as packed RGB8 (3 bytes per pixel), as RGBA8, or float radiance")
-    ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path even with one rank")
-    args = ap.parse_args()
-    if args.steps is None:
-        args.steps = {1: 2000, 2: 2000, 3: 500, 4: 100}[args.config]
-    if args.warmup is None:
-        args.warmup = max(args.steps // 10, 1)
-    if args.steps < 4 * args.timing_stride:
-        args.timing_stride = 1  # short runs: time every frame
+class Job:
+    """What all workloads of one bench.py run share: ranks, torch handles, the dataset."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and not (self.world == 1 and args.gpus == 1):
+            raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the shading pass")
+        torch.cuda.set_device(self.local_rank)
+        self.process_group = self.world > 1
+        if self.process_group:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+        self.tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % self.rank)
+        from vulkan_renderer_amd import synthetic
+        # SURVEY.md 8(d): ground plane of 2 x 256^2 triangles + 64 boxes, LTC tables with R = 64, 51 layers
+        self.dataset = synthetic.write_dataset(self.tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=args.ltc_resolution, fresnel_count=51)
+        self.stream = torch.cuda.current_stream()
 
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.process_group:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        if not self.process_group:
+            return float(value)
+        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, values):
+        """-> list over ranks of lists"""
+        if not self.process_group:
+            return [list(values)]
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device="cuda")
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[float(v) for v in o.tolist()] for o in out]
+
+    def broadcast_bytes(self, payload, count):
+        """rank 0's bytes on every rank (the rendezvous token of the C-side communicator)"""
+        if not self.process_group:
+            return payload
+        t = self.torch.zeros(count, dtype=self.torch.uint8, device="cuda")
+        if self.rank == 0:
+            t.copy_(self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8))
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    def close(self):
+        if self.process_group:
+            self.dist.destroy_process_group()
+        self.tmp.cleanup()
+
+
+def run_workload(job, config, primary):
+    """Sets one BASELINE configuration up, times it and returns the dict that describes the run."""
     from vulkan_renderer_amd import renderer, synthetic
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1 or args.force_distributed
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the shading pass")
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    config = args.config
+    args, torch = job.args, job.torch
+    rank, world = job.rank, job.world
     settings = dict(synthetic.CONFIG_SETTINGS[config])
+    strong = args.scaling == "strong"
+    exchange = args.exchange if (world > 1 or args.force_distributed) else "none"
+    distributed = world > 1 or args.force_distributed
     width = args.width or settings["width"]
-    height_per_gpu = args.height or settings["height"]
-    height = height_per_gpu * world
+    height = (args.height or settings["height"]) * (1 if strong else world)
     if args.spp:
         settings["sample_count"] = args.spp
     sample_count = settings["sample_count"]
     if args.no_rays:
         settings["trace_shadow_rays"] = False
+    steps = args.steps if args.steps is not None else {1: 2000, 2: 2000, 3: 500, 4: 100, "target": 1000}[config]
+    warmup = args.warmup if args.warmup is not None else max(steps // 10, 1)
+    if not primary:
+        steps, warmup = max(4, min(steps, 25)), max(1, min(warmup, 5))
+    timing_stride = 1 if steps < 4 * args.timing_stride else args.timing_stride
 
-    tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % rank)
-    dataset = synthetic.write_dataset(tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51)
-    stream = torch.cuda.current_stream()
-    r = renderer.Renderer(hip_device=local_rank, stream=stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays,
-                          timing_stride=args.timing_stride, frames_in_flight=args.frames_in_flight)
-    renderer.setup_config(r, config, dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=True,
+    # ---- set-up (untimed, reported separately: BASELINE.md section 3) -------------------------
+    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays,
+                          timing_stride=timing_stride, frames_in_flight=args.frames_in_flight, binary_traversal=args.binary_traversal)
+    t = time.perf_counter()
+    renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh,
                           trace_shadow_rays=settings["trace_shadow_rays"])
-    r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1)
+    r.sync()
+    load_ms = (time.perf_counter() - t) * 1e3
+    structure = r.app.scene.acceleration_structure
+    r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1, slab_layout=distributed)
     r.create_targets()
     r.create_pass()
+    t = time.perf_counter()
     r.render_visibility()
     r.sync()
+    visibility_ms = (time.perf_counter() - t) * 1e3
     light_count = r.app.scene_specification.polygonal_light_count
     techniques = 1 if settings["sampling_strategies"] == "diffuse_only" else 2
+    total_pixels = width * height
 
-    if distributed:
-        # Every rank shades its tiles into a dense slab.  What is exchanged is the pass's
-        # real output, the encoded RGBA8 frame (reference: the swapchain image), a quarter of
-        # the bytes of the float radiance.  The all-gather of frame k runs on RCCL's stream
-        # while frame k + 1 is shaded (two sets of buffers); a frame counts as done when it
-        # has been reassembled, and the timed region ends only after the last one has.
-        slab_pixels = r.slab_pixel_count(0)
-        # one set of buffers per frame in flight (at least two): frame k + 1 is shaded while frame k
-        # is encoded and exchanged
-        sets = max(2, args.frames_in_flight)
-        slab = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
-        if args.exchange == "none":
-            send = gathered = frame = None
-        elif args.exchange == "rgb8":
-            send = [torch.zeros(3 * slab_pixels, dtype=torch.uint8, device="cuda") for _ in range(sets)]
-            gathered = [torch.zeros(world * 3 * slab_pixels, dtype=torch.uint8, device="cuda") for _ in range(sets)]
-            frame = torch.zeros((height, width), dtype=torch.int32, device="cuda")
-        elif args.exchange == "rgba8":
-            send = [torch.zeros(slab_pixels, dtype=torch.int32, device="cuda") for _ in range(sets)]
-            gathered = [torch.zeros(world * slab_pixels, dtype=torch.int32, device="cuda") for _ in range(sets)]
-            frame = torch.zeros((height, width), dtype=torch.int32, device="cuda")
-        else:
-            send = [torch.zeros((slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
-            gathered = [torch.zeros((world * slab_pixels, 4), dtype=torch.float32, device="cuda") for _ in range(sets)]
-            frame = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
-        pending = [None] * sets
-        frame_counter = [0]
-        # The frames run on the device's frame streams, not on torch's stream.  Before a frame
-        # overwrites buffer set b, those streams wait for the last reader of that set (the encode
-        # kernel resp. the collective), via an event recorded on torch's stream.
-        frame_streams = [torch.cuda.ExternalStream(int(r.app.device.frame_streams[i])) for i in range(args.frames_in_flight)] if args.frames_in_flight >= 2 else []
-        readers_done = [None] * sets
-
-        def finish(b):
-            if pending[b] is not None:
-                pending[b].wait()  # the compute stream waits for the collective, not the host
-                if args.exchange == "rgb8":
-                    r.assemble_rgb8(gathered[b].data_ptr(), frame.data_ptr())
-                elif args.exchange == "rgba8":
-                    r.assemble_encoded(gathered[b].data_ptr(), frame.data_ptr())
-                else:
-                    r.assemble(gathered[b].data_ptr(), frame.data_ptr())
-                    readers_done[b] = torch.cuda.Event()
-                    readers_done[b].record()
-                pending[b] = None
+    slab = None
+    if exchange != "none":
+        # the rendezvous token comes from rank 0 (ncclGetUniqueId behind the C-ABI) over the process group
+        token = job.broadcast_bytes(r.exchange_id() if rank == 0 else b"", 128)
+        r.create_exchange(token, exchange)
 
         def step():
-            if args.exchange == "none":
-                return r.render(slab[0].data_ptr())
-            b = frame_counter[0] % sets
-            frame_counter[0] += 1
-            finish(b)  # frame k - sets is complete, its buffers are free again
-            if readers_done[b] is not None:
-                for s in frame_streams:
-                    s.wait_event(readers_done[b])
-            if args.exchange in ("rgb8", "rgba8"):
-                r.render(slab[b].data_ptr())
-                if args.exchange == "rgb8":
-                    r.encode_slab_rgb8(slab[b].data_ptr(), send[b].data_ptr(), slab_pixels)
-                else:
-                    r.encode_slab(slab[b].data_ptr(), send[b].data_ptr(), slab_pixels)
-                readers_done[b] = torch.cuda.Event()
-                readers_done[b].record()
-            else:
-                r.render(send[b].data_ptr())
-                r.finish_frames()  # torch's stream waits for the frame before RCCL reads it
-            pending[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
+            r.render_and_exchange(None)
 
         def drain():
-            for i in range(sets):
-                finish((frame_counter[0] + i) % sets)
+            r.finish_exchange()
+    elif distributed:
+        slab = torch.zeros((r.slab_pixel_count(0), 4), dtype=torch.float32, device="cuda")
+
+        def step():
+            r.render(slab.data_ptr())
+
+        def drain():
+            r.finish_frames()
     else:
         def step():
             r.render()
 
         def drain():
-            pass
+            r.finish_frames()
 
     def fence():
         drain()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
+        job.barrier()
 
-    for _ in range(args.warmup):
+    # clocks and the frame pipeline reach their steady state only after a few hundred frames (config 2:
+    # 100 frames are 14 ms); the driver's --warmup 5 alone would time a cold GPU
+    prewarm = 0
+    t0 = time.perf_counter()
+    while prewarm < args.prewarm_frames and (prewarm < 8 or time.perf_counter() - t0 < args.prewarm_seconds):
+        step()
+        prewarm += 1
+        if prewarm % 16 == 0:
+            drain()
+            torch.cuda.synchronize()
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     issue_seconds = time.perf_counter() - t0  # host time to queue the steps (a bound if the host cannot keep up)
     fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    total_pixels = width * height
-    value = total_pixels * sample_count / (elapsed / args.steps) / 1e6
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = elapsed / steps * 1e3
+    value = total_pixels * sample_count / (elapsed / steps) / 1e6
 
-    # ---- roofline of the shading kernel, from HIP events recorded inside the timed region --------
-    timed_frames = max(1, min(args.steps // max(args.timing_stride, 1), 256))
-    launch_ms = r.dispatch_ms(timed_frames)
+    # ---- what the timed region looked like from the inside ---------------------------------------
+    timed_frames = max(1, min(steps // max(timing_stride, 1), 256))
+    overlapped_kernel_ms = r.shading_kernel_ms(timed_frames)
     period_ms = r.frame_period_ms(max(1, timed_frames - 1))
-    # The dominant kernel is shade_pixels; its launches are bracketed by HIP events on the stream
-    # they run on (every timing_stride-th frame).  One launch of the whole pass is shade + trace +
-    # resolve; with frames in flight two passes share the GPU, so the pass duration that counts
-    # is the period between completions.
+    launch_ms = r.dispatch_ms(timed_frames)
     pipelined = bool(r.app.shading_pass.last_frame_in_flight)
-    kernel_ms = r.shading_kernel_ms(timed_frames)
-    pass_ms = float(np.mean(period_ms if (pipelined and period_ms) else launch_ms)) if launch_ms else float("nan")
-    kernel_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    frames_in_flight = int(r.app.shading_pass.last_frame_in_flight) if pipelined else 1
+    rays = r.last_ray_count()
+    stages = None
+    if exchange != "none":
+        mine = r.exchange_ms() or [float("nan")] * 3
+        per_rank = job.gather_floats(mine)
+        stages = {"shade_ms": [round(v[0], 4) for v in per_rank], "all_gather_ms": [round(v[1], 4) for v in per_rank],
+                  "scatter_ms": [round(v[2], 4) for v in per_rank],
+                  "note": "per rank, HIP events of the most recent timed frame: shading (+ encoding) of the rank's slab on its frame stream, ncclAllGather and scatter on the exchange stream; they overlap the next frame, so they do not add up to ms_per_step"}
+    # the assembled frame against a single-GPU render of the whole frame (rank 0)
+    scaling_parity = None
+    assembled = None
+    if exchange != "none" and rank == 0:
+        if exchange == "rgba32f":
+            assembled = r.read_radiance()
+        else:
+            assembled = np.zeros((height, width, 4), np.uint8)
+            r.lib.read_back_encoded(ctypes.byref(r.app), assembled.ctypes.data)
+    if exchange != "none":
+        r.destroy_exchange()
     visibility = r.read_visibility()
     own_pixels = r.slab_pixel_count(rank) if distributed else total_pixels
     if distributed:
         # shaded fraction of the pixels this rank owns
-        import ctypes as C
         xy = np.zeros((own_pixels, 2), np.uint32)
-        slots = r.lib.get_slab_pixel_coordinates(C.byref(r.app), rank, xy.ctypes.data, own_pixels)
+        slots = r.lib.get_slab_pixel_coordinates(ctypes.byref(r.app), rank, xy.ctypes.data, own_pixels)
         valid = xy[:slots, 0] != 0xFFFFFFFF
         own_visibility = visibility[xy[:slots][valid, 1], xy[:slots][valid, 0]]
     else:
@@ -279,52 +281,106 @@ def main():
     shaded = int((own_visibility != 0xFFFFFFFF).sum())
     background = int(own_visibility.size - shaded)
     bytes_per_launch = shaded * algorithmic_bytes_per_pixel(light_count, sample_count, techniques) + background * 20
-    achieved = bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9
-    traffic = None
-    valu_floor_us = None
+
+    # ---- the dominant kernel alone: a short pass with one frame at a time, every frame timed -------
+    r.frames_in_flight, r.timing_stride = 1, 1
+    r.create_pass()
+    target = slab.data_ptr() if slab is not None else None
+    alone_frames = max(4, min(steps, 16))
+    for _ in range(alone_frames + 3):
+        r.render(target)
+    r.sync()
+    kernel_alone_ms = r.shading_kernel_ms(alone_frames)
+    pass_alone_ms = r.dispatch_ms(alone_frames)
+    kernel_ms = float(np.mean(kernel_alone_ms)) if kernel_alone_ms else float("nan")
+    traversal = None
+    if (args.traversal_stats or primary) and rays and not args.inline_rays and world == 1:
+        traversal = {}
+        for wide in ([True, False] if structure.wide_nodes else [False]):
+            s = r.traversal_statistics(wide)
+            traversal[s["tree"]] = {"fetches_per_ray": round(s["node_visits"] / max(s["rays"], 1), 2), "boxes_tested_per_ray": round(s["boxes_tested"] / max(s["rays"], 1), 2),
+                                    "triangle_tests_per_ray": round(s["triangle_tests"] / max(s["rays"], 1), 2), "lane_use": round(s["node_visits"] / max(64 * s["wave_steps"], 1), 3),
+                                    "longest_ray_fetches": s["longest_ray_visits"]}
+        traversal["walked"] = "wide" if (structure.wide_nodes and not args.binary_traversal) else "binary"
+    if assembled is not None:
+        # single-GPU render of the whole frame with the same pass settings
+        r.set_tiles(16, 0, 1, slab_layout=False)
+        r.render()
+        single = r.read_radiance() if exchange == "rgba32f" else r.read_encoded(False, 0)
+        differing = int((assembled.view(np.uint32) != single.view(np.uint32)).any(axis=-1).sum()) if exchange == "rgba32f" else int((assembled != single).any(axis=-1).sum())
+        scaling_parity = {"pixels_differing_from_single_gpu_frame": differing, "pixels": total_pixels, "format": exchange}
+        r.set_tiles(args.tile_size, rank, world, slab_layout=True)
+    # PCIe-inclusive figures (never part of `value`): the frame to the host, a visibility buffer from the host
+    t = time.perf_counter()
+    gpu_image = r.read_radiance()
+    readback_ms = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    r.upload_visibility(visibility)
+    r.sync()
+    upload_ms = (time.perf_counter() - t) * 1e3
+
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    pass_ms = float(np.mean(period_ms if (pipelined and period_ms) else launch_ms)) if launch_ms else float("nan")
+    pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             table = json.load(open(pmc_path))
-            entry = table.get("config%d_%s" % (config, args.mode))
+            entry = table.get("config%s_%s" % (config, args.mode))
             if entry and world == 1 and width == entry.get("width") and height == entry.get("height"):
-                traffic = entry["hbm_bytes_per_launch"]
-                valu_floor_us = table.get("config%d_%s_valu_floor_us" % (config, args.mode))
+                pmc = entry
         except Exception:
-            traffic = None
-    rays = r.last_ray_count()
-    traversal = None
-    if args.traversal_stats and rays and not args.inline_rays:
-        traversal = r.traversal_statistics()
-        traversal["visits_per_ray"] = round(traversal["node_visits"] / max(traversal["rays"], 1), 2)
-        traversal["tests_per_ray"] = round(traversal["triangle_tests"] / max(traversal["rays"], 1), 2)
-        traversal["lane_use"] = round(traversal["node_visits"] / max(64 * traversal["wave_steps"], 1), 3)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                "kernel_ms": round(kernel_avg_ms, 4), "pass_ms": round(pass_ms, 4),
-                "achieved_over_pass": round(bytes_per_launch / (pass_ms * 1e-3) / 1e9, 3),
-                "pass_latency_ms": round(float(np.mean(launch_ms)), 4) if launch_ms else None,
-                "frames_in_flight": int(r.app.shading_pass.last_frame_in_flight) if pipelined else 1, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count,
-                                                                   int(r.app.shading_pass.use_ray_tracing), args.mode),
-                "note": "kernel_ms = shade_pixels alone (dominant kernel), pass_ms = shade + trace + resolve per frame; "
-                        "compute-bound pass: FP32 VALU issue and BVH latency limit it, not HBM (SURVEY.md 8d)"}
+            pmc = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                "traffic_source": ("%s: rocprofv3 --pmc of this configuration, not measured in this run" % pmc.get("source", "profiles/pmc_traffic.json")) if pmc else None,
+                "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count, int(r.app.shading_pass.use_ray_tracing), args.mode),
+                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel_ms_source": "HIP events around the kernel on its stream, %d frames with one frame at a time (nothing else on the GPU), run right after the timed region" % alone_frames,
+                "pass_alone_ms": round(float(np.mean(pass_alone_ms)), 4) if pass_alone_ms else None,
+                "overlapped": {"frames_in_flight": frames_in_flight, "frame_period_ms": round(pass_ms, 4),
+                               "kernel_bracket_ms": round(float(np.mean(overlapped_kernel_ms)), 4) if overlapped_kernel_ms else None,
+                               "note": "inside the timed region %d frames share the GPU: the bracket of one frame's shade_pixels then spans time in which the other frames' trace and resolve kernels run too, so it can exceed ms_per_step; it is not used for `achieved`" % frames_in_flight},
+                "note": "nominal roofline (SURVEY.md 8d): the pass is bound by FP32 VALU issue and BVH latency, not by HBM"}
+    if pmc and pmc.get("valu_floor_us"):
+        # the bound that actually holds: wave64 VALU instructions counted by the PMC pass in profiles/
+        # x 4 clocks / 1024 SIMDs / 2.4 GHz, per kernel of the pass
+        floors = pmc["valu_floor_us"]
+        roofline["valu_issue"] = {"shade_pixels_floor_ms": round(floors.get("shade_pixels", 0.0) * 1e-3, 4),
+                                  "shade_pixels_frac": round(floors.get("shade_pixels", 0.0) * 1e-3 / kernel_ms, 4),
+                                  "floor_ms_per_pass": round(sum(floors.values()) * 1e-3, 4), "frac_of_ms_per_step": round(sum(floors.values()) * 1e-3 / ms_per_step, 4),
+                                  "source": "instruction counts from %s (rocprofv3 --pmc, not measured in this run), times live" % pmc.get("source", "profiles/pmc_traffic.json")}
 
-    if valu_floor_us:
-        # the bound that actually holds: wave64 VALU instructions counted by the PMC
-        # pass in profiles/ x 4 clocks / 1024 SIMDs / 2.4 GHz, per kernel of the pass, against the
-        # live frame period
-        floor_ms = sum(valu_floor_us.values()) * 1e-3
-        roofline["valu_issue"] = {"floor_ms_per_pass": round(floor_ms, 4), "frac": round(floor_ms / pass_ms, 4),
-                                  "shade_pixels_floor_ms": round(valu_floor_us.get("shade_pixels", 0.0) * 1e-3, 4),
-                                  "source": "profiles/pmc_traffic.json (instruction counts from rocprofv3 --pmc), time live"}
+    result = {
+        "metric": "Msamples/s (pixels x spp / s), shading pass", "value": round(value, 3), "unit": "Msamples/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config %s: %dx%d, %d spp per technique, %d polygonal light(s), %s + %s, %s, %s arithmetic"
+                               % (config, width, height, sample_count, light_count, settings["sampling_strategies"], settings["polygon_technique"],
+                                  ("shadow rays through the %s BVH (%s)" % ("four-wide" if (structure.wide_nodes and not args.binary_traversal and not args.inline_rays) else "binary",
+                                                                            renderer.BVH_BUILDER_NAME[int(structure.builder)])) if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
+                   "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
+                   "parallelism": ("tiles %dx%d round-robin over %d rank(s), %s" % (args.tile_size, args.tile_size, world,
+                                   ("RCCL all-gather of %s slabs (ncclAllGather from C) + scatter per frame inside the timed region, overlapped with the next frame" % exchange) if exchange != "none" else "every rank keeps its slab of the frame (no data-path collective)")) if distributed else "one GPU, whole frame",
+                   "scene_triangles": int(r.app.scene.mesh.triangle_count), "ltc_resolution": int(r.app.ltc_table.roughness_count)},
+        "prewarm_frames": prewarm, "host_issue_ms_per_step": round(issue_seconds / steps * 1e3, 4),
+        "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (ms_per_step * 1e-3) / 1e6, 2) if rays else 0.0,
+        "setup": {"load_and_upload_ms": round(load_ms - structure.build_milliseconds, 2), "bvh_build_ms": round(float(structure.build_milliseconds), 3),
+                  "bvh_builder": renderer.BVH_BUILDER_NAME[int(structure.builder)], "visibility_pass_ms": round(visibility_ms, 3),
+                  "readback_ms": round(readback_ms, 3), "upload_ms": round(upload_ms, 3),
+                  "note": "untimed set-up, once per scene (load = parse .vks / LTC fits / noise + copies to the device); readback = RGBA32F frame to the host, upload = a visibility buffer from the host (what a PCIe-inclusive frame would add; never part of value)"},
+        "roofline": roofline,
+    }
+    if stages:
+        result["stages"] = stages
+    if scaling_parity:
+        result["scaling_parity"] = scaling_parity
+    if traversal:
+        result["traversal"] = traversal
 
-    # ---- CPU baseline and parity on a bounded sample (rank 0, N = 1 only) ------------------------
-    cpu_baseline = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- CPU baseline and parity on a bounded sample (rank 0, N = 1, first workload only) --------
+    if primary and rank == 0 and world == 1 and not distributed and not args.no_cpu_baseline:
         import oracle
-        gpu_image = r.read_radiance()
         inputs = r.host_inputs(visibility)
         bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
         frame_o = oracle.make_frame(inputs, r.oracle_settings(), bvh)
@@ -344,8 +400,7 @@ def main():
         per_row = max((time.perf_counter() - t) / band, 1e-7)
         rows_budget = int(min(height, max(band, 12.0 / per_row)))
         bands = max(1, rows_budget // band)
-        starts = [int(i * (height - band) / max(bands - 1, 1)) for i in range(bands)]
-        starts = sorted(set(starts))
+        starts = sorted(set(int(i * (height - band) / max(bands - 1, 1)) for i in range(bands)))
         cpu_time = 0.0
         sq, cnt, worst, nan = 0.0, 0, 0.0, int(np.isnan(gpu_image).sum())
         flipped, sq_without_flips, mismatched = 0, 0.0, 0
@@ -370,46 +425,66 @@ def main():
                 oracle.shade(frame_o, y0, y0 + band, cores)
             cpu_time += time.perf_counter() - t
             passes += 1
-        cpu_baseline = {"value": round(passes * sample_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores,
-                        "kind": "port", "seconds": round(cpu_time, 2), "sample": "%d pass(es) over %d band(s) of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP over 64-pixel chunks, %s)" % (passes, len(starts), band, sample_pixels, total_pixels, "deterministic polynomial math" if args.mode == "exact" else "libm")}
+        result["cpu_baseline"] = {"value": round(passes * sample_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                                  "kind": "port", "seconds": round(cpu_time, 2),
+                                  "sample": "%d pass(es) over %d band(s) of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP over 64-pixel chunks, %s)" % (passes, len(starts), band, sample_pixels, total_pixels, "deterministic polynomial math" if args.mode == "exact" else "libm")}
+        result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
         oracle.set_math_mode(0)
-        parity = {"rmse_vs_oracle": math.sqrt(sq / max(cnt, 1)), "max_abs": worst, "nan": nan, "tolerance_rmse": 1e-4,
-                  "sample_pixels": sample_pixels, "pixels_differing": mismatched, "pixels_over_1e-2": flipped,
-                  "rmse_without_those": math.sqrt(sq_without_flips / max(cnt, 1)),
-                  "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
+        result["parity"] = {"rmse_vs_oracle": math.sqrt(sq / max(cnt, 1)), "max_abs": worst, "nan": nan, "tolerance_rmse": 1e-4,
+                            "sample_pixels": sample_pixels, "pixels_differing": mismatched, "pixels_over_1e-2": flipped,
+                            "rmse_without_those": math.sqrt(sq_without_flips / max(cnt, 1)),
+                            "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
+    r.close()
+    return result
 
+
+def parse_config(text):
+    return text if text == "target" else int(text)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 2000 / 2000 / 500 / 100 for configs 1-4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames right before the timed ones (default: a tenth of the steps); --prewarm-frames come before them")
+    ap.add_argument("--config", type=parse_config, default=3, choices=[1, 2, 3, 4, "target"], help="BASELINE.json configuration (default 3, the heaviest 1080p one); target = 1920x1080, 4 spp, 1 light")
+    ap.add_argument("--no-secondary", action="store_true", help="do not also measure BASELINE config 4 (3840x2160, 8 spp, 8 lights)")
+    ap.add_argument("--mode", default="exact", choices=["fast", "exact"],
+                    help="exact: IEEE arithmetic, bit-identical to the CPU oracle (default); fast: approximate reciprocals + contraction")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed frame is cut into tiles (default); weak = the frame height grows with N")
+    ap.add_argument("--exchange", choices=("rgba32f", "rgb8", "none"), default="rgba32f",
+                    help="N > 1: all-gather of the tile slabs per frame as float radiance (default) or as packed RGB8 of the encoded output, then the scatter into the frame on every rank; none leaves every rank's slab in its HBM")
+    ap.add_argument("--tile-size", type=int, default=32)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--bvh", default="sah_device", choices=["sah_device", "lbvh_device", "sah_host"], help="who builds the BVH (default: binned SAH by HIP kernels)")
+    ap.add_argument("--binary-traversal", action="store_true", help="walk the binary tree in the wavefront kernel instead of the four-wide one")
+    ap.add_argument("--no-rays", action="store_true", help="disable shadow rays (TRACE_SHADOW_RAYS=0) for experiments")
+    ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
+    ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")
+    ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")
+    ap.add_argument("--ltc-resolution", type=int, default=64, help="roughness / inclination resolution R of the generated LTC tables (SURVEY.md 8d: 64)")
+    ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path (slab layout, exchange) even with one rank")
+    args = ap.parse_args()
+
+    job = Job(args)
+    result = run_workload(job, args.config, True)
+    if not args.no_secondary and args.config != 4 and not (args.width or args.height or args.spp):
+        second = run_workload(job, 4, False)
+        keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "shadow_rays_per_frame", "Mrays_per_s", "stages", "scaling_parity", "setup", "roofline", "traversal")
+        result["secondary"] = {k: second[k] for k in keep if k in second}
     # the library reports like the reference does (printf): every rank flushes C stdio before rank 0
     # prints, so that the JSON line is the last line of the job's output
     ctypes.CDLL(None).fflush(None)
-    if distributed:
-        dist.barrier()
-    if rank == 0:
-        result = {
-            "metric": "Msamples/s (pixels x spp / s), shading pass", "value": round(value, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config %d: %dx%d, %d spp per technique, %d polygonal light(s), %s + %s, %s, %s arithmetic"
-                                   % (config, width, height, sample_count, light_count, settings["sampling_strategies"],
-                                      settings["polygon_technique"], "LBVH shadow rays" if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
-                       "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
-                       "parallelism": "tiles %dx%d round-robin over %d rank(s)%s" % (args.tile_size, args.tile_size, world, (", every rank keeps its slab of the frame (no data-path collective)" if args.exchange == "none" else " + RCCL all-gather of %s slabs overlapped with the next frame" % args.exchange) if distributed else ""),
-                       "scene_triangles": int(r.app.scene.mesh.triangle_count)},
-            "host_issue_ms_per_step": round(issue_seconds / args.steps * 1e3, 4),
-            "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (pass_ms * 1e-3) / 1e6, 2) if rays else 0.0,
-            "roofline": roofline,
-        }
-        if traversal:
-            result["traversal"] = traversal
-        if cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline
-            result["speedup_vs_cpu"] = round(value / cpu_baseline["value"], 1)
-        if parity:
-            result["parity"] = parity
+    job.barrier()
+    if job.rank == 0:
         print(json.dumps(result), flush=True)
-    r.close()
-    if distributed:
-        dist.destroy_process_group()
-    tmp.cleanup()
+    job.close()
 
 
 if __name__ == "__main__":

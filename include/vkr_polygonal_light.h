@@ -6,8 +6,9 @@
 #include "vkr_device.h"
 
 /*! Same values as sample_polygon_technique_t, reference polygonal_light.h:30-69.
-	The related-work samplers (Turk, Urena, Arvo, Hart) are out of scope: the
-	shading pass rejects them at create time. */
+	All thirteen techniques have kernel variants (the related-work samplers of Turk, Urena,
+	Arvo and Hart for the strategies their shader branch exists for); create_shading_pass()
+	rejects the combinations the reference's GUI rejects (user_interface.cpp:90-180). */
 typedef enum sample_polygon_technique_e {
 	sample_polygon_baseline,
 	sample_polygon_area_turk,
@@ -26,7 +27,8 @@ typedef enum sample_polygon_technique_e {
 } sample_polygon_technique_t;
 
 /*! Same values as polygon_texturing_technique_t, reference polygonal_light.h:75-90.
-	Only polygon_texturing_none is implemented (light textures are out of scope). */
+	All four are implemented (shading_pass.frag.glsl:151-185); a light that uses a texture needs
+	create_and_assign_light_textures() before create_shading_pass(). */
 typedef enum polygon_texturing_technique_e {
 	polygon_texturing_none = 0,
 	polygon_texturing_area = 1,

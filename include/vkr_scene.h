@@ -53,6 +53,21 @@ typedef struct materials_s {
 	void* srgb_table;
 } materials_t;
 
+/*! Who builds the BVH (request_acceleration_structure of load_scene()).  The reference asks the
+	driver (vkCmdBuildAccelerationStructuresKHR, scene.c:254-262, PREFER_FAST_TRACE). */
+typedef enum acceleration_structure_builder_e {
+	acceleration_structure_none = 0,
+	/*! binned surface-area heuristic, built breadth-first by HIP kernels (lbvh_build.hip); the
+		default (VK_TRUE) and the counterpart of PREFER_FAST_TRACE */
+	acceleration_structure_sah_device = 1,
+	/*! Morton-code LBVH by HIP kernels: the counterpart of PREFER_FAST_BUILD (more node visits per ray) */
+	acceleration_structure_lbvh_device = 2,
+	/*! the same binned surface-area heuristic on the host (sah_bvh.c), kept as the plain C
+		statement of the algorithm that the device builder is checked against */
+	acceleration_structure_sah_host = 3,
+	acceleration_structure_builder_count
+} acceleration_structure_builder_t;
+
 /*! Replaces reference scene.h:161-175: a binary BVH over the de-quantised
 	triangle soup (same de-quantisation as scene.c:176-187). */
 typedef struct acceleration_structure_s {
@@ -67,6 +82,18 @@ typedef struct acceleration_structure_s {
 	uint32_t root;
 	/*! the grid of the quantised boxes: world = grid_origin + q / grid_inverse_cell */
 	float grid_origin[3], grid_inverse_cell[3];
+	/*! The same tree collapsed to four children per node for the wavefront shadow-ray kernel:
+		64-byte nodes (the children's boxes on the same grid + their links), children of a node
+		stored next to each other, see vulkan_renderer_amd/csrc/lbvh.h.  NULL if the collapse
+		was not requested or not possible; the kernels then walk `nodes`. */
+	void* wide_nodes;
+	uint32_t wide_node_count;
+	/*! most stack entries a ray can need in the wide tree (sum over a root path of children - 1) */
+	uint32_t wide_stack_need;
+	/*! acceleration_structure_builder_t that made the tree, and the time from the de-quantised
+		triangles on the device to the finished structures (HIP kernels, or host build + upload) */
+	uint32_t builder;
+	float build_milliseconds;
 } acceleration_structure_t;
 
 /*! reference scene.h:161-166 */
@@ -82,9 +109,8 @@ VKR_API const char* get_material_texture_suffix(material_texture_type_t type);
 	files are read when present (uncompressed float / half formats only; the
 	smallest mip level supplies the constant), otherwise defaults apply: base
 	colour 0.8, specular (1, 0.5, 0), flat normal.
-	request_acceleration_structure: VK_FALSE none, VK_TRUE the fast-trace build (SAH on
-	the host, the counterpart of PREFER_FAST_TRACE at scene.c:254-262), 2 the fast-build
-	variant (Morton-code LBVH on the device). */
+	request_acceleration_structure: an acceleration_structure_builder_t; VK_FALSE none, VK_TRUE
+	the fast-trace build by HIP kernels (the counterpart of PREFER_FAST_TRACE at scene.c:254-262). */
 VKR_API int load_scene(scene_t* scene, const device_t* device, const char* file_path, const char* texture_path, VkBool32 request_acceleration_structure);
 /*! reference scene.h:184 */
 VKR_API void destroy_scene(scene_t* scene, const device_t* device);

@@ -45,8 +45,9 @@ typedef enum mis_heuristic_e {
 	mis_heuristic_count
 } mis_heuristic_t;
 
-/*! reference main.h:93-118.  Only error_display_none is implemented in the
-	kernels; the sampler's error functions are exposed for tests instead. */
+/*! reference main.h:93-118.  All displays are implemented (the projected solid angle
+	techniques define them, shading_pass.frag.glsl:80-114, polygon_sampling.glsl:823-883);
+	a frame with an error display returns before it samples, so it traces no rays. */
 typedef enum error_display_e {
 	error_display_none,
 	error_display_diffuse_backward,
@@ -125,10 +126,13 @@ typedef struct screenshot_s {
 
 /*! How pixels are distributed over GPUs: the image is cut into square tiles,
 	tile t (row-major) belongs to rank t % rank_count, and a rank stores its tiles
-	densely one after the other ("slab").  rank_count == 1 renders in place. */
+	densely one after the other ("slab").  rank_count == 1 renders in place unless
+	slab_layout is set (the dense layout with a single rank: how the exchange path of
+	include/vkr_slab_exchange.h is exercised on one GPU). */
 typedef struct tile_schedule_s {
 	uint32_t tile_size;
 	uint32_t rank, rank_count;
+	VkBool32 slab_layout;
 } tile_schedule_t;
 
 /*! Replaces shading_pass_t (reference main.h:278-285).  The "pipeline" is a
@@ -186,6 +190,13 @@ typedef struct shading_pass_s {
 	/*! time every timing_stride-th frame only (0 or 1: every frame; set before
 		create_shading_pass like fast_math); frames rendered so far */
 	uint32_t timing_stride, frame_counter;
+	/*! 1 if the most recent render_shading_pass() traced shadow rays (an error display frame
+		does not, whatever the settings say): get_last_ray_count() reports 0 otherwise */
+	uint32_t last_frame_traced_rays;
+	/*! 1: the wavefront kernel walks the binary tree even if the scene has the four-wide one
+		(acceleration_structure_t.wide_nodes), for comparisons; results are identical.  Set before
+		create_shading_pass like fast_math. */
+	int32_t binary_traversal;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
@@ -337,13 +348,17 @@ VKR_API uint64_t get_last_ray_count(const application_t* app);
 	and writes {rays, node visits, triangle tests, blocked rays, wave steps (sum over
 	groups of 64 rays of the longest ray's visits), longest ray's visits}.  0 on success. */
 VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]);
+/*! The same for the tree of the caller's choice - the binary one (one box per visit) or the
+	four-wide one (a visit fetches one node and tests up to four boxes) - whatever the frame itself
+	walked, plus [6] boxes tested (wide tree only) and [7] the deepest stack a ray reached (wide tree only) */
+VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]);
 
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,
 	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,
 	materials_t, acceleration_structure_t, scene_t, scene_specification_t,
 	render_settings_t, per_frame_constants_t, swapchain_t, render_targets_t,
 	screenshot_t, tile_schedule_t, shading_pass_t, application_t, experiment_t,
-	experiment_list_t) so that bindings can
+	experiment_list_t, slab_exchange_id_t, slab_exchange_t) so that bindings can
 	check their mirrors.  Returns the number of structs. */
 VKR_API uint32_t get_abi_struct_sizes(uint64_t* sizes, uint32_t capacity);
 

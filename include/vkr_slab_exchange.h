@@ -1,0 +1,100 @@
+/* Multi-GPU exchange of the shading pass: every rank shades the tiles that
+ * app->tile_schedule gives it into a dense slab, one all-gather over RCCL (xGMI)
+ * delivers all slabs to all ranks, a scatter kernel turns them back into the frame.
+ *
+ * The reference renders on one GPU and has no counterpart; the contract is
+ * BASELINE.json configs[3] ("image tiled across 8 x MI355X with RCCL all-gather over
+ * xGMI") and SURVEY.md 8(e).  What the exchange moves is the output of the pass
+ * (reference: the colour attachment written at shading_pass.frag.glsl:866-892):
+ * either vec4(final_color * exposure, 1) as RGBA32F or the sRGB-encoded 8-bit colour
+ * as packed RGB8.
+ *
+ * Host code is plain C; RCCL is bound at run time (dlopen of librccl.so.1, or the
+ * library named by VKR_RCCL_LIBRARY), so that single-GPU users of libvkr_shading.so
+ * need no RCCL.  One process (or thread) per GPU:
+ *
+ *     slab_exchange_id_t id;                       // rank 0
+ *     get_slab_exchange_id(&id);                   //   ... broadcast it (MPI_Bcast, a file, a socket)
+ *     app.tile_schedule = (tile_schedule_t) {32, rank, rank_count, 0};
+ *     create_slab_exchange(&exchange, &app, &id, slab_format_rgba32f);
+ *     for (;;) render_and_exchange_frame(&app, &exchange, NULL);   // asynchronous, frames overlap
+ *     finish_slab_exchange(&app, &exchange);       // app.device.stream now sees the last frame
+ */
+#ifndef VKR_SLAB_EXCHANGE_H
+#define VKR_SLAB_EXCHANGE_H
+#include "vkr_shading_pass.h"
+
+typedef enum slab_format_e {
+	/*! 16 bytes per pixel: the radiance target as it is (render_targets_t.radiance) */
+	slab_format_rgba32f = 0,
+	/*! 3 bytes per pixel: the encoded output without its constant alpha (encode_slab_rgb8);
+		the frame is assembled as RGBA8 (render_targets_t.encoded) */
+	slab_format_rgb8 = 1,
+	slab_format_count
+} slab_format_t;
+
+/*! The rendezvous token of a communicator (an ncclUniqueId, 128 bytes): made by one
+	rank, handed to all ranks by whatever launched them */
+typedef struct slab_exchange_id_s {
+	char bytes[128];
+} slab_exchange_id_t;
+
+typedef struct slab_exchange_s {
+	/*! RCCL binding and communicator (internal) */
+	void* binding;
+	uint32_t rank, rank_count;
+	slab_format_t format;
+	/*! pixels of one rank's slab (get_slab_pixel_count(app, 0): all slabs are padded to it)
+		and bytes of it in the exchanged format */
+	uint64_t slab_pixel_count;
+	uint64_t send_bytes;
+	/*! one set of buffers per frame that may be in flight (at least two): the RGBA32F slab
+		the frame is shaded into, the slab in the exchanged format (the same buffer for
+		rgba32f) and the gathered slabs of all ranks */
+	uint32_t set_count, next_set;
+	void* slab_radiance[VKR_MAX_FRAMES_IN_FLIGHT];
+	void* send[VKR_MAX_FRAMES_IN_FLIGHT];
+	void* gathered[VKR_MAX_FRAMES_IN_FLIGHT];
+	/*! hipStream_t of the collectives and the scatter kernels (owned) */
+	void* stream;
+	/*! hipEvent_t per set: frame shaded (and encoded); frame assembled */
+	void* rendered[VKR_MAX_FRAMES_IN_FLIGHT];
+	void* assembled[VKR_MAX_FRAMES_IN_FLIGHT];
+	/*! timing events per set (render start, rendered, gather start, gathered, assembled) and
+		whether the set's most recent frame recorded them */
+	void* timing[VKR_MAX_FRAMES_IN_FLIGHT][5];
+	uint32_t timed[VKR_MAX_FRAMES_IN_FLIGHT];
+	/*! frames submitted so far; every timing_stride-th is timed (0 or 1: all) */
+	uint64_t frame_counter;
+	uint32_t timing_stride;
+	/*! where the most recent frame is assembled */
+	void* last_frame;
+} slab_exchange_t;
+
+/*! Creates the rendezvous token (ncclGetUniqueId).  Call on one rank. */
+VKR_API int get_slab_exchange_id(slab_exchange_id_t* id);
+/*! Joins the communicator (ncclCommInitRank with app->tile_schedule.rank / rank_count;
+	collective: returns when all ranks have joined) and allocates the buffer sets for the
+	current extent, tile schedule and app->shading_pass.frames_in_flight.  With one rank,
+	app->tile_schedule.slab_layout must be set.  Several ranks in one process: call from one
+	thread per GPU.  0 on success; prints the reason and cleans up otherwise. */
+VKR_API int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const slab_exchange_id_t* id, slab_format_t format);
+VKR_API void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app);
+/*! One frame of the multi-GPU pass, queued asynchronously: render_shading_pass() of this rank's
+	tiles into a slab (encoded on the same stream for rgb8), ncclAllGather of the slabs on the
+	exchange stream, scatter into `out_frame` (NULL: render_targets.radiance for rgba32f,
+	render_targets.encoded for rgb8).  The collective and the scatter of frame k overlap the
+	shading of frame k + 1; frames complete in order. */
+VKR_API int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, void* out_frame);
+/*! The collective alone: ncclAllGather of `send_bytes` bytes per rank from `send` into
+	`gathered` (rank-major) on hipStream_t `stream`, for callers that schedule the steps themselves */
+VKR_API int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered, void* stream);
+/*! Makes app->device.stream wait (on the device) for every frame submitted so far to be
+	assembled.  read_back_radiance() / read_back_encoded() / encode_output() then see that frame. */
+VKR_API int finish_slab_exchange(application_t* app, slab_exchange_t* exchange);
+/*! Durations in milliseconds of the most recent timed frame that has completed:
+	{shading (+ encoding) of the slab, all-gather, scatter into the frame}.  Blocks until that
+	frame is done.  Returns 0 if no frame has been timed yet, else 1. */
+VKR_API uint32_t get_slab_exchange_milliseconds(slab_exchange_t* exchange, float out_milliseconds[3]);
+
+#endif

@@ -10,7 +10,7 @@
  * GLSL leaves the precision of atan/acos/sin/cos/inversesqrt to the driver
  * (reference: src/shaders/polygon_sampling.glsl:79-82 quotes "at most 2 ulps" for
  * native atan on Turing).  Both modes here are within 2-3 ulp of the exact value
- * (tests/test_oracle_math.py).
+ * (tests/test_oracle_properties.py::test_deterministic_math_is_accurate).
  *
  * Everything must be compiled with -ffp-contract=off; fused operations appear
  * only where the GLSL says fma(). */

@@ -1,0 +1,222 @@
+"""The BVH builders (HIP kernels: binned SAH, LBVH; host: binned SAH), the two traversal
+layouts (binary threaded, four-wide with an LDS stack) and the multi-GPU slab exchange
+(RCCL behind the C-ABI, include/vkr_slab_exchange.h) on a real MI355X.
+
+Shadow rays are any-hit queries: whatever tree answers them, the frame must be the oracle's
+frame bit for bit (reference contract: ray-query semantics, shading_pass.frag.glsl:120-138)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_cases
+from helpers import DeviceBuffer, compare, oracle_render
+from vulkan_renderer_amd import experiments, renderer, synthetic
+
+pytestmark = pytest.mark.gpu
+
+BUILDERS = ["sah_device", "lbvh_device", "sah_host"]
+
+
+def render_config(dataset, config, width, height, builder="sah_device", binary_traversal=False, frames_in_flight=1, **overrides):
+    r = renderer.Renderer(binary_traversal=binary_traversal, frames_in_flight=frames_in_flight)
+    renderer.setup_config(r, config, dataset, width=width, height=height, acceleration_structure=builder, **overrides)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.render()
+    return r, r.read_radiance()
+
+
+@pytest.mark.parametrize("binary_traversal", [False, True], ids=["wide", "binary"])
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_every_builder_and_both_trees_give_the_oracle_frame(dataset, builder, binary_traversal):
+    r, image = render_config(dataset, 3, 256, 144, builder, binary_traversal)
+    structure = r.app.scene.acceleration_structure
+    assert structure.builder == renderer.BVH_BUILDER[builder] and structure.build_milliseconds > 0.0
+    assert structure.wide_nodes and 0 < structure.wide_node_count < structure.node_count
+    assert 3 <= structure.wide_stack_need <= 128
+    visibility = r.read_visibility()
+    rays = r.last_ray_count()
+    cpu, inputs, bvh = oracle_render(r, visibility=visibility, math_mode=1)
+    stats = compare(image, cpu)
+    # the same rays through both layouts: the wide tree must be a collapse of the binary one
+    wide, binary = r.traversal_statistics(True), r.traversal_statistics(False)
+    stack_need = int(structure.wide_stack_need)
+    r.close()
+    assert stats["bit_exact"], (builder, binary_traversal, stats)
+    assert rays > 0 and wide["rays"] == binary["rays"] == rays
+    assert wide["blocked_rays"] == binary["blocked_rays"]
+    assert wide["node_visits"] < binary["node_visits"]
+    assert wide["deepest_stack"] <= stack_need
+
+
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_primary_visibility_does_not_depend_on_the_builder(dataset, builder):
+    import oracle
+    r = renderer.Renderer()
+    renderer.setup_config(r, 2, dataset, width=320, height=180, acceleration_structure=builder)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    gpu = r.read_visibility()
+    inputs = r.host_inputs()
+    bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
+    cam = r.app.scene_specification.camera
+    cpu = oracle.primary_visibility(inputs["constants"], bvh, 320, 180, cam.near, cam.far)
+    r.close()
+    assert np.array_equal(gpu, cpu), "%d pixels differ" % int((gpu != cpu).sum())
+
+
+def test_device_sah_tree_is_as_good_as_the_host_tree_and_wide_visits_are_few(big_dataset):
+    """Same algorithm, same bins: the trees may differ where triangles tie, not in quality.  And
+    the point of the wide layout: a handful of dependent fetches per shadow ray."""
+    per_ray = {}
+    for builder in ("sah_device", "sah_host", "lbvh_device"):
+        r, _ = render_config(big_dataset, 3, 960, 540, builder)
+        binary, wide = r.traversal_statistics(False), r.traversal_statistics(True)
+        per_ray[builder] = (binary["node_visits"] / binary["rays"], wide["node_visits"] / wide["rays"], wide["boxes_tested"] / wide["rays"],
+                            r.app.scene.acceleration_structure.build_milliseconds, r.app.scene.acceleration_structure.wide_stack_need)
+        r.close()
+    print(per_ray)
+    assert abs(per_ray["sah_device"][0] - per_ray["sah_host"][0]) <= 0.05 * per_ray["sah_host"][0], per_ray
+    assert per_ray["sah_device"][1] <= 8.0, per_ray
+    assert per_ray["lbvh_device"][0] > per_ray["sah_device"][0], per_ray
+
+
+def test_full_size_config_3_is_bit_exact(big_dataset):
+    """BASELINE config 3 at its full size (1920x1080, 4 lights, 4 spp per technique, shadow rays)"""
+    r, image = render_config(big_dataset, 3, 1920, 1080, frames_in_flight=2)
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+    r.close()
+    stats = compare(image, cpu)
+    assert stats["bit_exact"] and stats["nan"] == 0, stats
+
+
+def test_error_display_frame_reports_no_rays_and_bad_settings_are_caught_at_render_time(dataset):
+    r = renderer.Renderer()
+    renderer.setup_config(r, 3, dataset, width=128, height=72, acceleration_structure=True)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.render()
+    assert r.last_ray_count() > 0
+    r.app.render_settings.error_display = 1  # diffuse backward error: the program returns before it samples
+    r.render()
+    assert r.last_ray_count() == 0
+    # an out-of-range strategy is legal only while an error display is really shown (experiment_list.c:107)
+    r.app.render_settings.error_display = 0
+    r.render()
+    assert r.last_ray_count() > 0
+    r.create_pass()
+    r.app.render_settings.sampling_strategies = 5
+    r.app.render_settings.error_display = 1
+    r.create_pass()
+    r.render()
+    r.app.render_settings.error_display = 0
+    assert r.lib.render_shading_pass(C.byref(r.app), None) == 1
+    r.app.render_settings.error_display = 1
+    r.app.render_settings.sample_count = 0
+    assert r.lib.render_shading_pass(C.byref(r.app), None) == 1
+    r.close()
+
+
+@pytest.mark.parametrize("frames_in_flight", [2, 3])
+def test_a_reader_of_the_target_is_ordered_between_two_frames_in_flight(dataset, frames_in_flight):
+    """render A, encode A on device->stream, render B into the same target: B's resolve must wait
+    for the encoding of A (and for A), although finish_frames() has cleared A's pending flag."""
+    r, _ = render_config(dataset, 3, 512, 288, frames_in_flight=frames_in_flight)
+    expected = {}
+    for exposure in (1.0, 7.0):
+        r.app.render_settings.exposure_factor = exposure
+        r.render()
+        expected[exposure] = r.read_encoded(False, 0)
+    assert not np.array_equal(expected[1.0], expected[7.0])
+    out = np.zeros((288, 512, 4), np.uint8)
+    for _ in range(20):
+        r.app.render_settings.exposure_factor = 1.0
+        r.render()
+        assert r.lib.encode_output(C.byref(r.app), 0) == 0  # asynchronous, reads the radiance target
+        r.app.render_settings.exposure_factor = 7.0
+        r.render()  # another frame stream, same target
+        assert r.lib.read_back_encoded(C.byref(r.app), out.ctypes.data) == 0
+        assert np.array_equal(out, expected[1.0])
+        assert np.array_equal(r.read_encoded(False, 0), expected[7.0])
+    r.close()
+
+
+@pytest.mark.parametrize("slab_format", ["rgba32f", "rgb8"])
+def test_slab_exchange_with_one_rank_reproduces_the_frame(dataset, slab_format):
+    """The whole multi-GPU chain on one GPU: slab layout, ncclAllGather through the C-ABI (a
+    communicator of one rank), scatter on the exchange stream, frames overlapping."""
+    r, _ = render_config(dataset, 3, 200, 120, frames_in_flight=2)
+    expected = {}
+    for exposure in (1.0, 2.0, 3.0):
+        r.app.render_settings.exposure_factor = exposure
+        r.render()
+        expected[exposure] = r.read_radiance() if slab_format == "rgba32f" else r.read_encoded(False, 0)
+    r.set_tiles(32, 0, 1, slab_layout=True)
+    r.create_exchange(r.exchange_id(), slab_format)
+    assert r.exchange.rank_count == 1 and r.exchange.slab_pixel_count == r.slab_pixel_count(0)
+    e = r.app.swapchain.extent
+    frames = [DeviceBuffer(e.width * e.height * (16 if slab_format == "rgba32f" else 4)) for _ in range(5)]
+    exposures = [1.0, 2.0, 3.0, 2.0, 1.0]
+    for exposure, frame in zip(exposures, frames):  # five frames, no synchronisation in between
+        r.app.render_settings.exposure_factor = exposure
+        r.render_and_exchange(frame.ptr.value)
+    r.finish_exchange()
+    r.sync()
+    for exposure, frame in zip(exposures, frames):
+        if slab_format == "rgba32f":
+            got = frame.download((e.height, e.width, 4), np.float32)
+            assert np.array_equal(got.view(np.uint32), expected[exposure].view(np.uint32)), exposure
+        else:
+            assert np.array_equal(frame.download((e.height, e.width, 4), np.uint8), expected[exposure]), exposure
+        frame.free()
+    # into the render targets, which read_back_* see after finish_slab_exchange()
+    r.app.render_settings.exposure_factor = 3.0
+    r.render_and_exchange(None)
+    r.finish_exchange()
+    if slab_format == "rgba32f":
+        assert np.array_equal(r.read_radiance().view(np.uint32), expected[3.0].view(np.uint32))
+    else:
+        out = np.zeros((e.height, e.width, 4), np.uint8)
+        assert r.lib.read_back_encoded(C.byref(r.app), out.ctypes.data) == 0
+        assert np.array_equal(out, expected[3.0])
+    stages = r.exchange_ms()
+    assert stages is not None and all(ms >= 0.0 for ms in stages)
+    r.destroy_exchange()
+    r.close()
+
+
+def test_exchange_refuses_a_frame_layout_and_a_changed_schedule(dataset):
+    r, _ = render_config(dataset, 2, 128, 72)
+    token = r.exchange_id()
+    with pytest.raises(RuntimeError):
+        r.create_exchange(token)  # one rank without slab_layout
+    r.set_tiles(32, 0, 1, slab_layout=True)
+    r.create_exchange(token)
+    r.set_tiles(16, 0, 1, slab_layout=True)
+    with pytest.raises(RuntimeError):
+        r.render_and_exchange(None)
+    r.destroy_exchange()
+    r.close()
+
+
+def test_c_program_tiles_an_experiment_over_the_gpus_of_the_node(tmp_path):
+    """vkr_multi_gpu (csrc/examples/vkr_multi_gpu.c): threads + RCCL behind the C-ABI; with one
+    GPU the communicator has one rank, the chain is the same"""
+    binary = os.path.join(os.path.dirname(renderer.__file__), "vkr_multi_gpu")
+    assert os.path.exists(binary), "run make -C vulkan_renderer_amd/csrc (build() does)"
+    root = str(tmp_path / "root")
+    made = experiments.write_synthetic_data_root(root, grid=64, box_count=16)
+    table = experiments.experiment_table()
+    index = next(i for i in range(table.count) if table.experiments[i].screenshot_path == b"data/experiments/mis_plane_clamped_optimal_ours_2spp_%.3f.png")
+    for slab_format in ("rgba32f", "rgb8"):
+        done = subprocess.run([binary, "--gpus", "1", "-e%d" % index, "--frames", "12", "--format", slab_format, "--white-noise",
+                               "--fresnel", str(made["fresnel_count"]), root], capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0, done.stdout + done.stderr
+        assert "0 values differ from the single-GPU frame" in done.stdout, done.stdout
+    assert os.path.exists(os.path.join(root, "data", "multi_gpu.png"))

@@ -77,7 +77,9 @@ class Materials(C.Structure):
 class AccelerationStructure(C.Structure):
     _fields_ = [("triangle_vertices", C.c_void_p), ("triangle_indices", C.c_void_p), ("nodes", C.c_void_p),
                 ("node_count", C.c_uint32), ("root", C.c_uint32),
-                ("grid_origin", C.c_float * 3), ("grid_inverse_cell", C.c_float * 3)]
+                ("grid_origin", C.c_float * 3), ("grid_inverse_cell", C.c_float * 3),
+                ("wide_nodes", C.c_void_p), ("wide_node_count", C.c_uint32), ("wide_stack_need", C.c_uint32),
+                ("builder", C.c_uint32), ("build_milliseconds", C.c_float)]
 
 
 class Scene(C.Structure):
@@ -123,7 +125,7 @@ class Screenshot(C.Structure):
 
 
 class TileSchedule(C.Structure):
-    _fields_ = [("tile_size", C.c_uint32), ("rank", C.c_uint32), ("rank_count", C.c_uint32)]
+    _fields_ = [("tile_size", C.c_uint32), ("rank", C.c_uint32), ("rank_count", C.c_uint32), ("slab_layout", C.c_uint32)]
 
 
 class LightTextures(C.Structure):
@@ -135,7 +137,7 @@ class ShadingPass(C.Structure):
     _fields_ = [("use_ray_tracing", C.c_uint32), ("variant", C.c_int32), ("max_polygon_vertex_count", C.c_uint32),
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t), ("constants_ring", C.c_void_p),
                 ("fast_math", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("last_frame_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("pixel_materials", C.c_void_p), ("pixel_materials_size", C.c_size_t), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
-                ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32)]
+                ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32), ("last_frame_traced_rays", C.c_uint32), ("binary_traversal", C.c_int32)]
 
 
 class Application(C.Structure):
@@ -156,9 +158,29 @@ class ExperimentList(C.Structure):
                 ("frame_index", C.c_uint32), ("state", C.c_int32)]
 
 
+MAX_FRAMES_IN_FLIGHT = 4  # VKR_MAX_FRAMES_IN_FLIGHT
+
+
+class SlabExchangeId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
+class SlabExchange(C.Structure):
+    _fields_ = [("binding", C.c_void_p), ("rank", C.c_uint32), ("rank_count", C.c_uint32), ("format", C.c_int32),
+                ("slab_pixel_count", C.c_uint64), ("send_bytes", C.c_uint64), ("set_count", C.c_uint32), ("next_set", C.c_uint32),
+                ("slab_radiance", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("send", C.c_void_p * MAX_FRAMES_IN_FLIGHT),
+                ("gathered", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("stream", C.c_void_p),
+                ("rendered", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("assembled", C.c_void_p * MAX_FRAMES_IN_FLIGHT),
+                ("timing", (C.c_void_p * 5) * MAX_FRAMES_IN_FLIGHT), ("timed", C.c_uint32 * MAX_FRAMES_IN_FLIGHT),
+                ("frame_counter", C.c_uint64), ("timing_stride", C.c_uint32), ("last_frame", C.c_void_p)]
+
+
+SLAB_FORMAT = {"rgba32f": 0, "rgb8": 1}
+
 ABI_STRUCTS = [Device, PolygonalLight, Camera, LtcConstants, LtcTable, NoiseTable, Mesh, Materials,
                AccelerationStructure, Scene, SceneSpecification, RenderSettings, PerFrameConstants, Swapchain,
-               RenderTargets, Screenshot, TileSchedule, LightTextures, ShadingPass, Application, Experiment, ExperimentList]
+               RenderTargets, Screenshot, TileSchedule, LightTextures, ShadingPass, Application, Experiment, ExperimentList,
+               SlabExchangeId, SlabExchange]
 
 # every symbol include/*.h declares, with (restype, argtypes)
 P = C.POINTER
@@ -222,6 +244,7 @@ SIGNATURES = {
     "finish_frames": (C.c_int, [P(Application)]),
     "mark_inputs_changed": (None, [P(Application)]),
     "get_slab_pixel_coordinates": (C.c_uint64, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
+    "get_traversal_statistics_of_tree": (C.c_int, [P(Application), C.c_uint32, P(C.c_uint64)]),
     "get_abi_struct_sizes": (C.c_uint32, [P(C.c_uint64), C.c_uint32]),
     "create_experiment_list": (None, [P(ExperimentList)]),
     "destroy_experiment_list": (None, [P(ExperimentList)]),
@@ -231,6 +254,13 @@ SIGNATURES = {
     "write_png_rgb8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "write_hdr_rgb32f": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "take_screenshot": (C.c_int, [P(Application), C.c_char_p, C.c_char_p]),
+    "get_slab_exchange_id": (C.c_int, [P(SlabExchangeId)]),
+    "create_slab_exchange": (C.c_int, [P(SlabExchange), P(Application), P(SlabExchangeId), C.c_int]),
+    "destroy_slab_exchange": (None, [P(SlabExchange), P(Application)]),
+    "render_and_exchange_frame": (C.c_int, [P(Application), P(SlabExchange), C.c_void_p]),
+    "all_gather_slabs": (C.c_int, [P(SlabExchange), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finish_slab_exchange": (C.c_int, [P(Application), P(SlabExchange)]),
+    "get_slab_exchange_milliseconds": (C.c_uint32, [P(SlabExchange), P(C.c_float)]),
 }
 
 _lib = None

@@ -3,6 +3,7 @@
  * helpers :173-216, defaults :232-249, quick_save/quick_load :49-130). */
 #include "vkr_internal.h"
 #include "vkr_experiments.h"
+#include "vkr_slab_exchange.h"
 
 /* Cofactor inverse with the term order of reference math_utilities.h:24-47:
    entry (i, j) is (-1)^(i+j) times the 3x3 minor without row j and column i,
@@ -289,7 +290,8 @@ VKR_API uint32_t get_abi_struct_sizes(uint64_t* sizes, uint32_t capacity) {
 		sizeof(ltc_table_t), sizeof(noise_table_t), sizeof(mesh_t), sizeof(materials_t), sizeof(acceleration_structure_t),
 		sizeof(scene_t), sizeof(scene_specification_t), sizeof(render_settings_t), sizeof(per_frame_constants_t),
 		sizeof(swapchain_t), sizeof(render_targets_t), sizeof(screenshot_t), sizeof(tile_schedule_t), sizeof(light_textures_t),
-		sizeof(shading_pass_t), sizeof(application_t), sizeof(experiment_t), sizeof(experiment_list_t)};
+		sizeof(shading_pass_t), sizeof(application_t), sizeof(experiment_t), sizeof(experiment_list_t),
+		sizeof(slab_exchange_id_t), sizeof(slab_exchange_t)};
 	uint32_t count = (uint32_t) VKR_COUNT_OF(all);
 	for (uint32_t i = 0; i != count && i != capacity; ++i) sizes[i] = all[i];
 	return count;

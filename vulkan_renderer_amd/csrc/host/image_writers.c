@@ -36,19 +36,19 @@ static int bytes_put(bytes_t* b, uint8_t value) { return bytes_append(b, &value,
 
 /* ---- checksums ------------------------------------------------------------------- */
 
+/* CRC-32 (polynomial 0xEDB88320) of one byte, four bits at a time: a 16-entry constant table,
+ * so there is no lazily initialised state that two contexts could race on. */
+static const uint32_t crc32_nibble_table[16] = {
+	0x00000000u, 0x1DB71064u, 0x3B6E20C8u, 0x26D930ACu, 0x76DC4190u, 0x6B6B51F4u, 0x4DB26158u, 0x5005713Cu,
+	0xEDB88320u, 0xF00F9344u, 0xD6D6A3E8u, 0xCB61B38Cu, 0x9B64C2B0u, 0x86D3D2D4u, 0xA00AE278u, 0xBDBDF21Cu};
+
 static uint32_t crc32_update(uint32_t crc, const uint8_t* data, size_t count) {
-	static uint32_t table[256];
-	static int ready = 0;
-	if (!ready) {
-		for (uint32_t n = 0; n != 256; ++n) {
-			uint32_t c = n;
-			for (int k = 0; k != 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-			table[n] = c;
-		}
-		ready = 1;
-	}
 	crc = ~crc;
-	for (size_t i = 0; i != count; ++i) crc = table[(crc ^ data[i]) & 0xFF] ^ (crc >> 8);
+	for (size_t i = 0; i != count; ++i) {
+		crc ^= data[i];
+		crc = crc32_nibble_table[crc & 0xF] ^ (crc >> 4);
+		crc = crc32_nibble_table[crc & 0xF] ^ (crc >> 4);
+	}
 	return ~crc;
 }
 

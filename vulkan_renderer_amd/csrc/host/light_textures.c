@@ -44,6 +44,10 @@ static int load_level_0_rgba32f(float** out_texels, uint32_t* out_width, uint32_
 		vkr_fill_srgb_table(srgb_table);
 		uint64_t count = (uint64_t) texture.width * texture.height;
 		float* texels = (float*) malloc(count * 4 * sizeof(float));
+		if (!texels) {
+			vkr_free_host_texture(&texture);
+			return 2;
+		}
 		for (uint64_t i = 0; i != count; ++i) {
 			for (uint32_t c = 0; c != 3; ++c)
 				texels[4 * i + c] = texture.srgb ? srgb_table[texture.texels[4 * i + c]] : (float) texture.texels[4 * i + c] / 255.0f;
@@ -74,6 +78,10 @@ static int load_level_0_rgba32f(float** out_texels, uint32_t* out_width, uint32_
 		return 2;
 	}
 	float* texels = (float*) malloc(count * 4 * sizeof(float));
+	if (!texels) {
+		free(raw);
+		return 2;
+	}
 	for (uint64_t i = 0; i != count; ++i) {
 		for (uint32_t c = 0; c != 4; ++c) {
 			float value = 1.0f;
@@ -106,6 +114,7 @@ int create_and_assign_light_textures(light_textures_t* light_textures, const dev
 	/* the list of distinct paths; absent files fall back to white like in the reference */
 	uint32_t light_count = scene_specification->polygonal_light_count;
 	const char** unique_paths = (const char**) malloc(sizeof(char*) * (light_count + 1));
+	if (!unique_paths) return 1;
 	uint32_t unique_count = 0;
 	for (uint32_t i = 0; i != light_count; ++i) {
 		polygonal_light_t* light = &scene_specification->polygonal_lights[i];
@@ -132,6 +141,11 @@ int create_and_assign_light_textures(light_textures_t* light_textures, const dev
 	if (unique_count == 0) unique_paths[unique_count++] = g_default_path;
 	light_textures->texture_count = unique_count;
 	light_textures->host_descriptors = (uint32_t(*)[4]) calloc(unique_count, sizeof(uint32_t[4]));
+	if (!light_textures->host_descriptors) {
+		free(unique_paths);
+		destroy_light_textures(light_textures, device);
+		return 1;
+	}
 	for (uint32_t i = 0; i != unique_count; ++i) {
 		if (unique_paths[i] == g_default_path) continue;
 		float* texels;
@@ -143,7 +157,15 @@ int create_and_assign_light_textures(light_textures_t* light_textures, const dev
 			return 1;
 		}
 		uint64_t count = (uint64_t) width * height;
-		light_textures->host_texels = (float*) realloc(light_textures->host_texels, (light_textures->texel_count + count) * 4 * sizeof(float));
+		float* grown = (float*) realloc(light_textures->host_texels, (light_textures->texel_count + count) * 4 * sizeof(float));
+		if (!grown) {
+			printf("Out of memory for the light texture at path %s.\n", unique_paths[i]);
+			free(texels);
+			free(unique_paths);
+			destroy_light_textures(light_textures, device);
+			return 1;
+		}
+		light_textures->host_texels = grown;
 		memcpy(light_textures->host_texels + 4 * light_textures->texel_count, texels, count * 4 * sizeof(float));
 		free(texels);
 		light_textures->host_descriptors[i][0] = (uint32_t) light_textures->texel_count;

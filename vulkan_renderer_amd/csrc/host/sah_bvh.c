@@ -2,10 +2,11 @@
  *
  * The reference asks the driver for a PREFER_FAST_TRACE acceleration structure once
  * per scene (reference src/scene.c:254-262); the equivalent here is a surface-area-
- * heuristic build on the host when the scene is loaded.  It writes exactly the layout
- * that csrc/lbvh.h walks (and that the Morton-code builder in lbvh_build.hip also
- * produces): 2n-1 nodes of 32 bytes in depth-first order, one triangle per leaf,
- * triangles as three float4 in leaf order.
+ * heuristic build on the host when the scene is loaded.  It writes the intermediate layout
+ * that every builder of lbvh_build.hip produces: 2n-1 fp32 nodes of 32 bytes (lo.xyz, hi.xyz,
+ * skip, leaf slot) in depth-first order, one triangle per leaf, triangles as three float4 in
+ * leaf order.  That is NOT what the kernels walk: the device code quantises these nodes
+ * afterwards into the traversal layouts of csrc/lbvh.h (mandatory second step).
  *
  * Why it matters: in scenes with a large floor the Morton-code tree mixes floor and
  * objects down to small cells, so every ray that leaves the floor descends ten

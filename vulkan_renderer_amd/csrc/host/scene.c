@@ -154,10 +154,12 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 	printf("Triangle count: %llu\n", (unsigned long long) mesh->triangle_count);
 	uint64_t material_count = scene->materials.material_count;
 	scene->materials.material_names = (char**) calloc(material_count ? material_count : 1, sizeof(char*));
+	if (!scene->materials.material_names) { header_ok = 0; material_count = 0; }
 	for (uint64_t i = 0; i != material_count; ++i) {
 		uint64_t length = 0;
 		if (fread(&length, sizeof(length), 1, file) != 1 || length > 4096) { header_ok = 0; break; }
 		scene->materials.material_names[i] = (char*) calloc(length + 1, 1);
+		if (!scene->materials.material_names[i]) { header_ok = 0; break; }
 		if (fread(scene->materials.material_names[i], 1, length + 1, file) != length + 1) { header_ok = 0; break; }
 		scene->materials.material_names[i][length] = 0;
 	}
@@ -167,7 +169,8 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 	mesh->host_normals_and_tex_coords = (uint16_t*) malloc(sizeof(uint16_t) * 4 * vertex_count);
 	mesh->host_material_indices = (uint8_t*) malloc(mesh->triangle_count);
 	uint32_t eof_marker = 0;
-	header_ok = header_ok
+	/* (sizes come from the file: an allocation may fail) */
+	header_ok = header_ok && mesh->host_positions && mesh->host_normals_and_tex_coords && mesh->host_material_indices
 		&& fread(mesh->host_positions, sizeof(uint32_t) * 2, vertex_count, file) == vertex_count
 		&& fread(mesh->host_normals_and_tex_coords, sizeof(uint16_t) * 4, vertex_count, file) == vertex_count
 		&& fread(mesh->host_material_indices, 1, mesh->triangle_count, file) == mesh->triangle_count
@@ -187,6 +190,11 @@ int load_scene(scene_t* scene, const device_t* device, const char* file_path, co
 	/* material constants */
 	scene->materials.host_constants = (float*) malloc(sizeof(float) * 8 * (material_count ? material_count : 1));
 	scene->materials.host_texture_descriptors = (uint32_t*) calloc(12 * (material_count ? material_count : 1), sizeof(uint32_t));
+	if (!scene->materials.host_constants || !scene->materials.host_texture_descriptors) {
+		printf("Out of memory for the materials of the scene file at path %s.\n", file_path);
+		destroy_scene(scene, device);
+		return 1;
+	}
 	for (uint64_t i = 0; i != material_count; ++i) {
 		float* k = scene->materials.host_constants + 8 * i;
 		const float defaults[8] = {0.8f, 0.8f, 0.8f, 1.0f, 0.5f, 0.0f, 0.5f, 0.5f};

@@ -1,0 +1,223 @@
+/* Multi-GPU exchange of the shading pass (include/vkr_slab_exchange.h): shade this rank's
+ * tiles -> ncclAllGather of the slabs over xGMI -> scatter into the frame, one frame after the
+ * other without the host ever waiting.  Plain C on top of the HIP runtime's C API; RCCL is bound
+ * with dlopen so that libvkr_shading.so itself does not depend on it.
+ *
+ * Streams of one frame k (buffer set b = k mod set_count):
+ *   frame stream (the pass's own, render_shading_pass)   shade, trace, resolve [, encode] -> rendered[b]
+ *   exchange stream (owned by the exchange)              wait rendered[b], all-gather, scatter -> assembled[b]
+ * and the frame that reuses set b waits for assembled[b] before it starts, so the collective of
+ * frame k runs while frame k + 1 is shaded.  Contract: BASELINE.json configs[3], SURVEY.md 8(e). */
+#include "vkr_internal.h"
+#include "vkr_slab_exchange.h"
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+typedef struct rccl_binding_s {
+	void* library;
+	__typeof__(&ncclGetUniqueId) get_unique_id;
+	__typeof__(&ncclCommInitRank) comm_init_rank;
+	__typeof__(&ncclCommDestroy) comm_destroy;
+	__typeof__(&ncclAllGather) all_gather;
+	__typeof__(&ncclGetErrorString) get_error_string;
+	ncclComm_t communicator;
+} rccl_binding_t;
+
+static int hip_failed(hipError_t error, const char* what) {
+	if (error == hipSuccess) return 0;
+	printf("HIP error while %s: %s\n", what, hipGetErrorString(error));
+	return 1;
+}
+
+/* Binds the handful of RCCL entry points the exchange uses.  A process that already holds an
+   RCCL (PyTorch brings its own copy) gets that one: the loader matches the soname. */
+static int bind_rccl(rccl_binding_t* binding) {
+	memset(binding, 0, sizeof(*binding));
+	const char* requested = getenv("VKR_RCCL_LIBRARY");
+	const char* candidates[] = {requested, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	for (uint32_t i = 0; i != VKR_COUNT_OF(candidates) && !binding->library; ++i)
+		if (candidates[i] && candidates[i][0]) binding->library = dlopen(candidates[i], RTLD_NOW | RTLD_LOCAL);
+	if (!binding->library) {
+		printf("The multi-GPU exchange needs RCCL, but librccl.so.1 could not be loaded (%s). Set VKR_RCCL_LIBRARY to its path.\n", dlerror());
+		return 1;
+	}
+	*(void**) &binding->get_unique_id = dlsym(binding->library, "ncclGetUniqueId");
+	*(void**) &binding->comm_init_rank = dlsym(binding->library, "ncclCommInitRank");
+	*(void**) &binding->comm_destroy = dlsym(binding->library, "ncclCommDestroy");
+	*(void**) &binding->all_gather = dlsym(binding->library, "ncclAllGather");
+	*(void**) &binding->get_error_string = dlsym(binding->library, "ncclGetErrorString");
+	if (!binding->get_unique_id || !binding->comm_init_rank || !binding->comm_destroy || !binding->all_gather || !binding->get_error_string) {
+		printf("The RCCL library lacks one of ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclGetErrorString.\n");
+		dlclose(binding->library);
+		memset(binding, 0, sizeof(*binding));
+		return 1;
+	}
+	return 0;
+}
+
+static int rccl_failed(const rccl_binding_t* binding, ncclResult_t result, const char* what) {
+	if (result == ncclSuccess) return 0;
+	printf("RCCL error while %s: %s\n", what, binding->get_error_string(result));
+	return 1;
+}
+
+int get_slab_exchange_id(slab_exchange_id_t* id) {
+	memset(id, 0, sizeof(*id));
+	rccl_binding_t binding;
+	if (bind_rccl(&binding)) return 1;
+	ncclUniqueId unique;
+	_Static_assert(sizeof(ncclUniqueId) <= sizeof(slab_exchange_id_t), "slab_exchange_id_t must hold an ncclUniqueId");
+	int failed = rccl_failed(&binding, binding.get_unique_id(&unique), "creating the rendezvous token");
+	if (!failed) memcpy(id->bytes, &unique, sizeof(unique));
+	/* (the library stays loaded: RCCL keeps the bootstrap thread of the token alive in it) */
+	return failed;
+}
+
+void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
+	/* frames in flight and collectives still use the buffers that are freed below */
+	if (exchange->stream) (void) hipStreamSynchronize((hipStream_t) exchange->stream);
+	if (app && app->shading_pass.wavefront) (void) wait_for_device(&app->device);
+	rccl_binding_t* binding = (rccl_binding_t*) exchange->binding;
+	if (binding) {
+		if (binding->communicator) (void) binding->comm_destroy(binding->communicator);
+		free(binding);
+	}
+	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT; ++b) {
+		if (exchange->send[b] && exchange->send[b] != exchange->slab_radiance[b]) (void) hipFree(exchange->send[b]);
+		if (exchange->slab_radiance[b]) (void) hipFree(exchange->slab_radiance[b]);
+		if (exchange->gathered[b]) (void) hipFree(exchange->gathered[b]);
+		if (exchange->rendered[b]) (void) hipEventDestroy((hipEvent_t) exchange->rendered[b]);
+		if (exchange->assembled[b]) (void) hipEventDestroy((hipEvent_t) exchange->assembled[b]);
+		for (uint32_t i = 0; i != 5; ++i)
+			if (exchange->timing[b][i]) (void) hipEventDestroy((hipEvent_t) exchange->timing[b][i]);
+	}
+	if (exchange->stream) (void) hipStreamDestroy((hipStream_t) exchange->stream);
+	memset(exchange, 0, sizeof(*exchange));
+}
+
+int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const slab_exchange_id_t* id, slab_format_t format) {
+	memset(exchange, 0, sizeof(*exchange));
+	const tile_schedule_t* schedule = &app->tile_schedule;
+	uint32_t rank_count = schedule->rank_count > 1 ? schedule->rank_count : 1;
+	if ((int) format < 0 || format >= slab_format_count || schedule->rank >= rank_count || (rank_count == 1 && !schedule->slab_layout)) {
+		printf("create_slab_exchange() needs a slab format, a rank below the rank count and, with a single rank, tile_schedule.slab_layout.\n");
+		return 1;
+	}
+	exchange->rank = schedule->rank;
+	exchange->rank_count = rank_count;
+	exchange->format = format;
+	exchange->slab_pixel_count = get_slab_pixel_count(app, 0);
+	exchange->send_bytes = exchange->slab_pixel_count * (format == slab_format_rgba32f ? 16u : 3u);
+	exchange->timing_stride = app->shading_pass.timing_stride;
+	uint32_t sets = app->shading_pass.frames_in_flight;
+	if (sets < 2) sets = 2;
+	if (sets > VKR_MAX_FRAMES_IN_FLIGHT) sets = VKR_MAX_FRAMES_IN_FLIGHT;
+	exchange->set_count = sets;
+	if (hip_failed(hipSetDevice(app->device.hip_device), "selecting the device")) return 1;
+	rccl_binding_t* binding = (rccl_binding_t*) calloc(1, sizeof(rccl_binding_t));
+	exchange->binding = binding;
+	if (!binding || bind_rccl(binding)) {
+		destroy_slab_exchange(exchange, app);
+		return 1;
+	}
+	ncclUniqueId unique;
+	memcpy(&unique, id->bytes, sizeof(unique));
+	if (rccl_failed(binding, binding->comm_init_rank(&binding->communicator, (int) rank_count, unique, (int) exchange->rank), "joining the communicator")) {
+		binding->communicator = NULL;
+		destroy_slab_exchange(exchange, app);
+		return 1;
+	}
+	int failed = hip_failed(hipStreamCreateWithFlags((hipStream_t*) &exchange->stream, hipStreamNonBlocking), "creating the exchange stream");
+	for (uint32_t b = 0; b != sets && !failed; ++b) {
+		failed = hip_failed(hipMalloc(&exchange->slab_radiance[b], exchange->slab_pixel_count * 16u), "allocating a slab")
+			|| hip_failed(hipMalloc(&exchange->gathered[b], exchange->send_bytes * rank_count), "allocating the gathered slabs")
+			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->rendered[b], hipEventDisableTiming), "creating events")
+			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->assembled[b], hipEventDisableTiming), "creating events");
+		if (!failed && format == slab_format_rgba32f) exchange->send[b] = exchange->slab_radiance[b];
+		else if (!failed) failed = hip_failed(hipMalloc(&exchange->send[b], exchange->send_bytes), "allocating an encoded slab");
+		for (uint32_t i = 0; i != 5 && !failed; ++i)
+			failed = hip_failed(hipEventCreate((hipEvent_t*) &exchange->timing[b][i]), "creating timing events");
+		/* padding slots of the last tile row / column are never written by the kernels */
+		if (!failed) failed = hip_failed(hipMemset(exchange->slab_radiance[b], 0, exchange->slab_pixel_count * 16u), "clearing a slab");
+	}
+	if (failed) {
+		destroy_slab_exchange(exchange, app);
+		return 1;
+	}
+	return 0;
+}
+
+int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered, void* stream) {
+	rccl_binding_t* binding = (rccl_binding_t*) exchange->binding;
+	if (!binding || !binding->communicator) {
+		printf("all_gather_slabs() needs an exchange made by create_slab_exchange().\n");
+		return 1;
+	}
+	/* bytes, so that both formats share one call; slabs are multiples of 256 pixels, i.e. of 16 bytes */
+	return rccl_failed(binding, binding->all_gather(send, gathered, (size_t) exchange->send_bytes, ncclUint8, binding->communicator, (hipStream_t) stream), "gathering the slabs");
+}
+
+int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, void* out_frame) {
+	if (!exchange->binding || exchange->slab_pixel_count != get_slab_pixel_count(app, 0)
+		|| exchange->rank != app->tile_schedule.rank || exchange->rank_count != (app->tile_schedule.rank_count > 1 ? app->tile_schedule.rank_count : 1))
+	{
+		printf("The slab exchange does not match the tile schedule or extent. Recreate it.\n");
+		return 1;
+	}
+	uint32_t b = exchange->next_set;
+	exchange->next_set = (b + 1) % exchange->set_count;
+	int timed = exchange->timing_stride <= 1 || exchange->frame_counter % exchange->timing_stride == 0;
+	int reused = exchange->frame_counter >= exchange->set_count;
+	++exchange->frame_counter;
+	hipStream_t exchange_stream = (hipStream_t) exchange->stream;
+	/* the stream this frame will run on: the set's previous frame must have left the buffers */
+	hipStream_t frame_stream = (hipStream_t) get_next_frame_stream(app);
+	if (reused && hip_failed(hipStreamWaitEvent(frame_stream, (hipEvent_t) exchange->assembled[b], 0), "waiting for the buffers of an earlier frame")) return 1;
+	/* (an untimed frame leaves the set's timing events alone: they keep the last timed frame) */
+	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][0], frame_stream);
+	int failed = exchange->format == slab_format_rgb8
+		? render_shading_pass_encoded(app, exchange->slab_radiance[b], exchange->send[b])
+		: render_shading_pass(app, exchange->slab_radiance[b]);
+	if (failed) return 1;
+	/* (render_shading_pass falls back to device->stream when it cannot pipeline: ask again) */
+	hipStream_t used_stream = app->shading_pass.last_frame_in_flight ? frame_stream : (hipStream_t) app->device.stream;
+	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][1], used_stream);
+	if (hip_failed(hipEventRecord((hipEvent_t) exchange->rendered[b], used_stream), "marking the frame")
+		|| hip_failed(hipStreamWaitEvent(exchange_stream, (hipEvent_t) exchange->rendered[b], 0), "waiting for the frame"))
+		return 1;
+	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][2], exchange_stream);
+	if (all_gather_slabs(exchange, exchange->send[b], exchange->gathered[b], exchange_stream)) return 1;
+	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][3], exchange_stream);
+	void* target = out_frame ? out_frame : (exchange->format == slab_format_rgba32f ? app->render_targets.radiance : app->render_targets.encoded);
+	if (vkr_assemble_slabs_on_stream(app, exchange->gathered[b], target, (int) exchange->format, exchange_stream)) return 1;
+	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][4], exchange_stream);
+	if (timed) exchange->timed[b] = 1;
+	exchange->last_frame = target;
+	return hip_failed(hipEventRecord((hipEvent_t) exchange->assembled[b], exchange_stream), "marking the assembled frame");
+}
+
+int finish_slab_exchange(application_t* app, slab_exchange_t* exchange) {
+	if (!exchange->frame_counter) return 0;
+	/* the exchange stream completes frames in order: the most recent set is the last one */
+	uint32_t last = (exchange->next_set + exchange->set_count - 1) % exchange->set_count;
+	return finish_frames(app)
+		|| hip_failed(hipStreamWaitEvent((hipStream_t) app->device.stream, (hipEvent_t) exchange->assembled[last], 0), "waiting for the assembled frame");
+}
+
+uint32_t get_slab_exchange_milliseconds(slab_exchange_t* exchange, float out_milliseconds[3]) {
+	out_milliseconds[0] = out_milliseconds[1] = out_milliseconds[2] = 0.0f;
+	/* newest timed set first */
+	for (uint32_t i = 0; i != exchange->set_count; ++i) {
+		uint32_t b = (exchange->next_set + 2 * exchange->set_count - 1 - i) % exchange->set_count;
+		if (!exchange->timed[b]) continue;
+		hipEvent_t* e = (hipEvent_t*) exchange->timing[b];
+		if (hipEventSynchronize(e[4]) != hipSuccess) return 0;
+		if (hipEventElapsedTime(&out_milliseconds[0], e[0], e[1]) != hipSuccess
+			|| hipEventElapsedTime(&out_milliseconds[1], e[2], e[3]) != hipSuccess
+			|| hipEventElapsedTime(&out_milliseconds[2], e[3], e[4]) != hipSuccess)
+			return 0;
+		return 1;
+	}
+	return 0;
+}

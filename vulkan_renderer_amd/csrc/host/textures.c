@@ -119,7 +119,12 @@ int vkr_load_texture_rgba8(vkr_host_texture_t* out, const char* path) {
 		free(payload);
 		return 2;
 	}
-	out->texels = (uint8_t*) malloc(4 * texel_count);
+	out->texels = (uint8_t*) malloc(texel_count ? 4 * texel_count : 1);
+	if (!out->texels) {
+		printf("Out of memory while decoding the texture file at path %s.\n", path);
+		free(payload);
+		return 2;
+	}
 	out->width = widths[0]; out->height = heights[0]; out->mip_count = (uint32_t) mip_count;
 	out->srgb = format == format_r8g8b8a8_srgb || format == format_bc1_rgb_srgb || format == format_bc1_rgba_srgb;
 	out->texel_count = texel_count;
@@ -129,7 +134,8 @@ int vkr_load_texture_rgba8(vkr_host_texture_t* out, const char* path) {
 		const uint8_t* source = payload + offsets[m];
 		uint64_t block_bytes = is_bc5 ? 16 : 8;
 		uint64_t needed = is_rgba8 ? 4ull * w * h : block_bytes * ((w + 3) / 4) * ((h + 3) / 4);
-		if (offsets[m] + needed > payload_size || sizes[m] < needed) { ok = 0; break; }
+		/* (written so that a crafted offset near 2^64 cannot wrap the sum) */
+		if (offsets[m] > payload_size || needed > payload_size - offsets[m] || sizes[m] < needed) { ok = 0; break; }
 		if (is_rgba8) memcpy(target, source, 4ull * w * h);
 		else
 			for (uint32_t by = 0; by != (h + 3) / 4; ++by)

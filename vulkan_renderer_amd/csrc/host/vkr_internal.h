@@ -48,14 +48,16 @@ void vkr_matrix_inverse(float inverse[4][4], const float matrix[4][4]);
 /*! reference math_utilities.h:50-57 */
 uint32_t vkr_wang_random_number(uint32_t seed);
 
-/*! Builds the threaded BVH (csrc/lbvh.h) over the mesh.  builder 1: surface-area
-	heuristic on the host (sah_bvh.c; best traversal), builder 2: Morton-code LBVH on the
-	device (lbvh_build.hip; build time about a millisecond).  The environment variable
-	VKR_BVH_BUILDER=sah|lbvh overrides the argument. */
+/*! Builds the BVH over the mesh with the given acceleration_structure_builder_t
+	(include/vkr_scene.h) and derives both traversal layouts of csrc/lbvh.h from it */
 int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh, int builder);
 /*! sah_bvh.c: malloc'ed nodes (8 floats each, depth-first) and triangles (12 floats per leaf slot) */
 int vkr_build_sah_bvh_host(const mesh_t* mesh, float pad, float** out_nodes, float** out_triangles, uint32_t* out_node_count);
 void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, const device_t* device);
+
+/*! shading_pass.hip: scatters all-gathered slabs (format: slab_format_t of vkr_slab_exchange.h)
+	into a frame on the given hipStream_t */
+int vkr_assemble_slabs_on_stream(application_t* app, const void* gathered_slabs, void* out_frame, int format, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,10 @@
 // ray-query semantics: opaque geometry, first hit terminates, no face culling,
 // t in [t_min, t_max], triangle soup de-quantised like scene.c:176-187.
 //
+// Two layouts are built from the same binary tree.  The wavefront shadow-ray kernel walks the
+// four-wide one (further down: "wide BVH"), everything else (primary visibility, rays traced
+// inside the shading kernel) the binary one:
+//
 // Layout in HBM ("threaded" BVH): all 2n-1 nodes of the binary tree, inner nodes and
 // leaves alike, stored in depth-first order as 16 bytes each:
 //     uint4 = (lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16, link)
@@ -121,6 +125,29 @@ VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) 
 		node = (hit || is_leaf) ? node + 1 : n.w;
 	}
 	return false;
+}
+
+// ---- wide BVH -------------------------------------------------------------------------
+// The binary tree collapsed to four children per node (lbvh_build.hip k_collapse_level: a node's
+// two children, then twice the child with the largest box replaced by its own children).  One node
+// is 64 bytes = one half cache line, fetched with four dwordx4 loads:
+//     uint4 x = (lo.x | hi.x << 16) of children 0..3      (same 16-bit grid as the binary nodes)
+//     uint4 y, uint4 z likewise
+//     uint4 link: child is an inner node -> its index; a triangle -> kLeafBit | triangle slot;
+//                 absent -> kWideEmpty
+// The children of a node are stored next to each other and levels one after the other, so the
+// first nodes of the array are the top of the tree.  A visit tests four boxes with one dependent
+// fetch, which shortens the chain of dependent fetches per ray four- to fivefold against the
+// binary walk (profiles/).  Hit children beyond the first go to a per-lane stack: 16 entries in
+// LDS ([entry][thread], conflict-free), deeper ones - the build computes the worst case,
+// acceleration_structure_t.wide_stack_need - spill to global memory.  Any-hit queries are
+// order-independent, so the result (a boolean) is the same as with any other tree.
+constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kWideStackLds = 16;   // stack entries per lane that live in LDS
+constexpr uint32_t kWideStackMax = 128;  // deepest stack the kernels are prepared for (else: binary walk)
+
+VKR_DEV bool ray_box_packed(uint32_t qx, uint32_t qy, uint32_t qz, const grid_ray& r, float t_min, float t_max) {
+	return ray_box(make_uint4(qx, qy, qz, 0u), r, t_min, t_max);
 }
 
 // Closest hit with back-face culling (primary visibility).  Returns the original

@@ -1,16 +1,24 @@
-// LBVH construction on the GPU (Karras 2012: Morton codes -> radix sort ->
-// binary radix tree -> bottom-up refit -> depth-first "threaded" layout).  Replaces create_acceleration_structure
-// of the reference (src/scene.c:142-406), which hands the same de-quantised
-// triangle soup to the Vulkan driver.  Runs once per scene.
+// BVH construction on the GPU.  Replaces create_acceleration_structure of the reference
+// (src/scene.c:142-406), which hands the same de-quantised triangle soup to the Vulkan driver.
+// Runs once per scene.  Three builders produce the same intermediate form (fp32 nodes in
+// depth-first "threaded" order, one triangle per leaf):
+//   - binned surface-area heuristic, breadth-first, by HIP kernels (the default: "sah device")
+//   - Morton-code LBVH (Karras 2012: Morton codes -> radix sort -> binary radix tree -> refit)
+//   - the binned SAH on the host (host/sah_bvh.c), the plain C statement of the first one
+// and two kernels turn it into what the traversal reads (lbvh.h): k_quantize_nodes (16-byte
+// binary nodes) and k_collapse_level (64-byte four-wide nodes).
 #include "lbvh.h"
 #include "host/vkr_internal.h"
 #include <hipcub/hipcub.hpp>
+#include <time.h>
 
 using namespace vkr;
 
 namespace {
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+// inside a do { } while (0) that cleans up behind itself
+#define HIP_OK_BREAK(call) if ((call) != hipSuccess) break
 
 struct build_params {
 	const uint2* quantized_positions;
@@ -189,6 +197,341 @@ __global__ void __launch_bounds__(256) k_quantize_nodes(uint32_t node_count, con
 	quantized[id] = make_uint4(packed[0], packed[1], packed[2], leaf != kNoLeaf ? (kLeafBit | leaf) : skip);
 }
 
+
+// ---- binned SAH, breadth-first on the device ----------------------------------------------
+// The algorithm of host/sah_bvh.c (16 centroid bins per axis, cost = area x count of the two
+// sides, one triangle per leaf) without its recursion and without moving triangles around:
+// a node of the depth-first layout is fully described by (position, first leaf slot, triangle
+// count) - the left child of (p, f, c) with l triangles on the left is (p + 1, f, l), the right
+// one (p + 2 l, f + l, c - l) - so a triangle only has to remember which node of the current
+// level it is in.  Per level: bin the triangles of every open node (atomics on the node's bins),
+// pick each node's split, hand every triangle to its child (growing the child's boxes with
+// atomics) or, when the child holds one triangle, write the leaf.  Float minima / maxima are
+// atomics on an order-preserving integer encoding, hence independent of the order of arrival.
+constexpr int kSahBinCount = 16;
+constexpr uint32_t kSahDone = 0xFFFFFFFFu;
+constexpr uint32_t kSahLeafChild = 0xFFFFFFFEu;
+
+struct sah_open_node {
+	uint32_t position, first, count;
+	uint32_t fallback_rank;        // hands out ranks when no plane separates the centroids
+	uint32_t bounds[6];            // lo.xyz, hi.xyz of the triangles, ordered encoding
+	uint32_t centroid_bounds[6];
+	// the split (k_sah_split)
+	int32_t axis, split_bin;
+	float bin_origin, bin_scale;
+	uint32_t left_count;
+	uint32_t child[2];             // index among the next level's open nodes or kSahLeafChild
+	uint32_t pad;
+};
+
+struct sah_bin {
+	uint32_t count;
+	uint32_t lo[3], hi[3];
+};
+
+__device__ __forceinline__ uint32_t ordered(float f) {
+	uint32_t bits = __float_as_uint(f);
+	return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__device__ __forceinline__ float unordered(uint32_t u) {
+	return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+	for (int offset = 32; offset > 0; offset >>= 1) v = min(v, (uint32_t) __shfl_xor((int) v, offset));
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+	for (int offset = 32; offset > 0; offset >>= 1) v = max(v, (uint32_t) __shfl_xor((int) v, offset));
+	return v;
+}
+
+__device__ __forceinline__ void reset_open_node(sah_open_node* node, uint32_t position, uint32_t first, uint32_t count) {
+	node->position = position; node->first = first; node->count = count; node->fallback_rank = 0;
+	for (int j = 0; j != 3; ++j) {
+		node->bounds[j] = node->centroid_bounds[j] = 0xFFFFFFFFu;
+		node->bounds[3 + j] = node->centroid_bounds[3 + j] = 0u;
+	}
+}
+
+// Grows the boxes of an open node by one triangle.  When the whole wave feeds the same node
+// (the first levels: all 131 k triangles would otherwise queue up on twelve addresses) the wave
+// reduces first and one lane does the atomics.
+__device__ __forceinline__ void grow_open_node(sah_open_node* node, bool active, f3 lo, f3 hi, bool wave_uniform) {
+	const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+	for (int j = 0; j != 3; ++j) {
+		uint32_t b0 = active ? ordered(l[j]) : 0xFFFFFFFFu, b1 = active ? ordered(h[j]) : 0u;
+		// centroids like sah_bvh.c: 0.5 (lo + hi)
+		uint32_t c = ordered(0.5f * (l[j] + h[j]));
+		uint32_t c0 = active ? c : 0xFFFFFFFFu, c1 = active ? c : 0u;
+		if (wave_uniform) {
+			b0 = wave_min(b0); b1 = wave_max(b1); c0 = wave_min(c0); c1 = wave_max(c1);
+			if ((threadIdx.x & 63u) != 0) continue;
+		}
+		else if (!active) continue;
+		atomicMin(&node->bounds[j], b0); atomicMax(&node->bounds[3 + j], b1);
+		atomicMin(&node->centroid_bounds[j], c0); atomicMax(&node->centroid_bounds[3 + j], c1);
+	}
+}
+
+__device__ __forceinline__ void triangle_bounds(const build_params& p, uint32_t t, f3 (&v)[3], f3& lo, f3& hi) {
+	for (int i = 0; i != 3; ++i) v[i] = dequantize(p.quantized_positions[3 * (size_t) t + i], p);
+	lo = mk3(fminf(v[0].x, fminf(v[1].x, v[2].x)), fminf(v[0].y, fminf(v[1].y, v[2].y)), fminf(v[0].z, fminf(v[1].z, v[2].z)));
+	hi = mk3(fmaxf(v[0].x, fmaxf(v[1].x, v[2].x)), fmaxf(v[0].y, fmaxf(v[1].y, v[2].y)), fmaxf(v[0].z, fmaxf(v[1].z, v[2].z)));
+}
+
+__device__ __forceinline__ void write_threaded_node(float4* threaded, uint32_t position, f3 lo, f3 hi, float pad, uint32_t skip, uint32_t leaf) {
+	threaded[2 * (size_t) position] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, hi.x + pad);
+	threaded[2 * (size_t) position + 1] = make_float4(hi.y + pad, hi.z + pad, __uint_as_float(skip), __uint_as_float(leaf));
+}
+
+__device__ __forceinline__ void write_leaf(const build_params& p, uint32_t t, const f3 (&v)[3], f3 lo, f3 hi, uint32_t position, uint32_t slot, float4* threaded, float4* triangles) {
+	write_threaded_node(threaded, position, lo, hi, p.pad, position + 1u, slot);
+	triangles[3 * (size_t) slot + 0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(t));
+	triangles[3 * (size_t) slot + 1] = make_float4(v[1].x, v[1].y, v[1].z, 0.0f);
+	triangles[3 * (size_t) slot + 2] = make_float4(v[2].x, v[2].y, v[2].z, 0.0f);
+}
+
+// level 0: every triangle is in the root
+__global__ void __launch_bounds__(256) k_sah_init(build_params p, uint32_t* triangle_node, sah_open_node* root, float4* threaded, float4* triangles) {
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	bool active = t < p.triangle_count;
+	f3 v[3], lo = mk3(0.0f, 0.0f, 0.0f), hi = lo;
+	if (active) {
+		triangle_bounds(p, t, v, lo, hi);
+		triangle_node[t] = p.triangle_count > 1 ? 0u : kSahDone;
+		if (p.triangle_count == 1) write_leaf(p, t, v, lo, hi, 0u, 0u, threaded, triangles);
+	}
+	grow_open_node(root, active, lo, hi, true);
+}
+
+__global__ void __launch_bounds__(256) k_sah_reset_root(sah_open_node* root, uint32_t triangle_count, uint32_t* counters) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		reset_open_node(root, 0u, 0u, triangle_count);
+		counters[0] = counters[1] = 0u;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_sah_clear_bins(sah_bin* bins, uint32_t bin_count) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= bin_count) return;
+	sah_bin b;
+	b.count = 0;
+	for (int j = 0; j != 3; ++j) { b.lo[j] = 0xFFFFFFFFu; b.hi[j] = 0u; }
+	bins[i] = b;
+}
+
+// bin index of a centroid coordinate, the arithmetic of sah_bvh.c
+__device__ __forceinline__ float sah_bin_scale(float lo, float hi) {
+	float width = hi - lo;
+	return width > 0.0f ? (float) kSahBinCount * (1.0f - 1.0e-6f) / width : 0.0f;
+}
+__device__ __forceinline__ int sah_bin_index(float c, float lo, float scale) {
+	int k = (int) ((c - lo) * scale);
+	return k < 0 ? 0 : (k >= kSahBinCount ? kSahBinCount - 1 : k);
+}
+
+__global__ void __launch_bounds__(256) k_sah_bin(build_params p, const uint32_t* triangle_node, const sah_open_node* open, sah_bin* bins) {
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= p.triangle_count) return;
+	uint32_t id = triangle_node[t];
+	if (id == kSahDone) return;
+	const sah_open_node* node = open + id;
+	f3 v[3], lo, hi;
+	triangle_bounds(p, t, v, lo, hi);
+	const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+	for (int j = 0; j != 3; ++j) {
+		float c_lo = unordered(node->centroid_bounds[j]), c_hi = unordered(node->centroid_bounds[3 + j]);
+		float scale = sah_bin_scale(c_lo, c_hi);
+		if (!(scale > 0.0f)) continue;
+		int k = sah_bin_index(0.5f * (l[j] + h[j]), c_lo, scale);
+		sah_bin* bin = bins + ((size_t) id * 3 + j) * kSahBinCount + k;
+		atomicAdd(&bin->count, 1u);
+		for (int a = 0; a != 3; ++a) {
+			atomicMin(&bin->lo[a], ordered(l[a]));
+			atomicMax(&bin->hi[a], ordered(h[a]));
+		}
+	}
+}
+
+struct sah_box {
+	float lo[3], hi[3];
+};
+__device__ __forceinline__ void sah_box_reset(sah_box& b) {
+	for (int j = 0; j != 3; ++j) { b.lo[j] = 3.402823466e+38f; b.hi[j] = -3.402823466e+38f; }
+}
+__device__ __forceinline__ void sah_box_merge(sah_box& b, const sah_bin& bin) {
+	for (int j = 0; j != 3; ++j) {
+		b.lo[j] = fminf(b.lo[j], unordered(bin.lo[j]));
+		b.hi[j] = fmaxf(b.hi[j], unordered(bin.hi[j]));
+	}
+}
+__device__ __forceinline__ float sah_half_area(const sah_box& b) {
+	float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+	return x * y + y * z + z * x;
+}
+
+// One thread per open node: the cheapest of the 3 x 15 splits (same order of evaluation and the
+// same strict comparison as sah_bvh.c), the node itself in the output, its children as open
+// nodes of the next level.  counters[0]: open nodes of the next level.
+__global__ void __launch_bounds__(64) k_sah_split(sah_open_node* open, uint32_t open_count, const sah_bin* bins, sah_open_node* next_open, uint32_t* counters, float4* threaded, float pad) {
+	uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= open_count) return;
+	sah_open_node* node = open + id;
+	uint32_t count = node->count;
+	float best_cost = 3.402823466e+38f;
+	int best_axis = -1, best_split = 0;
+	uint32_t best_left = 0;
+	for (int j = 0; j != 3; ++j) {
+		float c_lo = unordered(node->centroid_bounds[j]), c_hi = unordered(node->centroid_bounds[3 + j]);
+		if (!(sah_bin_scale(c_lo, c_hi) > 0.0f)) continue;
+		const sah_bin* axis_bins = bins + ((size_t) id * 3 + j) * kSahBinCount;
+		float right_area[kSahBinCount];
+		uint32_t right_count[kSahBinCount];
+		sah_box sweep;
+		sah_box_reset(sweep);
+		uint32_t n = 0;
+		for (int k = kSahBinCount - 1; k > 0; --k) {
+			if (axis_bins[k].count) sah_box_merge(sweep, axis_bins[k]);
+			n += axis_bins[k].count;
+			right_area[k] = n ? sah_half_area(sweep) : 0.0f;
+			right_count[k] = n;
+		}
+		sah_box_reset(sweep);
+		n = 0;
+		for (int k = 0; k != kSahBinCount - 1; ++k) {
+			if (axis_bins[k].count) sah_box_merge(sweep, axis_bins[k]);
+			n += axis_bins[k].count;
+			if (n == 0 || right_count[k + 1] == 0) continue;
+			float cost = sah_half_area(sweep) * (float) n + right_area[k + 1] * (float) right_count[k + 1];
+			if (cost < best_cost) { best_cost = cost; best_axis = j; best_split = k; best_left = n; }
+		}
+	}
+	// all centroids coincide: any split is as good as another (triangles are dealt by rank)
+	uint32_t left_count = best_axis < 0 ? count / 2u : best_left;
+	node->axis = best_axis;
+	node->split_bin = best_split;
+	node->left_count = left_count;
+	if (best_axis >= 0) {
+		node->bin_origin = unordered(node->centroid_bounds[best_axis]);
+		node->bin_scale = sah_bin_scale(node->bin_origin, unordered(node->centroid_bounds[3 + best_axis]));
+	}
+	f3 lo = mk3(unordered(node->bounds[0]), unordered(node->bounds[1]), unordered(node->bounds[2]));
+	f3 hi = mk3(unordered(node->bounds[3]), unordered(node->bounds[4]), unordered(node->bounds[5]));
+	write_threaded_node(threaded, node->position, lo, hi, pad, node->position + 2u * count - 1u, kNoLeaf);
+	for (uint32_t side = 0; side != 2; ++side) {
+		uint32_t child_count = side ? count - left_count : left_count;
+		if (child_count < 2) { node->child[side] = kSahLeafChild; continue; }
+		uint32_t child = atomicAdd(&counters[0], 1u);
+		node->child[side] = child;
+		reset_open_node(next_open + child, side ? node->position + 2u * left_count : node->position + 1u, side ? node->first + left_count : node->first, child_count);
+	}
+}
+
+// Every triangle of an open node moves to the child on its side of the split, or becomes a leaf
+__global__ void __launch_bounds__(256) k_sah_assign(build_params p, uint32_t* triangle_node, sah_open_node* open, sah_open_node* next_open, float4* threaded, float4* triangles) {
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t id = t < p.triangle_count ? triangle_node[t] : kSahDone;
+	bool active = id != kSahDone;
+	// (a wave whose triangles share one parent reduces the children's boxes before the atomics)
+	uint32_t first_id = __builtin_amdgcn_readfirstlane(id);
+	bool wave_uniform = __all(id == first_id) && first_id != kSahDone;
+	f3 v[3], lo = mk3(0.0f, 0.0f, 0.0f), hi = lo;
+	uint32_t side = 0, child = kSahDone;
+	if (active) {
+		sah_open_node* node = open + id;
+		triangle_bounds(p, t, v, lo, hi);
+		int axis = node->axis;
+		if (axis >= 0) {
+			float c = 0.5f * (axis == 0 ? lo.x + hi.x : (axis == 1 ? lo.y + hi.y : lo.z + hi.z));
+			side = sah_bin_index(c, node->bin_origin, node->bin_scale) > node->split_bin ? 1u : 0u;
+		}
+		else side = atomicAdd(&node->fallback_rank, 1u) >= node->left_count ? 1u : 0u;
+		child = node->child[side];
+		if (child == kSahLeafChild) {
+			uint32_t position = side ? node->position + 2u * node->left_count : node->position + 1u;
+			uint32_t slot = side ? node->first + node->left_count : node->first;
+			write_leaf(p, t, v, lo, hi, position, slot, threaded, triangles);
+			triangle_node[t] = kSahDone;
+		}
+		else triangle_node[t] = child;
+	}
+	bool grows = active && child != kSahLeafChild;
+	if (wave_uniform) {
+		uint32_t children[2] = {open[first_id].child[0], open[first_id].child[1]};
+		for (uint32_t s = 0; s != 2; ++s)
+			if (children[s] != kSahLeafChild) grow_open_node(next_open + children[s], grows && side == s, lo, hi, true);
+	}
+	else if (grows) grow_open_node(next_open + child, true, lo, hi, false);
+}
+
+// ---- collapse to the four-wide layout (lbvh.h) ------------------------------------------------
+
+struct wide_item {
+	uint32_t wide_index, binary_position, need;
+};
+
+__device__ __forceinline__ float quantized_half_area(uint4 n) {
+	float x = (float) ((n.x >> 16) - (n.x & 0xFFFFu)), y = (float) ((n.y >> 16) - (n.y & 0xFFFFu)), z = (float) ((n.z >> 16) - (n.z & 0xFFFFu));
+	return x * y + y * z + z * x;
+}
+
+// One thread per wide node of this level.  counters: [0] items of the next level, [1] wide nodes
+// allocated so far, [2] deepest stack a ray can need.
+__global__ void __launch_bounds__(64) k_collapse_level(const uint4* binary, const wide_item* items, uint32_t item_count, wide_item* next_items, uint32_t* counters, uint4* wide) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= item_count) return;
+	wide_item item = items[i];
+	uint32_t position[4];
+	uint4 node[4];
+	position[0] = item.binary_position + 1u;
+	node[0] = binary[position[0]];
+	position[1] = (node[0].w & kLeafBit) ? item.binary_position + 2u : node[0].w;
+	node[1] = binary[position[1]];
+	uint32_t count = 2;
+	while (count < 4) {
+		// open the inner child with the largest box
+		int widest = -1;
+		float widest_area = -1.0f;
+		for (uint32_t c = 0; c != count; ++c) {
+			float area = quantized_half_area(node[c]);
+			if (!(node[c].w & kLeafBit) && area > widest_area) { widest = (int) c; widest_area = area; }
+		}
+		if (widest < 0) break;
+		uint32_t parent = position[widest];
+		uint32_t left = parent + 1u;
+		uint4 left_node = binary[left];
+		uint32_t right = (left_node.w & kLeafBit) ? parent + 2u : left_node.w;
+		position[widest] = left; node[widest] = left_node;
+		position[count] = right; node[count] = binary[right];
+		++count;
+	}
+	uint32_t inner = 0;
+	for (uint32_t c = 0; c != count; ++c) inner += (node[c].w & kLeafBit) ? 0u : 1u;
+	uint32_t base = inner ? atomicAdd(&counters[1], inner) : 0u;
+	uint32_t next_base = inner ? atomicAdd(&counters[0], inner) : 0u;
+	uint32_t need = item.need + count - 1u;
+	atomicMax(&counters[2], need);
+	uint32_t qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0}, qz[4] = {0, 0, 0, 0}, link[4] = {kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty};
+	uint32_t k = 0;
+	for (uint32_t c = 0; c != count; ++c) {
+		qx[c] = node[c].x; qy[c] = node[c].y; qz[c] = node[c].z;
+		if (node[c].w & kLeafBit) link[c] = node[c].w;
+		else {
+			link[c] = base + k;
+			wide_item child = {base + k, position[c], need};
+			next_items[next_base + k] = child;
+			++k;
+		}
+	}
+	uint4* out = wide + 4 * (size_t) item.wide_index;
+	out[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+	out[1] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
+	out[2] = make_uint4(qz[0], qz[1], qz[2], qz[3]);
+	out[3] = make_uint4(link[0], link[1], link[2], link[3]);
+}
+
 }  // namespace
 
 // Replaces structure->nodes (fp32 threaded nodes on the device) by the quantised nodes
@@ -219,63 +562,106 @@ extern "C" void vkr_destroy_acceleration_structure(acceleration_structure_t* str
 	(void) device;
 	if (structure->triangle_vertices) (void) hipFree(structure->triangle_vertices);
 	if (structure->nodes) (void) hipFree(structure->nodes);
+	if (structure->wide_nodes) (void) hipFree(structure->wide_nodes);
 	memset(structure, 0, sizeof(*structure));
 }
 
-extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh, int builder) {
-	memset(structure, 0, sizeof(*structure));
-	const char* requested = getenv("VKR_BVH_BUILDER");
-	if (requested && strcmp(requested, "lbvh") == 0) builder = 2;
-	if (requested && strcmp(requested, "sah") == 0) builder = 1;
-	if (mesh->triangle_count > 0x7FFFFFFFull) {
-		printf("The LBVH supports at most 2^31 triangles.\n");
-		return 1;
-	}
+// Binary quantised nodes -> four-wide nodes, one level per launch (a level's node count is only
+// known when the level before it has been written).  Leaves structure->wide_nodes NULL (the
+// kernels then walk the binary tree) if the tree is a single leaf or a ray could need a deeper
+// stack than the kernels provide.
+static int collapse_to_wide(acceleration_structure_t* structure, const device_t* device) {
+	uint32_t triangle_count = (structure->node_count + 1) / 2;
+	if (triangle_count < 2) return 0;
 	hipStream_t stream = (hipStream_t) device->stream;
-	uint32_t n = (uint32_t) mesh->triangle_count;
-	build_params p;
-	p.quantized_positions = (const uint2*) mesh->positions;
-	p.triangle_count = n;
-	float extent = 0.0f;
-	for (int j = 0; j != 3; ++j) {
-		p.factor[j] = mesh->dequantization_factor[j];
-		p.summand[j] = mesh->dequantization_summand[j];
-		// largest coordinate magnitude and extent of the quantisation grid
-		extent = fmaxf(extent, 2097152.0f * fabsf(mesh->dequantization_factor[j]));
-		extent = fmaxf(extent, fmaxf(fabsf(mesh->dequantization_summand[j]), fabsf(mesh->dequantization_summand[j] + 2097152.0f * mesh->dequantization_factor[j])));
+	wide_item* items[2] = {NULL, NULL};
+	uint32_t* counters = NULL;
+	uint4* wide = NULL;
+	int failed = 1;
+	uint32_t host_counters[3] = {0, 1, 0};
+	do {
+		HIP_OK_BREAK(hipMalloc(&items[0], sizeof(wide_item) * (size_t) triangle_count));
+		HIP_OK_BREAK(hipMalloc(&items[1], sizeof(wide_item) * (size_t) triangle_count));
+		HIP_OK_BREAK(hipMalloc(&counters, sizeof(uint32_t) * 3));
+		HIP_OK_BREAK(hipMalloc(&wide, sizeof(uint4) * 4 * (size_t) (triangle_count - 1)));
+		wide_item root = {0u, 0u, 0u};
+		HIP_OK_BREAK(hipMemcpyAsync(items[0], &root, sizeof(root), hipMemcpyHostToDevice, stream));
+		HIP_OK_BREAK(hipMemcpyAsync(counters, host_counters, sizeof(host_counters), hipMemcpyHostToDevice, stream));
+		uint32_t item_count = 1, level = 0;
+		bool ok = true;
+		while (item_count && ok) {
+			k_collapse_level<<<(item_count + 63) / 64, 64, 0, stream>>>((const uint4*) structure->nodes, items[level & 1], item_count, items[(level + 1) & 1], counters, wide);
+			ok = hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, stream) == hipSuccess
+				&& hipStreamSynchronize(stream) == hipSuccess;
+			item_count = host_counters[0];
+			uint32_t zero = 0;
+			ok = ok && hipMemcpyAsync(counters, &zero, sizeof(zero), hipMemcpyHostToDevice, stream) == hipSuccess && ++level < 4096;
+		}
+		if (!ok || hipGetLastError() != hipSuccess) break;
+		failed = 0;
+	} while (0);
+	(void) hipFree(items[0]); (void) hipFree(items[1]); (void) hipFree(counters);
+	if (failed || host_counters[2] > kWideStackMax) {
+		if (!failed) printf("The four-wide BVH would need a stack of %u entries per ray (at most %u are provided); shadow rays walk the binary tree.\n", host_counters[2], kWideStackMax);
+		(void) hipFree(wide);
+		return failed;
 	}
-	// Conservative padding.  The slab test evaluates plane * (1/d) - o * (1/d) with a
-	// 1-ulp reciprocal and two roundings, i.e. it misplaces a plane by about
-	// |o| 2^-23; the triangle test may accept hits about as far outside the triangle.
-	// 2e-6 of the largest coordinate is sixteen times that.  (The padding must stay
-	// far below t_min = 1e-3: a ray leaving a flat floor would otherwise start inside
-	// the padded boxes of the floor and walk down to its own triangle.)
-	p.pad = 2.0e-6f * extent;
-	if (builder != 2) {
-		// surface-area heuristic on the host, then one upload
-		float *host_nodes = NULL, *host_triangles = NULL;
-		uint32_t node_count = 0;
-		if (vkr_build_sah_bvh_host(mesh, p.pad, &host_nodes, &host_triangles, &node_count)) {
-			printf("Building the SAH BVH over %u triangles failed (out of memory or no host copy of the positions).\n", n);
-			return 1;
+	structure->wide_nodes = wide;
+	structure->wide_node_count = host_counters[1];
+	structure->wide_stack_need = host_counters[2];
+	return 0;
+}
+
+// The binned SAH build by HIP kernels (see above); leaves fp32 threaded nodes in structure->nodes
+static int build_sah_on_device(acceleration_structure_t* structure, const device_t* device, const build_params& p) {
+	hipStream_t stream = (hipStream_t) device->stream;
+	uint32_t n = p.triangle_count;
+	uint32_t total_nodes = 2 * n - 1;
+	// at most n / 2 nodes with two or more triangles are open at a time
+	uint32_t open_capacity = n / 2 + 1;
+	sah_open_node* open[2] = {NULL, NULL};
+	sah_bin* bins = NULL;
+	uint32_t *triangle_node = NULL, *counters = NULL;
+	int failed = 1;
+	do {
+		HIP_OK_BREAK(hipMalloc(&structure->triangle_vertices, sizeof(float4) * 3 * (size_t) n));
+		HIP_OK_BREAK(hipMalloc(&structure->nodes, sizeof(float4) * 2 * (size_t) total_nodes));
+		HIP_OK_BREAK(hipMalloc(&open[0], sizeof(sah_open_node) * (size_t) open_capacity));
+		HIP_OK_BREAK(hipMalloc(&open[1], sizeof(sah_open_node) * (size_t) open_capacity));
+		HIP_OK_BREAK(hipMalloc(&bins, sizeof(sah_bin) * 3 * kSahBinCount * (size_t) open_capacity));
+		HIP_OK_BREAK(hipMalloc(&triangle_node, sizeof(uint32_t) * (size_t) n));
+		HIP_OK_BREAK(hipMalloc(&counters, sizeof(uint32_t) * 2));
+		uint32_t blocks = (n + 255) / 256;
+		k_sah_reset_root<<<1, 64, 0, stream>>>(open[0], n, counters);
+		k_sah_init<<<blocks, 256, 0, stream>>>(p, triangle_node, open[0], (float4*) structure->nodes, (float4*) structure->triangle_vertices);
+		uint32_t open_count = n > 1 ? 1u : 0u, level = 0;
+		bool ok = true;
+		while (open_count && ok) {
+			sah_open_node *now = open[level & 1], *next = open[(level + 1) & 1];
+			uint32_t bin_count = open_count * 3u * kSahBinCount;
+			k_sah_clear_bins<<<(bin_count + 255) / 256, 256, 0, stream>>>(bins, bin_count);
+			k_sah_bin<<<blocks, 256, 0, stream>>>(p, triangle_node, now, bins);
+			k_sah_split<<<(open_count + 63) / 64, 64, 0, stream>>>(now, open_count, bins, next, counters, (float4*) structure->nodes, p.pad);
+			k_sah_assign<<<blocks, 256, 0, stream>>>(p, triangle_node, now, next, (float4*) structure->nodes, (float4*) structure->triangle_vertices);
+			uint32_t next_count = 0, zero = 0;
+			ok = hipMemcpyAsync(&next_count, counters, sizeof(next_count), hipMemcpyDeviceToHost, stream) == hipSuccess
+				&& hipStreamSynchronize(stream) == hipSuccess
+				&& hipMemcpyAsync(counters, &zero, sizeof(zero), hipMemcpyHostToDevice, stream) == hipSuccess
+				&& next_count <= open_capacity && ++level < 4096;
+			open_count = next_count;
 		}
-		int upload_failed = vkr_device_upload(&structure->nodes, device, host_nodes, sizeof(float) * 8 * (size_t) node_count, "BVH nodes")
-			|| vkr_device_upload(&structure->triangle_vertices, device, host_triangles, sizeof(float) * 12 * (size_t) n, "BVH triangles");
-		free(host_nodes);
-		free(host_triangles);
-		if (upload_failed) {
-			vkr_destroy_acceleration_structure(structure, device);
-			return 1;
-		}
-		structure->node_count = node_count;
+		if (!ok || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) break;
+		structure->node_count = total_nodes;
 		structure->root = 0;
-		if (quantize_nodes(structure, device)) {
-			printf("Quantising the BVH nodes failed.\n");
-			vkr_destroy_acceleration_structure(structure, device);
-			return 1;
-		}
-		return 0;
-	}
+		failed = 0;
+	} while (0);
+	(void) hipFree(open[0]); (void) hipFree(open[1]); (void) hipFree(bins); (void) hipFree(triangle_node); (void) hipFree(counters);
+	return failed;
+}
+
+static int build_lbvh_on_device(acceleration_structure_t* structure, const device_t* device, const build_params& p) {
+	hipStream_t stream = (hipStream_t) device->stream;
+	uint32_t n = p.triangle_count;
 	uint32_t inner_count = n > 1 ? n - 1 : 1;
 	uint32_t total_nodes = 2 * n - 1;
 	bvh_build_node* build_nodes = NULL;
@@ -308,14 +694,77 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 		structure->root = 0;
 		if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) break;
 		structure->node_count = total_nodes;
-		structure->triangle_indices = NULL;
-		failed = quantize_nodes(structure, device);
+		failed = 0;
 	} while (0);
 	(void) hipFree(keys); (void) hipFree(sorted_keys); (void) hipFree(lo); (void) hipFree(hi);
 	(void) hipFree(leaf_parents); (void) hipFree(arrivals); (void) hipFree(sort_storage); (void) hipFree(build_nodes);
-	if (failed) {
-		printf("Building the LBVH over %u triangles failed: %s\n", n, hipGetErrorString(hipGetLastError()));
-		vkr_destroy_acceleration_structure(structure, device);
-	}
 	return failed;
+}
+
+static int build_sah_on_host(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh, float pad) {
+	// surface-area heuristic on the host, then one upload
+	float *host_nodes = NULL, *host_triangles = NULL;
+	uint32_t node_count = 0;
+	if (vkr_build_sah_bvh_host(mesh, pad, &host_nodes, &host_triangles, &node_count)) {
+		printf("Building the SAH BVH over %llu triangles on the host failed (out of memory or no host copy of the positions).\n", (unsigned long long) mesh->triangle_count);
+		return 1;
+	}
+	int upload_failed = vkr_device_upload(&structure->nodes, device, host_nodes, sizeof(float) * 8 * (size_t) node_count, "BVH nodes")
+		|| vkr_device_upload(&structure->triangle_vertices, device, host_triangles, sizeof(float) * 12 * (size_t) mesh->triangle_count, "BVH triangles");
+	free(host_nodes);
+	free(host_triangles);
+	structure->node_count = node_count;
+	structure->root = 0;
+	return upload_failed;
+}
+
+extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* structure, const device_t* device, const mesh_t* mesh, int builder) {
+	memset(structure, 0, sizeof(*structure));
+	if (builder <= (int) acceleration_structure_none || builder >= (int) acceleration_structure_builder_count) {
+		printf("Invalid acceleration structure builder %d.\n", builder);
+		return 1;
+	}
+	if (mesh->triangle_count == 0 || mesh->triangle_count > 0x7FFFFFFFull) {
+		printf("The BVH builders support 1 to 2^31 triangles, the mesh has %llu.\n", (unsigned long long) mesh->triangle_count);
+		return 1;
+	}
+	hipStream_t stream = (hipStream_t) device->stream;
+	uint32_t n = (uint32_t) mesh->triangle_count;
+	build_params p;
+	p.quantized_positions = (const uint2*) mesh->positions;
+	p.triangle_count = n;
+	float extent = 0.0f;
+	for (int j = 0; j != 3; ++j) {
+		p.factor[j] = mesh->dequantization_factor[j];
+		p.summand[j] = mesh->dequantization_summand[j];
+		// largest coordinate magnitude and extent of the quantisation grid
+		extent = fmaxf(extent, 2097152.0f * fabsf(mesh->dequantization_factor[j]));
+		extent = fmaxf(extent, fmaxf(fabsf(mesh->dequantization_summand[j]), fabsf(mesh->dequantization_summand[j] + 2097152.0f * mesh->dequantization_factor[j])));
+	}
+	// Conservative padding.  The slab test evaluates plane * (1/d) - o * (1/d) with a
+	// 1-ulp reciprocal and two roundings, i.e. it misplaces a plane by about
+	// |o| 2^-23; the triangle test may accept hits about as far outside the triangle.
+	// 2e-6 of the largest coordinate is sixteen times that.  (The padding must stay
+	// far below t_min = 1e-3: a ray leaving a flat floor would otherwise start inside
+	// the padded boxes of the floor and walk down to its own triangle.)
+	p.pad = 2.0e-6f * extent;
+	if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+	struct timespec start, end;
+	clock_gettime(CLOCK_MONOTONIC, &start);
+	int failed = builder == (int) acceleration_structure_sah_host ? build_sah_on_host(structure, device, mesh, p.pad)
+		: (builder == (int) acceleration_structure_lbvh_device ? build_lbvh_on_device(structure, device, p) : build_sah_on_device(structure, device, p));
+	if (!failed) {
+		failed = quantize_nodes(structure, device);
+		if (failed) printf("Quantising the BVH nodes failed.\n");
+	}
+	if (!failed) failed = collapse_to_wide(structure, device);
+	if (failed) {
+		printf("Building the BVH over %u triangles failed: %s\n", n, hipGetErrorString(hipGetLastError()));
+		vkr_destroy_acceleration_structure(structure, device);
+		return 1;
+	}
+	clock_gettime(CLOCK_MONOTONIC, &end);
+	structure->builder = (uint32_t) builder;
+	structure->build_milliseconds = (float) ((double) (end.tv_sec - start.tv_sec) * 1.0e3 + (double) (end.tv_nsec - start.tv_nsec) * 1.0e-6);
+	return 0;
 }

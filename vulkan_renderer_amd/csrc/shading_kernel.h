@@ -62,6 +62,7 @@ struct shade_params {
 	bvh_view bvh;
 	// tile schedule (include/vkr_shading_pass.h tile_schedule_t)
 	uint32_t tile_size, rank, rank_count, tiles_x, tile_count;
+	uint32_t slab_layout;  // 0: out_radiance is the row-major frame (single rank), 1: this rank's dense slab
 	unsigned long long* ray_counter;
 	// wavefront mode (RAYS == kRaysDeferred): per-thread streams of pending terms and
 	// the compacted shadow-ray queue, see "wavefront" below
@@ -1239,7 +1240,7 @@ VKR_DEV bool locate_pixel(const shade_params& p, uint32_t& px, uint32_t& py, siz
 	uint32_t iy = (by << 4) + ((wave >> 1) << 3) + (lane >> 3);
 	px = tx * p.tile_size + ix;
 	py = ty * p.tile_size + iy;
-	if (p.rank_count == 1) out_index = (size_t) py * p.width + px;
+	if (!p.slab_layout) out_index = (size_t) py * p.width + px;
 	else out_index = (size_t) local_tile * p.tile_size * p.tile_size + (size_t) iy * p.tile_size + ix;
 	return px < p.width && py < p.height;
 }
@@ -1437,6 +1438,135 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 			}
 			busy = __ballot(node != kIdle);
 		} while (busy != 0 && (!may_refill || __popcll((unsigned long long) busy) > refill_threshold));
+	}
+}
+
+// The same persistent scheme on the four-wide tree (lbvh.h "wide BVH"): a visit fetches one
+// 64-byte node and tests its four boxes, hit children beyond the first go to the lane's stack
+// (kWideStackLds entries in LDS, [entry][thread]; deeper ones in `spill`, [entry][global thread],
+// which exists only if the tree can need them).  A lane whose next item is a triangle waits until
+// `leaf_batch` lanes of the wave have one (or no lane has a node left), so that the triangle test
+// runs with many lanes: the two kinds of work no longer share every step of the loop.
+__global__ void __launch_bounds__(256) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch) {
+	__shared__ uint32_t stack[kWideStackLds * 256];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t xcd = blockIdx.x & 7u;
+	const uint32_t my_queue = xcd * 64u + lane;
+	const uint32_t my_size = ray_queue_size[my_queue];
+	uint32_t xcd_rays = my_size;
+#pragma unroll
+	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
+	const uint32_t xcd_waves = (gridDim.x / 8u) * 4u;
+	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
+	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
+	uint32_t inclusive = my_chunks;
+#pragma unroll
+	for (int offset = 1; offset < 64; offset <<= 1) {
+		uint32_t other = __shfl_up(inclusive, offset);
+		if (lane >= (uint32_t) offset) inclusive += other;
+	}
+	const uint32_t exclusive = inclusive - my_chunks;
+	const uint32_t total_chunks = __shfl(inclusive, 63);
+	const float4* chunk_rays = ray_queue;
+	uint32_t chunk_count = 0, chunk_next = 0;
+	bool chunks_left = true;
+	// `item`: what the lane looks at next - a wide node (index), a triangle (kLeafBit | slot) or
+	// nothing (kIdle: the lane has no ray)
+	constexpr uint32_t kIdle = 0xFFFFFFFFu;
+	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
+	grid_ray ray = {o, o};
+	float t_max = 0.0f;
+	uint32_t item = kIdle, code_index = 0, depth = 0;
+	uint32_t* my_stack = stack + threadIdx.x;
+	uint32_t* my_spill = spill + (size_t) blockIdx.x * 256u + threadIdx.x;
+	const size_t spill_stride = (size_t) gridDim.x * 256u;
+	while (true) {
+		// ---- hand new rays to idle lanes (as in trace_shadow_rays) --------------------------
+		uint64_t idle = __ballot(item == kIdle);
+		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
+			if (chunk_next >= chunk_count) {
+				uint32_t chunk = 0;
+				if (lane == 0) chunk = atomicAdd(work_cursors + xcd * kCursorStride, 1u);
+				chunk = __builtin_amdgcn_readfirstlane(chunk);
+				if (chunk >= total_chunks) { chunks_left = false; break; }
+				uint64_t owner = __ballot(my_chunks != 0 && exclusive <= chunk && chunk < inclusive);
+				int owner_lane = __ffsll((unsigned long long) owner) - 1;
+				uint32_t queue = xcd * 64u + (uint32_t) owner_lane;
+				uint32_t first = (chunk - __shfl(exclusive, owner_lane)) * chunk_size;
+				uint32_t size = __shfl(my_size, owner_lane);
+				chunk_rays = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + first);
+				chunk_count = min(chunk_size, size - first);
+				chunk_next = 0;
+			}
+			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+			uint32_t index = chunk_next + rank;
+			if (item == kIdle && index < chunk_count) {
+				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
+				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
+				code_index = __float_as_uint(b.w);
+				ray = make_grid_ray(bvh, o, d);
+				item = 0;
+				depth = 0;
+				if (!(t_max >= 1.0e-3f)) {
+					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
+					item = kIdle;
+				}
+			}
+			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
+			idle = __ballot(item == kIdle);
+		}
+		if (__ballot(item != kIdle) == 0) break;
+		// ---- walk until every lane has run dry -----------------------------------------------
+		while (true) {
+			bool at_node = item != kIdle && !(item & kLeafBit);
+			bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
+			uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
+			if ((node_lanes | leaf_lanes) == 0) break;
+			bool pop = false;
+			if (at_node) {
+				const uint4* n = wide_nodes + 4 * (size_t) item;
+				uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
+				bool h0 = link.x != kWideEmpty && ray_box_packed(qx.x, qy.x, qz.x, ray, 1.0e-3f, t_max);
+				bool h1 = link.y != kWideEmpty && ray_box_packed(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
+				bool h2 = link.z != kWideEmpty && ray_box_packed(qx.z, qy.z, qz.z, ray, 1.0e-3f, t_max);
+				bool h3 = link.w != kWideEmpty && ray_box_packed(qx.w, qy.w, qz.w, ray, 1.0e-3f, t_max);
+				// the first hit child is next, the others wait on the stack
+				uint32_t next = kIdle;
+				const bool hits[4] = {h0, h1, h2, h3};
+				const uint32_t links[4] = {link.x, link.y, link.z, link.w};
+#pragma unroll
+				for (int c = 0; c != 4; ++c) {
+					if (!hits[c]) continue;
+					if (next == kIdle) next = links[c];
+					else {
+						if (depth < kWideStackLds) my_stack[depth * 256u] = links[c];
+						else my_spill[(size_t) (depth - kWideStackLds) * spill_stride] = links[c];
+						++depth;
+					}
+				}
+				item = next;
+				pop = next == kIdle;
+			}
+			bool test_leaves = leaf_lanes != 0 && (node_lanes == 0 || (uint32_t) __popcll((unsigned long long) leaf_lanes) >= leaf_batch);
+			if (test_leaves && at_leaf) {
+				const float4* t = bvh.triangles + 3 * (size_t) (item & ~kLeafBit);
+				float dist;
+				bool blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
+				// a blocked ray is done: its term keeps the code the shading kernel gave it
+				if (blocked) { item = kIdle; depth = 0; }
+				else pop = true;
+			}
+			if (pop) {
+				if (depth == 0) {
+					codes[code_index] = (uint8_t) kCodeVisible;
+					item = kIdle;
+				}
+				else {
+					--depth;
+					item = depth < kWideStackLds ? my_stack[depth * 256u] : my_spill[(size_t) (depth - kWideStackLds) * spill_stride];
+				}
+			}
+		}
 	}
 }
 

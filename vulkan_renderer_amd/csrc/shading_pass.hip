@@ -119,11 +119,16 @@ struct wavefront_buffers {
 	float4* ray_queue;
 	uint32_t* ray_queue_size;  // kRayCounterCount live counters (queue sizes, per-XCD work cursors), then last frame's copy
 	uint32_t thread_count, max_terms, max_codes, queue_capacity;
+	// stack entries beyond the LDS part of trace_shadow_rays_wide, [entry][thread of the trace grid];
+	// allocated only for trees that can need them
+	uint32_t* spill;
+	size_t spill_entries;
 };
 
 static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->codes); (void) hipFree(w->terms_visible); (void) hipFree(w->terms_hidden);
 	(void) hipFree(w->base_color); (void) hipFree(w->ray_queue); (void) hipFree(w->ray_queue_size);
+	(void) hipFree(w->spill);
 	memset(w, 0, sizeof(*w));
 }
 
@@ -133,11 +138,19 @@ static void free_wavefront_buffers(wavefront_buffers* w) {
 struct frame_context {
 	wavefront_buffers buffers;
 	hipEvent_t done;  // recorded behind the last kernel of the frame
+	bool recorded;    // `done` has been recorded: the next frame's resolve is ordered behind it
 	bool pending;     // device->stream has not been made to wait for `done` yet
+	uint32_t readers_seen;  // frame_pipeline::readers_generation this context's stream has waited for
 };
 struct frame_pipeline {
 	frame_context contexts[VKR_MAX_FRAMES_IN_FLIGHT];
 	hipEvent_t inputs_ready;  // marks what device->stream had submitted when a frame started
+	// Recorded on device->stream behind every kernel there that reads a target of the frames
+	// (output encoding of the frame or of a slab): a later frame in flight must not resolve into
+	// that target before the reader is done.  (finish_frames() orders device->stream behind the
+	// frames; this is the opposite direction.)
+	hipEvent_t readers_done;
+	uint32_t readers_generation;
 	uint32_t next;            // context of the next pipelined frame
 	uint32_t last;            // context of the most recent frame
 	uint32_t depth;           // frames in flight of the most recent pipelined frame
@@ -151,6 +164,7 @@ static void destroy_wavefront(shading_pass_t* pass) {
 		free_wavefront_buffers(&c.buffers);
 	}
 	if (frames->inputs_ready) (void) hipEventDestroy(frames->inputs_ready);
+	if (frames->readers_done) (void) hipEventDestroy(frames->readers_done);
 	free(frames);
 	pass->wavefront = NULL;
 }
@@ -160,7 +174,8 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	if (frames) return frames;
 	frames = (frame_pipeline*) calloc(1, sizeof(frame_pipeline));
 	pass->wavefront = frames;
-	bool failed = !frames || hipEventCreateWithFlags(&frames->inputs_ready, kSyncEventFlags) != hipSuccess;
+	bool failed = !frames || hipEventCreateWithFlags(&frames->inputs_ready, kSyncEventFlags) != hipSuccess
+		|| hipEventCreateWithFlags(&frames->readers_done, kSyncEventFlags) != hipSuccess;
 	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++i) failed = hipEventCreateWithFlags(&frames->contexts[i].done, kSyncEventFlags) != hipSuccess;
 	if (failed) {
 		printf("Failed to create the events of the frame pipeline.\n");
@@ -173,6 +188,20 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 // Slots a shading wave reserves per atomic (shade_params.ray_block): pays off when a lane
 // queues many rays; with one or two per lane the unused slots would outnumber the rays.
 static uint32_t ray_block_size(uint32_t max_terms) { return max_terms >= 8 ? 256u : 0u; }
+
+static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t trace_threads) {
+	size_t entries = stack_need > kWideStackLds ? (size_t) (stack_need - kWideStackLds) * trace_threads : 0;
+	if (entries <= w->spill_entries) return 0;
+	// (frees while other frames may be in flight: hipFree waits for the device)
+	(void) hipFree(w->spill);
+	w->spill = NULL; w->spill_entries = 0;
+	if (hipMalloc(&w->spill, entries * sizeof(uint32_t)) != hipSuccess) {
+		printf("Failed to allocate %.1f MiB for the traversal stacks that do not fit into LDS.\n", entries * 4.0 / 1048576.0);
+		return 1;
+	}
+	w->spill_entries = entries;
+	return 0;
+}
 
 static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
 	uint32_t max_codes = max_terms + light_count + 2;
@@ -224,12 +253,22 @@ extern "C" int finish_frames(application_t* app) {
 	frame_pipeline* frames = (frame_pipeline*) app->shading_pass.wavefront;
 	if (!frames) return 0;
 	int failed = 0;
+	// (only device->stream's view changes: the order among the frames themselves is kept by
+	// frame_context::recorded, which stays set)
 	for (frame_context& c : frames->contexts)
 		if (c.pending) {
 			failed |= hip_failed(hipStreamWaitEvent((hipStream_t) app->device.stream, c.done, 0), "waiting for a frame in flight");
 			c.pending = false;
 		}
 	return failed;
+}
+
+// Call behind a kernel on device->stream that reads a buffer frames in flight write (the radiance
+// target, a caller's slab): the next frames wait for it before they resolve.
+static void note_target_reader(application_t* app) {
+	frame_pipeline* frames = (frame_pipeline*) app->shading_pass.wavefront;
+	if (!frames || !app->shading_pass.last_frame_in_flight) return;
+	if (hipEventRecord(frames->readers_done, (hipStream_t) app->device.stream) == hipSuccess) ++frames->readers_generation;
 }
 
 // The constant buffer is a small ring: the host may record several frames ahead, so
@@ -422,7 +461,7 @@ static int create_timing_ring(shading_pass_t* pass) {
 }
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
-	int32_t fast_math = pass->fast_math, inline_rays = pass->inline_rays;
+	int32_t fast_math = pass->fast_math, inline_rays = pass->inline_rays, binary_traversal = pass->binary_traversal;
 	uint32_t timing_stride = pass->timing_stride, frames_in_flight = pass->frames_in_flight;
 	memset(pass, 0, sizeof(*pass));
 	pass->timing_stride = timing_stride;
@@ -430,6 +469,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	pass->inputs_changed = 1;
 	pass->fast_math = fast_math ? 1 : 0;
 	pass->inline_rays = inline_rays ? 1 : 0;
+	pass->binary_traversal = binary_traversal ? 1 : 0;
 	pass->variant = -1;
 	const device_t* device = &app->device;
 	if (validate_settings(app)) return 1;
@@ -456,6 +496,7 @@ static void fill_tile_schedule(shade_params& p, const application_t* app, uint32
 	p.tile_size = schedule.tile_size;
 	p.rank = schedule.rank;
 	p.rank_count = schedule.rank_count;
+	p.slab_layout = (schedule.rank_count > 1 || schedule.slab_layout) ? 1u : 0u;
 	p.tiles_x = (p.width + p.tile_size - 1) / p.tile_size;
 	uint32_t tiles_y = (p.height + p.tile_size - 1) / p.tile_size;
 	p.tile_count = p.tiles_x * tiles_y;
@@ -505,6 +546,7 @@ __global__ void k_encode_output_rgb8(const float4* radiance, uint32_t* packed, u
 static int ensure_srgb_code_thresholds(const device_t* device, hipStream_t stream);
 
 static int render_pass(application_t* app, void* out_radiance, void* out_rgb8);
+extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]);
 
 extern "C" int render_shading_pass(application_t* app, void* out_radiance) {
 	return render_pass(app, out_radiance, NULL);
@@ -526,6 +568,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		printf("render_shading_pass() needs a shading pass created by create_shading_pass().\n");
 		return 1;
 	}
+	// settings may have been edited since create_shading_pass(): the same legality rules apply, and the
+	// launcher tables below are indexed with them
+	if (validate_settings(app)) return 1;
 	if (get_constant_buffer_size(app) != pass->constants_size
 		|| get_max_polygon_vertex_count(&app->scene_specification, &app->render_settings) != pass->max_polygon_vertex_count
 		|| (int32_t) app->render_settings.sampling_strategies * kTechniqueCount + technique_index(&app->render_settings) != pass->variant)
@@ -590,6 +635,12 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			p.error_scale = 20.0f / ((5.0f - 0.0f) * log2f(10.0f));
 		}
 	}
+	if (error_mode == kErrorNone && (int) app->render_settings.sampling_strategies >= (int) sampling_strategies_count) {
+		// (an out-of-range strategy is only legal together with an error display that is really shown:
+		// a specular display without the combined path shows nothing and would index past the launcher table)
+		printf("No kernel variant exists for sampling strategy %d without an error display.\n", (int) app->render_settings.sampling_strategies);
+		return 1;
+	}
 	if (pass->use_ray_tracing) {
 		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
 		p.ray_counter = (unsigned long long*) pass->ray_counter;
@@ -600,6 +651,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	// any frame that is still in flight.
 	frame_context* frame = NULL;
 	bool pipelined = false;
+	// the tracing kernels are persistent: 8 waves per SIMD on every CU, each lane strides over the queues
+	const uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
+	const bool use_wide_tree = app->scene.acceleration_structure.wide_nodes && !pass->binary_traversal;
 	if (ray_mode == kRaysDeferred) {
 		uint32_t max_rays_per_lane = 2u * p.light_count * p.sample_count;
 		if ((int) app->render_settings.sampling_strategies >= (int) sampling_strategies_diffuse_specular_separately && ray_block_size(max_rays_per_lane))
@@ -618,6 +672,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		if (pipelined && frames->depth != depth) {
 			// another pipeline depth: contexts and streams pair up differently, start afresh
 			if (frames->depth && wait_for_device(device)) return 1;
+			for (frame_context& c : frames->contexts) c.recorded = c.pending = false;
 			frames->depth = depth;
 			frames->next = 0;
 		}
@@ -641,6 +696,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			}
 		}
 		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
+		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, trace_blocks * 256u)) return 1;
 		const wavefront_buffers* w = &frame->buffers;
 		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden; p.base_color = w->base_color;
 		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
@@ -651,6 +707,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
 	}
 	else if (finish_frames(app)) return 1;
+	pass->last_frame_traced_rays = ray_mode != kRaysNone;
 	pass->last_frame_in_flight = pipelined ? ((frame_pipeline*) pass->wavefront)->depth : 0u;
 	// textured scene: sample the material textures of every pixel first (same stream)
 	bool textured = app->scene.materials.textured && app->scene.materials.texture_descriptors;
@@ -703,23 +760,34 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		: g_launchers[(pass->fast_math ? 1 : 0) + (p.light_texture_descriptors ? 2 : 0)][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
 	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
 	if (status == 0 && is_deferred(ray_mode)) {
-		// enough resident waves to fill the chip; each lane strides over the queue
-		// persistent: 8 waves per SIMD on every CU
-		uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
-		trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
+		if (use_wide_tree) {
+			// tuning knob: lanes that must have a triangle waiting before the wave tests triangles
+			const char* batch = getenv("VKR_LEAF_BATCH");
+			trace_shadow_rays_wide<<<trace_blocks, 256, 0, stream>>>(p.bvh, (const uint4*) app->scene.acceleration_structure.wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
+				p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, batch ? (uint32_t) atoi(batch) : 16u);
+		}
+		else
+			trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
 		if (pipelined) {
 			// both frames in flight may write the same target: keep the frame order there
 			// (the frame before this one ran in the context before this one)
 			frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
+			// (whether device->stream has already been made to wait for that frame - finish_frames() -
+			// says nothing about this stream)
 			frame_context* previous = &frames->contexts[(frames->last + frames->depth - 1u) % frames->depth];
-			if (previous->pending) (void) hipStreamWaitEvent(stream, previous->done, 0);
+			if (previous != frame && previous->recorded) (void) hipStreamWaitEvent(stream, previous->done, 0);
+			// ... and behind whatever still reads the target on device->stream (output encoding)
+			if (frame->readers_seen != frames->readers_generation) {
+				(void) hipStreamWaitEvent(stream, frames->readers_done, 0);
+				frame->readers_seen = frames->readers_generation;
+			}
 		}
 		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
 		status = hipGetLastError() != hipSuccess;
 	}
 	if (status == 0 && out_rgb8) {
 		// slab layout: every thread of the grid owns a slot; full-frame layout: the pixels
-		uint64_t pixels = p.rank_count > 1 ? (uint64_t) grid_blocks * 256u : (uint64_t) p.width * p.height;
+		uint64_t pixels = p.slab_layout ? (uint64_t) grid_blocks * 256u : (uint64_t) p.width * p.height;
 		if (pixels % 4 != 0 || ensure_srgb_code_thresholds(device, stream)) {
 			printf("The frame cannot be encoded as packed RGB8 (its pixel count has to be a multiple of four).\n");
 			status = 1;
@@ -731,7 +799,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	}
 	if (status == 0 && pipelined) {
 		(void) hipEventRecord(frame->done, stream);
-		frame->pending = true;
+		frame->pending = frame->recorded = true;
 	}
 	if (timed) {
 		(void) hipEventRecord(ring[3 * slot + 2], stream);
@@ -847,6 +915,67 @@ __global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, cons
 	atomicAdd(out + 3, blocked_rays); atomicAdd(out + 4, wave_steps);
 }
 
+// The same for the four-wide tree: "visits" are fetched nodes (dependent loads), out[5] the longest
+// ray's, wave steps the longest ray of each group of 64; out[6] counts tested boxes, out[7] the
+// deepest stack a ray reached
+__global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh, const uint4* wide_nodes, const float4* ray_queue, const uint32_t* ray_queue_size, uint32_t ray_queue_capacity, unsigned long long* out) {
+	uint32_t queue = blockIdx.y;
+	uint32_t size = ray_queue_size[queue];
+	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0, boxes = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ((size + 63u) & ~63u); i += gridDim.x * 256u) {
+		uint32_t my_visits = 0;
+		const float4* r = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + i);
+		if (i < size && __float_as_uint(r[1].w) != kNullRay) {
+			float4 a = r[0], b = r[1];
+			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
+			float t_max = a.w;
+			grid_ray ray = make_grid_ray(bvh, o, d);
+			uint32_t stack[kWideStackMax];
+			uint32_t depth = 0, deepest = 0, item = 0;
+			bool blocked = false, done = !(t_max >= 1.0e-3f);
+			++rays;
+			while (!done) {
+				if (item & kLeafBit) {
+					const float4* t = bvh.triangles + 3 * (size_t) (item & ~kLeafBit);
+					float dist;
+					++tests;
+					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
+					if (blocked) break;
+					item = 0xFFFFFFFFu;
+				}
+				else {
+					const uint4* n = wide_nodes + 4 * (size_t) item;
+					uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
+					const uint32_t x[4] = {qx.x, qx.y, qx.z, qx.w}, y[4] = {qy.x, qy.y, qy.z, qy.w}, z[4] = {qz.x, qz.y, qz.z, qz.w}, links[4] = {link.x, link.y, link.z, link.w};
+					++my_visits;
+					item = 0xFFFFFFFFu;
+					for (int c = 0; c != 4; ++c) {
+						if (links[c] == kWideEmpty) continue;
+						++boxes;
+						if (!ray_box_packed(x[c], y[c], z[c], ray, 1.0e-3f, t_max)) continue;
+						if (item == 0xFFFFFFFFu) item = links[c];
+						else if (depth < kWideStackMax) stack[depth++] = links[c];
+					}
+					deepest = max(deepest, depth);
+				}
+				if (item == 0xFFFFFFFFu) {
+					if (depth == 0) done = true;
+					else item = stack[--depth];
+				}
+			}
+			blocked_rays += blocked ? 1 : 0;
+			atomicMax(out + 7, (unsigned long long) deepest);
+		}
+		visits += my_visits;
+		uint32_t longest = my_visits;
+		for (int offset = 32; offset > 0; offset >>= 1) longest = max(longest, (uint32_t) __shfl_xor((int) longest, offset));
+		if ((threadIdx.x & 63u) == 0) wave_steps += longest;
+		atomicMax(out + 5, (unsigned long long) my_visits);
+	}
+	atomicAdd(out + 0, rays); atomicAdd(out + 1, visits); atomicAdd(out + 2, tests);
+	atomicAdd(out + 3, blocked_rays); atomicAdd(out + 4, wave_steps); atomicAdd(out + 6, boxes);
+}
+
 extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]) {
 	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
@@ -854,21 +983,36 @@ extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statist
 		printf("get_traversal_statistics() needs a frame rendered with wavefront shadow rays.\n");
 		return 1;
 	}
+	uint64_t all[8];
+	int failed = get_traversal_statistics_of_tree(app, app->scene.acceleration_structure.wide_nodes && !app->shading_pass.binary_traversal, all);
+	memcpy(out_statistics, all, sizeof(uint64_t) * 6);
+	return failed;
+}
+
+extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]) {
+	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
+	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
+	const acceleration_structure_t* structure = &app->scene.acceleration_structure;
+	if (!w || !w->ray_queue || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays || (wide_tree && !structure->wide_nodes)) {
+		printf("get_traversal_statistics_of_tree() needs a frame rendered with wavefront shadow rays (and the tree it is asked about).\n");
+		return 1;
+	}
 	unsigned long long* counters = NULL;
-	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 6), "allocating traversal counters")) return 1;
+	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 8), "allocating traversal counters")) return 1;
 	hipStream_t stream = (hipStream_t) app->device.stream;
 	(void) finish_frames(app);
-	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 6, stream);
-	bvh_view bvh = make_bvh_view(&app->scene.acceleration_structure);
-	k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
-	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 6, &app->device);
+	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, stream);
+	bvh_view bvh = make_bvh_view(structure);
+	if (wide_tree) k_traversal_statistics_wide<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, (const uint4*) structure->wide_nodes, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
+	else k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
+	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 8, &app->device);
 	(void) hipFree(counters);
 	return failed;
 }
 
 extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	unsigned long long rays = 0;
-	if (!app->shading_pass.ray_counter || !app->shading_pass.use_ray_tracing) return 0;
+	if (!app->shading_pass.ray_counter || !app->shading_pass.use_ray_tracing || !app->shading_pass.last_frame_traced_rays) return 0;
 	if (!app->shading_pass.inline_rays) {
 		const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 		const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
@@ -900,8 +1044,7 @@ __global__ void __launch_bounds__(256) k_assemble_frame(const PIXEL* slabs, PIXE
 }
 
 template <typename PIXEL>
-static int assemble_slabs(application_t* app, const void* gathered_slabs, void* out_frame) {
-	if (finish_frames(app)) return 1;
+static int assemble_slabs(application_t* app, const void* gathered_slabs, void* out_frame, hipStream_t stream) {
 	shade_params p;
 	memset(&p, 0, sizeof(p));
 	p.width = app->swapchain.extent.width;
@@ -912,17 +1055,20 @@ static int assemble_slabs(application_t* app, const void* gathered_slabs, void* 
 	fill_tile_schedule(p, &first, grid_blocks);
 	uint64_t slab_stride = (uint64_t) grid_blocks * 256;
 	dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
-	k_assemble_frame<PIXEL><<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const PIXEL*) gathered_slabs, (PIXEL*) out_frame,
+	k_assemble_frame<PIXEL><<<grid, 256, 0, stream>>>((const PIXEL*) gathered_slabs, (PIXEL*) out_frame,
 		p.width, p.height, p.tile_size, p.tiles_x, p.rank_count, slab_stride);
 	return hip_failed(hipGetLastError(), "assembling the frame");
 }
 
 extern "C" int assemble_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_radiance) {
-	return assemble_slabs<float4>(app, gathered_slabs, out_radiance ? out_radiance : app->render_targets.radiance);
+	// (the radiance target may still be written by frames in flight)
+	if (finish_frames(app)) return 1;
+	return assemble_slabs<float4>(app, gathered_slabs, out_radiance ? out_radiance : app->render_targets.radiance, (hipStream_t) app->device.stream);
 }
 
 extern "C" int assemble_encoded_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded) {
-	return assemble_slabs<uint32_t>(app, gathered_slabs, out_encoded ? out_encoded : app->render_targets.encoded);
+	if (finish_frames(app)) return 1;
+	return assemble_slabs<uint32_t>(app, gathered_slabs, out_encoded ? out_encoded : app->render_targets.encoded, (hipStream_t) app->device.stream);
 }
 
 // slabs of packed RGB8 (encode_slab_rgb8) -> RGBA8 frame; alpha of the encoded output is always
@@ -943,8 +1089,7 @@ __global__ void __launch_bounds__(256) k_assemble_frame_rgb8(const uint32_t* sla
 	for (uint32_t i = 0; i != 4 && px + i < width; ++i) target[i] = out[i];
 }
 
-extern "C" int assemble_rgb8_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded) {
-	if (finish_frames(app)) return 1;
+static int assemble_rgb8_slabs(application_t* app, const void* gathered_slabs, void* out_encoded, hipStream_t stream) {
 	shade_params p;
 	memset(&p, 0, sizeof(p));
 	p.width = app->swapchain.extent.width;
@@ -958,9 +1103,21 @@ extern "C" int assemble_rgb8_frame_from_slabs(application_t* app, const void* ga
 		return 1;
 	}
 	dim3 grid((p.width + 255) / 256, (p.height + 3) / 4);
-	k_assemble_frame_rgb8<<<grid, 256, 0, (hipStream_t) app->device.stream>>>((const uint32_t*) gathered_slabs, (uint32_t*) (out_encoded ? out_encoded : app->render_targets.encoded),
+	k_assemble_frame_rgb8<<<grid, 256, 0, stream>>>((const uint32_t*) gathered_slabs, (uint32_t*) (out_encoded ? out_encoded : app->render_targets.encoded),
 		p.width, p.height, p.tile_size, p.tiles_x, p.rank_count, (uint64_t) grid_blocks * 256);
 	return hip_failed(hipGetLastError(), "assembling the frame");
+}
+
+extern "C" int assemble_rgb8_frame_from_slabs(application_t* app, const void* gathered_slabs, void* out_encoded) {
+	if (finish_frames(app)) return 1;
+	return assemble_rgb8_slabs(app, gathered_slabs, out_encoded, (hipStream_t) app->device.stream);
+}
+
+// For host/slab_exchange.c: the scatter of gathered slabs on a stream of the caller's choice
+// (the exchange stream, so that it does not wait for later frames), format as slab_format_t
+extern "C" int vkr_assemble_slabs_on_stream(application_t* app, const void* gathered_slabs, void* out_frame, int format, void* stream) {
+	if (format == 0) return assemble_slabs<float4>(app, gathered_slabs, out_frame ? out_frame : app->render_targets.radiance, (hipStream_t) stream);
+	return assemble_rgb8_slabs(app, gathered_slabs, out_frame, (hipStream_t) stream);
 }
 
 // ---- output encoding (shading_pass.frag.glsl:871-892, srgb_utility.glsl) --------------
@@ -1060,6 +1217,7 @@ extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 	if (!app->render_targets.radiance || !app->render_targets.encoded || ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
 	k_encode_output<<<(uint32_t) ((pixels + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) app->render_targets.radiance, (uint32_t*) app->render_targets.encoded,
 		pixels, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
+	note_target_reader(app);
 	return hip_failed(hipGetLastError(), "encoding the output");
 }
 
@@ -1068,6 +1226,7 @@ extern "C" int encode_slab(application_t* app, const void* slab_radiance, void* 
 	if (!slab_radiance || !slab_encoded || ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
 	k_encode_output<<<(uint32_t) ((pixel_count + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_encoded,
 		pixel_count, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
+	note_target_reader(app);
 	return hip_failed(hipGetLastError(), "encoding the slab");
 }
 
@@ -1080,6 +1239,7 @@ extern "C" int encode_slab_rgb8(application_t* app, const void* slab_radiance, v
 	if (ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
 	k_encode_output_rgb8<<<(uint32_t) ((pixel_count / 4 + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_rgb8,
 		pixel_count / 4, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
+	note_target_reader(app);
 	return hip_failed(hipGetLastError(), "encoding the slab");
 }
 

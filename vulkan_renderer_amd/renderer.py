@@ -21,6 +21,9 @@ TECHNIQUE = {"baseline": 0, "area_turk": 1, "rectangle_solid_angle_urena": 2, "s
              "projected_solid_angle_arvo": 10, "solid_angle": 4, "clipped_solid_angle": 5, "projected_solid_angle": 11,
              "projected_solid_angle_biased": 12}
 NOISE = {"white": 0, "blue": 1, "ahmed": 2}
+# acceleration_structure_builder_t (include/vkr_scene.h); True selects the default (HIP kernels, binned SAH)
+BVH_BUILDER = {False: 0, None: 0, True: 1, "sah_device": 1, "lbvh_device": 2, "sah_host": 3}
+BVH_BUILDER_NAME = {0: "none", 1: "binned SAH built by HIP kernels", 2: "Morton-code LBVH built by HIP kernels", 3: "binned SAH built on the host"}
 
 
 def _enum(table, value):
@@ -42,7 +45,7 @@ class HostScene:
 
     def load_scene(self, path, texture_path=None, acceleration_structure=False):
         rc = self.lib.load_scene(C.byref(self.app.scene), self._dev(), path.encode(),
-                                 texture_path.encode() if texture_path else None, int(acceleration_structure))
+                                 texture_path.encode() if texture_path else None, BVH_BUILDER[acceleration_structure])
         if rc:
             raise RuntimeError("load_scene failed for %s" % path)
 
@@ -201,6 +204,8 @@ class HostScene:
     def close(self):
         app = self.app
         dev = self._dev()
+        if getattr(self, "exchange", None) is not None:
+            self.destroy_exchange()
         if app.shading_pass.constants_device:
             self.lib.destroy_shading_pass(C.byref(app.shading_pass), dev)
         if app.render_targets.radiance:
@@ -223,8 +228,10 @@ class HostScene:
 class Renderer(HostScene):
     """The shading pass on one MI355X."""
 
-    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1):
+    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1, binary_traversal=False):
         super().__init__()
+        self.binary_traversal = binary_traversal
+        self.exchange = None
         self.timing_stride = timing_stride
         self.frames_in_flight = frames_in_flight
         if self.lib.create_hip_device(C.byref(self.app.device), hip_device, stream):
@@ -246,12 +253,13 @@ class Renderer(HostScene):
         self.app.shading_pass.inline_rays = int(self.inline_rays)
         self.app.shading_pass.timing_stride = int(self.timing_stride)
         self.app.shading_pass.frames_in_flight = int(self.frames_in_flight)
+        self.app.shading_pass.binary_traversal = int(self.binary_traversal)
         if self.lib.create_shading_pass(C.byref(self.app.shading_pass), C.byref(self.app)):
             raise RuntimeError("create_shading_pass failed")
 
-    def set_tiles(self, tile_size=16, rank=0, rank_count=1):
+    def set_tiles(self, tile_size=16, rank=0, rank_count=1, slab_layout=False):
         t = self.app.tile_schedule
-        t.tile_size, t.rank, t.rank_count = tile_size, rank, rank_count
+        t.tile_size, t.rank, t.rank_count, t.slab_layout = tile_size, rank, rank_count, int(slab_layout)
 
     def upload_visibility(self, visibility):
         v = np.ascontiguousarray(visibility, np.uint32)
@@ -298,13 +306,57 @@ class Renderer(HostScene):
     def last_ray_count(self):
         return int(self.lib.get_last_ray_count(C.byref(self.app)))
 
-    def traversal_statistics(self):
-        """Work of the BVH traversal for the rays of the last wavefront frame (diagnostics)."""
-        out = (C.c_uint64 * 6)()
-        if self.lib.get_traversal_statistics(C.byref(self.app), out):
-            raise RuntimeError("get_traversal_statistics failed")
-        keys = ("rays", "node_visits", "triangle_tests", "blocked_rays", "wave_steps", "longest_ray_visits")
-        return dict(zip(keys, (int(v) for v in out)))
+    def traversal_statistics(self, wide_tree=None):
+        """Work of the BVH traversal for the rays of the last wavefront frame (diagnostics).
+        wide_tree None: the tree the frame walked; True / False: the four-wide / the binary one."""
+        out = (C.c_uint64 * 8)()
+        if wide_tree is None:
+            wide_tree = bool(self.app.scene.acceleration_structure.wide_nodes) and not self.app.shading_pass.binary_traversal
+        if self.lib.get_traversal_statistics_of_tree(C.byref(self.app), int(wide_tree), out):
+            raise RuntimeError("get_traversal_statistics_of_tree failed")
+        keys = ("rays", "node_visits", "triangle_tests", "blocked_rays", "wave_steps", "longest_ray_visits", "boxes_tested", "deepest_stack")
+        stats = dict(zip(keys, (int(v) for v in out)))
+        stats["tree"] = "wide" if wide_tree else "binary"
+        if not wide_tree:
+            stats["boxes_tested"] = stats["node_visits"]
+            del stats["deepest_stack"]
+        return stats
+
+    # -- multi-GPU exchange (include/vkr_slab_exchange.h) ---------------------------------
+    def exchange_id(self):
+        """The rendezvous token of a new communicator as 128 bytes (call on one rank, broadcast)."""
+        token = capi.SlabExchangeId()
+        if self.lib.get_slab_exchange_id(C.byref(token)):
+            raise RuntimeError("get_slab_exchange_id failed (RCCL missing?)")
+        return bytes(C.string_at(C.byref(token), 128))
+
+    def create_exchange(self, token_bytes, slab_format="rgba32f"):
+        token = capi.SlabExchangeId()
+        C.memmove(C.byref(token), token_bytes, 128)
+        self.exchange = capi.SlabExchange()
+        if self.lib.create_slab_exchange(C.byref(self.exchange), C.byref(self.app), C.byref(token), capi.SLAB_FORMAT[slab_format]):
+            self.exchange = None
+            raise RuntimeError("create_slab_exchange failed")
+
+    def destroy_exchange(self):
+        if self.exchange is not None:
+            self.lib.destroy_slab_exchange(C.byref(self.exchange), C.byref(self.app))
+            self.exchange = None
+
+    def render_and_exchange(self, out_pointer=None):
+        if self.lib.render_and_exchange_frame(C.byref(self.app), C.byref(self.exchange), out_pointer):
+            raise RuntimeError("render_and_exchange_frame failed")
+
+    def finish_exchange(self):
+        if self.lib.finish_slab_exchange(C.byref(self.app), C.byref(self.exchange)):
+            raise RuntimeError("finish_slab_exchange failed")
+
+    def exchange_ms(self):
+        """(shade, all-gather, scatter) of the most recent timed frame, or None"""
+        out = (C.c_float * 3)()
+        if not self.lib.get_slab_exchange_milliseconds(C.byref(self.exchange), out):
+            return None
+        return [float(v) for v in out]
 
     def sync(self):
         self.lib.wait_for_device(C.byref(self.app.device))
@@ -368,7 +420,8 @@ def setup_config(scene, config, dataset, width=None, height=None, **overrides):
         settings["height"] = height
     settings.update(overrides)
     wants_rays = bool(settings.get("trace_shadow_rays", False))
-    scene.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=wants_rays or overrides.get("acceleration_structure", False))
+    # (a builder named by the caller wins; rays alone ask for the default builder)
+    scene.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=overrides.get("acceleration_structure") or wants_rays)
     scene.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
     scene.load_noise_table("white")
     cam = synthetic.DEFAULT_CAMERA

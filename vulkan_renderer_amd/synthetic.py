@@ -419,6 +419,9 @@ def config_lights(config):
         return [light_spec([(0, 0), (1, 0), (0, 1)], (-1.0, 0.5, 3.0), (pi, 0.0, 0.0), (10, 10, 10), (1.5, 1.5))]
     if config == 2:
         return [light_spec(regular_polygon(5), (-0.5, 1.0, 2.5), (0.85 * pi, 0.1, 0.3), (12, 11, 10), (1.6, 1.6))]
+    if config == "target":
+        # north_star's target shape: one light of config 3
+        return config_lights(3)[:1]
     if config == 3:
         out = []
         for k, (tx, ty) in enumerate([(-1.5, 1.5), (1.5, 1.5), (-1.5, 4.0), (1.5, 4.0)]):
@@ -448,6 +451,9 @@ CONFIG_SETTINGS = {
             polygon_technique="projected_solid_angle", trace_shadow_rays=True),
     4: dict(width=3840, height=2160, sample_count=8, sampling_strategies="diffuse_specular_mis", mis_heuristic="optimal_clamped",
             polygon_technique="projected_solid_angle", trace_shadow_rays=True),
+    # BASELINE.json north_star target: ">= 1 Gsample/s at 1920x1080, 4 spp, 1 polygonal light"
+    "target": dict(width=1920, height=1080, sample_count=4, sampling_strategies="diffuse_specular_mis", mis_heuristic="optimal_clamped",
+                   polygon_technique="projected_solid_angle", trace_shadow_rays=True),
 }
 
 
