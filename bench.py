@@ -328,7 +328,8 @@ def run_workload(job, config, primary):
             table = json.load(open(pmc_path))
             entry = table.get("config%s_%s" % (config, args.mode))
             if entry and world == 1 and width == entry.get("width") and height == entry.get("height"):
-                pmc = entry
+                pmc = dict(entry)
+                pmc["valu_floor_us"] = table.get("config%s_%s_valu_floor_us" % (config, args.mode))
         except Exception:
             pmc = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
@@ -345,7 +346,7 @@ def run_workload(job, config, primary):
     if pmc and pmc.get("valu_floor_us"):
         # the bound that actually holds: wave64 VALU instructions counted by the PMC pass in profiles/
         # x 4 clocks / 1024 SIMDs / 2.4 GHz, per kernel of the pass
-        floors = pmc["valu_floor_us"]
+        floors = {k: v for k, v in pmc["valu_floor_us"].items() if isinstance(v, (int, float))}
         roofline["valu_issue"] = {"shade_pixels_floor_ms": round(floors.get("shade_pixels", 0.0) * 1e-3, 4),
                                   "shade_pixels_frac": round(floors.get("shade_pixels", 0.0) * 1e-3 / kernel_ms, 4),
                                   "floor_ms_per_pass": round(sum(floors.values()) * 1e-3, 4), "frac_of_ms_per_step": round(sum(floors.values()) * 1e-3 / ms_per_step, 4),

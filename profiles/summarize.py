@@ -69,7 +69,7 @@ def main():
                 serial_us[row["Name"].split("(")[0]] = float(row["AverageNs"]) / 1e3
             lines.append("")
         merged, meta = {}, {}
-        for p in (1, 2, 3, 4):
+        for p in (1, 2, 3, 4, 5):
             c, m = counters(os.path.join(base, "cfg%d_pmc%d" % (cfg, p)))
             for k, v in c.items():
                 merged.setdefault(k, {}).update(v)
