@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvkr_shading.so")
+# VKR_SHADING_LIBRARY: an alternative build of the same library for A/B measurements (profiles/tools/ab_build.sh)
+LIB_PATH = os.environ.get("VKR_SHADING_LIBRARY") or os.path.join(_HERE, "libvkr_shading.so")
 
 c_float_p = C.POINTER(C.c_float)
 

@@ -13,8 +13,8 @@
 // Layout in HBM ("threaded" BVH): all 2n-1 nodes of the binary tree, inner nodes and
 // leaves alike, stored in depth-first order as 16 bytes each:
 //     uint4 = (lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16, link)
-// Box coordinates are 16-bit positions on a uniform grid over the (padded) scene box,
-// rounded outwards, so the quantised box contains the fp32 box.  The left child of an
+// Box coordinates are 15-bit positions (kGridMax, see "wide BVH") on a uniform grid over the
+// (padded) scene box, rounded outwards, so the quantised box contains the fp32 box.  The left child of an
 // inner node is the next node; for an inner node `link` is the index of the node that
 // follows its whole subtree, for a leaf it is 0x80000000 | triangle slot (the node after
 // a leaf is always the next one).  A ray walks the array with a single cursor: hit ->
@@ -131,10 +131,10 @@ VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) 
 // The binary tree collapsed to four children per node (lbvh_build.hip k_collapse_level: a node's
 // two children, then twice the child with the largest box replaced by its own children).  One node
 // is 64 bytes = one half cache line, fetched with four dwordx4 loads:
-//     uint4 x = (lo.x | hi.x << 16) of children 0..3      (same 16-bit grid as the binary nodes)
+//     uint4 x = (lo.x | hi.x << 16) of children 0..3      (same grid as the binary nodes)
 //     uint4 y, uint4 z likewise
 //     uint4 link: child is an inner node -> its index; a triangle -> kLeafBit | triangle slot;
-//                 absent -> kWideEmpty
+//                 absent -> kWideEmpty (and the box kWideEmptyBox, which no ray hits)
 // The children of a node are stored next to each other and levels one after the other, so the
 // first nodes of the array are the top of the tree.  A visit tests four boxes with one dependent
 // fetch, which shortens the chain of dependent fetches per ray four- to fivefold against the
@@ -145,9 +145,48 @@ VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) 
 constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kWideStackLds = 16;   // stack entries per lane that live in LDS
 constexpr uint32_t kWideStackMax = 128;  // deepest stack the kernels are prepared for (else: binary walk)
+// Grid coordinates are 15-bit (0 ... kGridMax): a plane q then sits in bits 8 ... 22 of the float
+// 2^15 + q, i.e. one v_perm_b32 turns a packed pair (lo | hi << 16) into that float - and the byte
+// selector chooses lo or hi per lane, so the near and the far plane of a ray's octant come out of
+// the same instruction (wide_ray below).  A 16-bit grid would need a conversion and a min / max
+// per plane: 93 instead of 62 clocks of VALU issue per box (profiles/tools/valu_rate.hip).
+constexpr float kGridMax = 32767.0f;
+// box of an absent child of a wide node: lo > hi on every axis, never hit
+constexpr uint32_t kWideEmptyBox = 0x00007FFFu;
 
-VKR_DEV bool ray_box_packed(uint32_t qx, uint32_t qy, uint32_t qz, const grid_ray& r, float t_min, float t_max) {
-	return ray_box(make_uint4(qx, qy, qz, 0u), r, t_min, t_max);
+// A ray prepared for the four-wide nodes: t = (2^15 + q) * inv + shift with the 2^15 folded into
+// shift (2^15 * inv is at most 2^-9 cells off after rounding; the boxes carry kGridMargin = 0.05),
+// and per axis the v_perm_b32 selectors of the plane the ray enters through and the one it leaves
+// through.  Selector bytes: 0x0C -> 0x00, 4 ... 7 -> bytes of the packed pair, 3 -> 0x47.
+struct wide_ray {
+	f3 inv, shift;
+	uint32_t near_x, near_y, near_z;
+};
+constexpr uint32_t kPermLo = 0x0305040Cu, kPermHi = 0x0307060Cu, kPermFlip = kPermLo ^ kPermHi, kPermMagic = 0x47000000u;
+
+VKR_DEV wide_ray make_wide_ray(const grid_ray& r) {
+	wide_ray w;
+	w.inv = r.inv;
+	w.shift = mk3(fmaf(-32768.0f, r.inv.x, r.shift.x), fmaf(-32768.0f, r.inv.y, r.shift.y), fmaf(-32768.0f, r.inv.z, r.shift.z));
+	// the sign bit decides (inv = -inf for d = -0 as well)
+	w.near_x = (__float_as_uint(r.inv.x) >> 31) ? kPermHi : kPermLo;
+	w.near_y = (__float_as_uint(r.inv.y) >> 31) ? kPermHi : kPermLo;
+	w.near_z = (__float_as_uint(r.inv.z) >> 31) ? kPermHi : kPermLo;
+	return w;
+}
+
+// Conservative slab test of one child box of a wide node.  A NaN (0 * inf for a ray inside a slab
+// it runs parallel to) is ignored by min / max, which is conservative.
+VKR_DEV bool wide_ray_box(uint32_t qx, uint32_t qy, uint32_t qz, const wide_ray& r, float t_min, float t_max) {
+	float nx = fmaf(__uint_as_float(__builtin_amdgcn_perm(qx, kPermMagic, r.near_x)), r.inv.x, r.shift.x);
+	float fx = fmaf(__uint_as_float(__builtin_amdgcn_perm(qx, kPermMagic, r.near_x ^ kPermFlip)), r.inv.x, r.shift.x);
+	float ny = fmaf(__uint_as_float(__builtin_amdgcn_perm(qy, kPermMagic, r.near_y)), r.inv.y, r.shift.y);
+	float fy = fmaf(__uint_as_float(__builtin_amdgcn_perm(qy, kPermMagic, r.near_y ^ kPermFlip)), r.inv.y, r.shift.y);
+	float nz = fmaf(__uint_as_float(__builtin_amdgcn_perm(qz, kPermMagic, r.near_z)), r.inv.z, r.shift.z);
+	float fz = fmaf(__uint_as_float(__builtin_amdgcn_perm(qz, kPermMagic, r.near_z ^ kPermFlip)), r.inv.z, r.shift.z);
+	float near = fmaxf(fmaxf(nx, ny), fmaxf(nz, t_min));
+	float far = fminf(fminf(fx, fy), fminf(fz, t_max));
+	return near <= far;
 }
 
 // Closest hit with back-face culling (primary visibility).  Returns the original

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_thread_nodes(int leaf_count, const bvh_
 }
 
 // fp32 threaded nodes (32 bytes: lo.xyz, hi.x | hi.yz, skip, leaf) -> 16-byte nodes with
-// boxes rounded outwards on the 16-bit grid (layout: lbvh.h)
+// boxes rounded outwards on the 15-bit grid (layout: lbvh.h)
 __global__ void __launch_bounds__(256) k_quantize_nodes(uint32_t node_count, const float4* nodes, f3 origin, f3 inverse_cell, uint4* quantized) {
 	uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
 	if (id >= node_count) return;
@@ -189,8 +189,8 @@ __global__ void __launch_bounds__(256) k_quantize_nodes(uint32_t node_count, con
 	for (int j = 0; j != 3; ++j) {
 		float q0 = floorf((lo[j] - g0[j]) * scale[j] - kGridMargin);
 		float q1 = ceilf((hi[j] - g0[j]) * scale[j] + kGridMargin);
-		q0 = fminf(fmaxf(q0, 0.0f), 65535.0f);
-		q1 = fminf(fmaxf(q1, 0.0f), 65535.0f);
+		q0 = fminf(fmaxf(q0, 0.0f), kGridMax);
+		q1 = fminf(fmaxf(q1, 0.0f), kGridMax);
 		packed[j] = (uint32_t) q0 | ((uint32_t) q1 << 16);
 	}
 	uint32_t skip = __float_as_uint(b.z), leaf = __float_as_uint(b.w);
@@ -511,9 +511,11 @@ __global__ void __launch_bounds__(64) k_collapse_level(const uint4* binary, cons
 	for (uint32_t c = 0; c != count; ++c) inner += (node[c].w & kLeafBit) ? 0u : 1u;
 	uint32_t base = inner ? atomicAdd(&counters[1], inner) : 0u;
 	uint32_t next_base = inner ? atomicAdd(&counters[0], inner) : 0u;
+	// a ray that hits all children has them all on its stack before it takes the first one off again
 	uint32_t need = item.need + count - 1u;
-	atomicMax(&counters[2], need);
-	uint32_t qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0}, qz[4] = {0, 0, 0, 0}, link[4] = {kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty};
+	atomicMax(&counters[2], item.need + count);
+	uint32_t qx[4] = {kWideEmptyBox, kWideEmptyBox, kWideEmptyBox, kWideEmptyBox}, qy[4] = {kWideEmptyBox, kWideEmptyBox, kWideEmptyBox, kWideEmptyBox},
+		qz[4] = {kWideEmptyBox, kWideEmptyBox, kWideEmptyBox, kWideEmptyBox}, link[4] = {kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty};
 	uint32_t k = 0;
 	for (uint32_t c = 0; c != count; ++c) {
 		qx[c] = node[c].x; qy[c] = node[c].y; qz[c] = node[c].z;
@@ -541,9 +543,9 @@ static int quantize_nodes(acceleration_structure_t* structure, const device_t* d
 	if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(root, structure->nodes, sizeof(root), hipMemcpyDeviceToHost) != hipSuccess) return 1;
 	const float lo[3] = {root[0], root[1], root[2]}, hi[3] = {root[3], root[4], root[5]};
 	for (int j = 0; j != 3; ++j) {
-		// one spare cell on either side keeps every box strictly inside [0, 65535]
+		// one spare cell on either side keeps every box strictly inside [0, kGridMax]
 		float extent = fmaxf(hi[j] - lo[j], 1.0e-20f);
-		float cell = extent / 65533.0f;
+		float cell = extent / (kGridMax - 2.0f);
 		structure->grid_origin[j] = lo[j] - cell;
 		structure->grid_inverse_cell[j] = 1.0f / cell;
 	}

@@ -1263,7 +1263,10 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 #endif
 inline namespace VKR_MODE_NAMESPACE {
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
-__global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
+#ifndef VKR_SHADE_BOUNDS
+#define VKR_SHADE_BOUNDS 256
+#endif
+__global__ void __launch_bounds__(VKR_SHADE_BOUNDS) shade_pixels(const shade_params p) {
 	uint32_t px, py;
 	size_t out_index;
 	bool inside = locate_pixel(p, px, py, out_index);
@@ -1333,286 +1336,5 @@ __global__ void __launch_bounds__(256) shade_pixels(const shade_params p) {
 }
 
 }  // inline namespace VKR_MODE_NAMESPACE
-
-// ---- wavefront: trace and resolve (instantiated once, in shading_pass.hip) -------------------
-#ifdef VKR_WAVEFRONT_KERNELS
-
-// Persistent waves trace the queued shadow rays.  Few registers, no LDS, no scratch:
-// 8 waves per SIMD hide the latency of the dependent node fetches.
-//  - Queues 64 x ... 64 x + 63 are served only by workgroups that run on XCD x
-//    (workgroup b is placed on XCD b % 8; used for cache affinity only, never for
-//    correctness), so counters and cursors never bounce between the eight L2s.
-//  - A wave claims kRayChunk rays with one atomic on its XCD's cursor and locates
-//    the chunk with a wave-wide prefix sum over the 64 queue sizes of that XCD.
-//  - Lanes whose ray has finished are refilled from the chunk while the others keep
-//    walking (shadow rays differ a lot in length), so lanes stay busy.
-// A ray that reaches the light flips its term's code to kCodeVisible.
-__global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t refill_threshold) {
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t xcd = blockIdx.x & 7u;
-	// exclusive prefix sum of the chunk counts of this XCD's 64 queues, one queue per lane
-	const uint32_t my_queue = xcd * 64u + lane;
-	const uint32_t my_size = ray_queue_size[my_queue];
-	// chunk size: large enough to keep the atomics rare, small enough that every resident
-	// wave of this XCD gets about two chunks (few rays: config 2 queues 0.9 M, config 3 29 M)
-	uint32_t xcd_rays = my_size;
-#pragma unroll
-	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
-	const uint32_t xcd_waves = (gridDim.x / 8u) * 4u;
-	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
-	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
-	uint32_t inclusive = my_chunks;
-#pragma unroll
-	for (int offset = 1; offset < 64; offset <<= 1) {
-		uint32_t other = __shfl_up(inclusive, offset);
-		if (lane >= (uint32_t) offset) inclusive += other;
-	}
-	const uint32_t exclusive = inclusive - my_chunks;
-	const uint32_t total_chunks = __shfl(inclusive, 63);
-	const uint32_t end = bvh.node_count;
-	// wave-uniform description of the claimed chunk
-	const float4* chunk_rays = ray_queue;
-	uint32_t chunk_count = 0, chunk_next = 0;
-	bool chunks_left = true;
-	// per-lane ray; a lane without a ray has the cursor kIdle (the walk and the ballots test the
-	// cursor itself: a separate flag costs two more instructions per step)
-	constexpr uint32_t kIdle = 0xFFFFFFFFu;
-	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
-	grid_ray ray = {o, o};
-	float t_max = 0.0f;
-	uint32_t node = kIdle, code_index = 0;
-	while (true) {
-		// ---- hand new rays to idle lanes ------------------------------------------------
-		uint64_t idle = __ballot(node == kIdle);
-		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
-			if (chunk_next >= chunk_count) {
-				uint32_t chunk = 0;
-				if (lane == 0) chunk = atomicAdd(work_cursors + xcd * kCursorStride, 1u);
-				chunk = __builtin_amdgcn_readfirstlane(chunk);
-				if (chunk >= total_chunks) { chunks_left = false; break; }
-				uint64_t owner = __ballot(my_chunks != 0 && exclusive <= chunk && chunk < inclusive);
-				int owner_lane = __ffsll((unsigned long long) owner) - 1;
-				uint32_t queue = xcd * 64u + (uint32_t) owner_lane;
-				uint32_t first = (chunk - __shfl(exclusive, owner_lane)) * chunk_size;
-				uint32_t size = __shfl(my_size, owner_lane);
-				chunk_rays = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + first);
-				chunk_count = min(chunk_size, size - first);
-				chunk_next = 0;
-			}
-			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-			uint32_t index = chunk_next + rank;
-			if (node == kIdle && index < chunk_count) {
-				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
-				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
-				code_index = __float_as_uint(b.w);
-				ray = make_grid_ray(bvh, o, d);
-				node = 0;
-				if (!(t_max >= 1.0e-3f)) {
-					// empty interval: nothing can block the ray (same rule as any_hit); or a
-					// slot that the shading wave reserved and did not need
-					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
-					node = kIdle;
-				}
-			}
-			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
-			idle = __ballot(node == kIdle);
-		}
-		uint64_t busy = __ballot(node != kIdle);
-		if (busy == 0) break;
-		// ---- walk until too many lanes have run dry (then refill) -------------------------
-		bool may_refill = chunk_next < chunk_count || chunks_left;
-		do {
-			if (node != kIdle) {
-				uint4 n = bvh.nodes[node];
-				bool is_leaf = (n.w & kLeafBit) != 0;
-				bool hit = ray_box(n, ray, 1.0e-3f, t_max);
-				bool blocked = false;
-				if (hit && is_leaf) {
-					const float4* t = bvh.triangles + 3 * (size_t) (n.w & ~kLeafBit);
-					float dist;
-					blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
-				}
-				node = (hit || is_leaf) ? node + 1 : n.w;
-				if (!blocked && node >= end) codes[code_index] = (uint8_t) kCodeVisible;
-				if (blocked || node >= end) node = kIdle;
-			}
-			busy = __ballot(node != kIdle);
-		} while (busy != 0 && (!may_refill || __popcll((unsigned long long) busy) > refill_threshold));
-	}
-}
-
-// The same persistent scheme on the four-wide tree (lbvh.h "wide BVH"): a visit fetches one
-// 64-byte node and tests its four boxes, hit children beyond the first go to the lane's stack
-// (kWideStackLds entries in LDS, [entry][thread]; deeper ones in `spill`, [entry][global thread],
-// which exists only if the tree can need them).  A lane whose next item is a triangle waits until
-// `leaf_batch` lanes of the wave have one (or no lane has a node left), so that the triangle test
-// runs with many lanes: the two kinds of work no longer share every step of the loop.
-__global__ void __launch_bounds__(256) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch) {
-	__shared__ uint32_t stack[kWideStackLds * 256];
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t xcd = blockIdx.x & 7u;
-	const uint32_t my_queue = xcd * 64u + lane;
-	const uint32_t my_size = ray_queue_size[my_queue];
-	uint32_t xcd_rays = my_size;
-#pragma unroll
-	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
-	const uint32_t xcd_waves = (gridDim.x / 8u) * 4u;
-	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
-	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
-	uint32_t inclusive = my_chunks;
-#pragma unroll
-	for (int offset = 1; offset < 64; offset <<= 1) {
-		uint32_t other = __shfl_up(inclusive, offset);
-		if (lane >= (uint32_t) offset) inclusive += other;
-	}
-	const uint32_t exclusive = inclusive - my_chunks;
-	const uint32_t total_chunks = __shfl(inclusive, 63);
-	const float4* chunk_rays = ray_queue;
-	uint32_t chunk_count = 0, chunk_next = 0;
-	bool chunks_left = true;
-	// `item`: what the lane looks at next - a wide node (index), a triangle (kLeafBit | slot) or
-	// nothing (kIdle: the lane has no ray)
-	constexpr uint32_t kIdle = 0xFFFFFFFFu;
-	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
-	grid_ray ray = {o, o};
-	float t_max = 0.0f;
-	uint32_t item = kIdle, code_index = 0, depth = 0;
-	uint32_t* my_stack = stack + threadIdx.x;
-	uint32_t* my_spill = spill + (size_t) blockIdx.x * 256u + threadIdx.x;
-	const size_t spill_stride = (size_t) gridDim.x * 256u;
-	while (true) {
-		// ---- hand new rays to idle lanes (as in trace_shadow_rays) --------------------------
-		uint64_t idle = __ballot(item == kIdle);
-		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
-			if (chunk_next >= chunk_count) {
-				uint32_t chunk = 0;
-				if (lane == 0) chunk = atomicAdd(work_cursors + xcd * kCursorStride, 1u);
-				chunk = __builtin_amdgcn_readfirstlane(chunk);
-				if (chunk >= total_chunks) { chunks_left = false; break; }
-				uint64_t owner = __ballot(my_chunks != 0 && exclusive <= chunk && chunk < inclusive);
-				int owner_lane = __ffsll((unsigned long long) owner) - 1;
-				uint32_t queue = xcd * 64u + (uint32_t) owner_lane;
-				uint32_t first = (chunk - __shfl(exclusive, owner_lane)) * chunk_size;
-				uint32_t size = __shfl(my_size, owner_lane);
-				chunk_rays = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + first);
-				chunk_count = min(chunk_size, size - first);
-				chunk_next = 0;
-			}
-			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-			uint32_t index = chunk_next + rank;
-			if (item == kIdle && index < chunk_count) {
-				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
-				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
-				code_index = __float_as_uint(b.w);
-				ray = make_grid_ray(bvh, o, d);
-				item = 0;
-				depth = 0;
-				if (!(t_max >= 1.0e-3f)) {
-					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
-					item = kIdle;
-				}
-			}
-			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
-			idle = __ballot(item == kIdle);
-		}
-		if (__ballot(item != kIdle) == 0) break;
-		// ---- walk until every lane has run dry -----------------------------------------------
-		while (true) {
-			bool at_node = item != kIdle && !(item & kLeafBit);
-			bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
-			uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
-			if ((node_lanes | leaf_lanes) == 0) break;
-			bool pop = false;
-			if (at_node) {
-				const uint4* n = wide_nodes + 4 * (size_t) item;
-				uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
-				bool h0 = link.x != kWideEmpty && ray_box_packed(qx.x, qy.x, qz.x, ray, 1.0e-3f, t_max);
-				bool h1 = link.y != kWideEmpty && ray_box_packed(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
-				bool h2 = link.z != kWideEmpty && ray_box_packed(qx.z, qy.z, qz.z, ray, 1.0e-3f, t_max);
-				bool h3 = link.w != kWideEmpty && ray_box_packed(qx.w, qy.w, qz.w, ray, 1.0e-3f, t_max);
-				// the first hit child is next, the others wait on the stack
-				uint32_t next = kIdle;
-				const bool hits[4] = {h0, h1, h2, h3};
-				const uint32_t links[4] = {link.x, link.y, link.z, link.w};
-#pragma unroll
-				for (int c = 0; c != 4; ++c) {
-					if (!hits[c]) continue;
-					if (next == kIdle) next = links[c];
-					else {
-						if (depth < kWideStackLds) my_stack[depth * 256u] = links[c];
-						else my_spill[(size_t) (depth - kWideStackLds) * spill_stride] = links[c];
-						++depth;
-					}
-				}
-				item = next;
-				pop = next == kIdle;
-			}
-			bool test_leaves = leaf_lanes != 0 && (node_lanes == 0 || (uint32_t) __popcll((unsigned long long) leaf_lanes) >= leaf_batch);
-			if (test_leaves && at_leaf) {
-				const float4* t = bvh.triangles + 3 * (size_t) (item & ~kLeafBit);
-				float dist;
-				bool blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
-				// a blocked ray is done: its term keeps the code the shading kernel gave it
-				if (blocked) { item = kIdle; depth = 0; }
-				else pop = true;
-			}
-			if (pop) {
-				if (depth == 0) {
-					codes[code_index] = (uint8_t) kCodeVisible;
-					item = kIdle;
-				}
-				else {
-					--depth;
-					item = depth < kWideStackLds ? my_stack[depth * 256u] : my_spill[(size_t) (depth - kWideStackLds) * spill_stride];
-				}
-			}
-		}
-	}
-}
-
-// Replays every pixel's sums in the order of the shading program: terms of one light
-// are added one after the other, the light's sum is scaled by 1 / SAMPLE_COUNT and
-// added to the colour (shading_pass.frag.glsl:710, :858), then NaN check and exposure.
-VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
-	uint32_t px, py;
-	size_t out_index;
-	if (!locate_pixel(p, px, py, out_index)) return;
-	uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-	float4 base = p.base_color[tid];
-	f3 color = mk3(base.x, base.y, base.z);
-	f3 sum = mk3(0.0f, 0.0f, 0.0f);
-	float rcp_samples = 1.0f / (float) p.sample_count;
-	uint32_t term = 0;
-	for (uint32_t k = 0; k < p.max_codes; ++k) {
-		uint32_t code = p.codes[(size_t) k * p.thread_count + tid];
-		if (code == kCodeEnd) break;
-		if (code == kCodeEndOfLight) {
-			color = color + sum * rcp_samples;
-			sum = mk3(0.0f, 0.0f, 0.0f);
-			continue;
-		}
-		size_t index = ((size_t) term * p.thread_count + tid) * 3;
-		++term;
-		if (code == kCodeVisible || code == kCodeFinal)
-			sum = sum + mk3(p.terms_visible[index], p.terms_visible[index + 1], p.terms_visible[index + 2]);
-		else if (code == kCodePendingWithHidden)
-			sum = sum + mk3(p.terms_hidden[index], p.terms_hidden[index + 1], p.terms_hidden[index + 2]);
-	}
-	store_final_color(p, out_index, color);
-}
-
-// Leaves the ray queues empty for the next frame (saves two fill launches per frame) and
-// keeps a copy of the counters for get_last_ray_count() / get_traversal_statistics().
-__global__ void __launch_bounds__(256) resolve_shadow_terms_and_reset(const shade_params p) {
-	resolve_shadow_terms_body(p);
-	if (blockIdx.x == 0) {
-		uint32_t* counters = const_cast<uint32_t*>(p.ray_queue_size);
-		for (uint32_t i = threadIdx.x; i < kRayCounterCount; i += 256u) {
-			counters[kRayCounterCount + i] = counters[i];
-			counters[i] = 0;
-		}
-	}
-}
-#endif
 
 }  // namespace vkr

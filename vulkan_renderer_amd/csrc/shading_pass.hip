@@ -2,8 +2,7 @@
 // output encoding and read-back behind the reference's entry points
 // (create_shading_pass src/main.c:598, write_constants :2114, the vkCmdDraw of
 // record_render_frame_commands :1428-1434, implement_screenshot :1719).
-#define VKR_WAVEFRONT_KERNELS 1
-#include "shading_kernel.h"
+#include "wavefront_kernels.h"
 #include "host/vkr_internal.h"
 #include <hip/hip_fp16.h>
 
@@ -929,7 +928,7 @@ __global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh,
 			float4 a = r[0], b = r[1];
 			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
 			float t_max = a.w;
-			grid_ray ray = make_grid_ray(bvh, o, d);
+			wide_ray ray = make_wide_ray(make_grid_ray(bvh, o, d));
 			uint32_t stack[kWideStackMax];
 			uint32_t depth = 0, deepest = 0, item = 0;
 			bool blocked = false, done = !(t_max >= 1.0e-3f);
@@ -952,7 +951,7 @@ __global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh,
 					for (int c = 0; c != 4; ++c) {
 						if (links[c] == kWideEmpty) continue;
 						++boxes;
-						if (!ray_box_packed(x[c], y[c], z[c], ray, 1.0e-3f, t_max)) continue;
+						if (!wide_ray_box(x[c], y[c], z[c], ray, 1.0e-3f, t_max)) continue;
 						if (item == 0xFFFFFFFFu) item = links[c];
 						else if (depth < kWideStackMax) stack[depth++] = links[c];
 					}
