@@ -353,6 +353,13 @@ VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics
 	walked, plus [6] boxes tested (wide tree only) and [7] the deepest stack a ray reached (wide tree only) */
 VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]);
 
+/*! Diagnostics for the arithmetic contract of the kernels (csrc/device_math.h, mirrored by
+	oracle/oracle_math.h): evaluates one primitive of the exact arithmetic mode element-wise on the
+	device.  operation 0: divide(a, b), 1: square_root(a), 2: rsqrt(a), 3: the compiler's IEEE a / b,
+	4: the compiler's IEEE sqrtf(a).  a, b (may be NULL for unary operations) and out are host
+	arrays of `count` floats.  0 on success. */
+VKR_API int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count);
+
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,
 	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,
 	materials_t, acceleration_structure_t, scene_t, scene_specification_t,

@@ -1,0 +1,104 @@
+"""The arithmetic contract of the exact mode (vulkan_renderer_amd/csrc/device_math.h): division and
+square root are the correctly rounded IEEE results - the ones the CPU oracle computes with `/` and
+sqrtf - for every operand outside the last decades of the exponent range, and for zeros, infinities
+and NaNs.  The primitives are evaluated on the device through the C-ABI
+(evaluate_device_arithmetic) and compared bit for bit with numpy's float32 arithmetic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from vulkan_renderer_amd import renderer
+
+pytestmark = pytest.mark.gpu
+
+
+def evaluate(r, operation, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.zeros_like(a)
+    fp = C.POINTER(C.c_float)
+    b_pointer = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32)
+        b_pointer = b.ctypes.data_as(fp)
+    assert r.lib.evaluate_device_arithmetic(C.byref(r.app.device), operation, a.ctypes.data_as(fp), b_pointer, out.ctypes.data_as(fp), a.size) == 0
+    return out
+
+
+def same_bits(x, y):
+    x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+    both_nan = np.isnan(x) & np.isnan(y)
+    return (x.view(np.uint32) == y.view(np.uint32)) | both_nan
+
+
+@pytest.fixture(scope="module")
+def device():
+    r = renderer.Renderer()
+    yield r
+    r.close()
+
+
+def random_floats(rng, count, low_exponent, high_exponent):
+    """Signed floats with uniformly random mantissas and exponents in [low, high)"""
+    mantissa = rng.integers(0, 1 << 23, count, dtype=np.uint32)
+    exponent = rng.integers(low_exponent + 127, high_exponent + 127, count, dtype=np.uint32)
+    sign = rng.integers(0, 2, count, dtype=np.uint32)
+    return ((sign << 31) | (exponent << 23) | mantissa).view(np.float32)
+
+
+def test_division_is_the_ieee_quotient_in_the_range_the_kernels_work_in(device):
+    rng = np.random.default_rng(7)
+    n = 1 << 21
+    with np.errstate(all="ignore"):
+        # the whole range the shading arithmetic lives in, and far beyond it
+        for low, high in ((-20, 20), (-40, 40), (-60, 36)):
+            a, b = random_floats(rng, n, low, high), random_floats(rng, n, low, high)
+            q = evaluate(device, 0, a, b)
+            assert same_bits(q, a / b).all(), (low, high, int((~same_bits(q, a / b)).sum()))
+        # mantissa patterns that make rounding hard: quotients next to a tie
+        b = random_floats(rng, n, -10, 10)
+        q_exact = random_floats(rng, n, -10, 10)
+        a = (q_exact.astype(np.float64) * b.astype(np.float64)).astype(np.float32)
+        assert same_bits(evaluate(device, 0, a, b), a / b).all()
+        # the compiler's own division agrees with numpy everywhere (sanity of the comparison)
+        a, b = random_floats(rng, n, -126, 127), random_floats(rng, n, -126, 127)
+        assert same_bits(evaluate(device, 3, a, b), a / b).all()
+
+
+def test_division_keeps_the_ieee_results_for_zeros_infinities_and_nans(device):
+    specials = np.array([0.0, -0.0, 1.0, -1.0, 3.5, -2.25e-3, np.inf, -np.inf, np.nan, 1.0e10, -1.0e-10], np.float32)
+    a, b = [x.ravel() for x in np.meshgrid(specials, specials)]
+    with np.errstate(all="ignore"):
+        expected = a / b
+    q = evaluate(device, 0, a, b)
+    assert same_bits(q, expected).all(), list(zip(a[~same_bits(q, expected)], b[~same_bits(q, expected)], q[~same_bits(q, expected)]))
+
+
+def test_where_the_short_division_leaves_the_ieee_quotient(device):
+    """Documents the edge of the contract: without the operand rescaling of v_div_scale_f32 the
+    quotient may be off once an operand or the quotient sits in the last decades of the exponent
+    range.  The test pins that the deviation stays out of [2^-100, 2^96]."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    a, b = random_floats(rng, n, -126, 127), random_floats(rng, n, -126, 127)
+    with np.errstate(all="ignore"):
+        expected = a / b
+    differs = ~same_bits(evaluate(device, 0, a, b), expected)
+    exponent = lambda x: ((x.view(np.uint32) >> 23) & 0xFF).astype(np.int32) - 127
+    inside = (np.abs(exponent(a)) <= 96) & (np.abs(exponent(b)) <= 96) & np.isfinite(expected) & (expected != 0) & (np.abs(exponent(expected)) <= 96)
+    assert not (differs & inside).any()
+
+
+def test_square_root_is_correctly_rounded(device):
+    rng = np.random.default_rng(3)
+    n = 1 << 21
+    x = np.abs(random_floats(rng, n, -100, 100))
+    assert same_bits(evaluate(device, 1, x), np.sqrt(x)).all()
+    # perfect squares and their neighbours
+    k = rng.integers(1, 4096, 4096).astype(np.float32)
+    for delta in (0, 1, -1):
+        y = ((k * k).view(np.uint32).astype(np.int64) + delta).astype(np.uint32).view(np.float32)
+        assert same_bits(evaluate(device, 1, y), np.sqrt(y)).all()
+    specials = np.array([0.0, -0.0, np.inf, np.nan, -1.0, 1.0, 4.0], np.float32)
+    with np.errstate(all="ignore"):
+        assert same_bits(evaluate(device, 1, specials), np.sqrt(specials)).all()

@@ -58,18 +58,33 @@ VKR_DEV float positive_part(float x) { return (x > 0.0f) ? x : 0.0f; }
 // arrays into scratch memory.
 VKR_DEV float opaque(float x) { asm("" : "+v"(x)); return x; }
 
-VKR_DEV float rcp(float x) {
-#if VKR_FAST_MATH
-	return __builtin_amdgcn_rcpf(x);
-#else
-	return 1.0f / x;
-#endif
-}
+// Division.  Exact mode: the correctly rounded quotient by the chain the compiler itself expands
+// a / b to - reciprocal estimate, one Newton step on it, the quotient and two corrections of it
+// with exact (FMA) residuals, v_div_fixup_f32 for zeros, infinities and NaNs - without the two
+// v_div_scale_f32 and the v_div_fmas_f32 that rescale operands near the ends of the exponent range:
+// 30 instead of 40 clocks of VALU issue (profiles/tools/valu_rate.hip; a fifth of the shading
+// kernel's instructions are divisions).  The result is the IEEE quotient - independent of the
+// estimate - whenever v_div_scale_f32 would not have rescaled: |b| in [2^-126, 2^126), a = 0 or
+// |a| >= 2^-103, |a / b| in [2^-126, 2^96) (tests/test_gpu_arithmetic.py pins that).  The operands
+// here are radiances, densities, areas and lengths of O(1e-10 ... 1e10); like square_root below
+// this gives up the last decades of the exponent range, nothing else.
 VKR_DEV float divide(float a, float b) {
 #if VKR_FAST_MATH
 	return a * __builtin_amdgcn_rcpf(b);
 #else
-	return a / b;
+	float r = __builtin_amdgcn_rcpf(b);
+	r = fmaf(fmaf(-b, r, 1.0f), r, r);
+	float q = a * r;
+	q = fmaf(fmaf(-b, q, a), r, q);
+	q = fmaf(fmaf(-b, q, a), r, q);
+	return __builtin_amdgcn_div_fixupf(q, b, a);
+#endif
+}
+VKR_DEV float rcp(float x) {
+#if VKR_FAST_MATH
+	return __builtin_amdgcn_rcpf(x);
+#else
+	return divide(1.0f, x);
 #endif
 }
 // Correctly rounded square root (== sqrtf of the oracle).  The compiler's expansion is 17

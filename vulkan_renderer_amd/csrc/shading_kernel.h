@@ -117,7 +117,7 @@ VKR_DEV float unorm16(uint32_t v) {
 #if VKR_FAST_MATH
 	return (float) v * (1.0f / 65535.0f);
 #else
-	return (float) v / 65535.0f;
+	return divide((float) v, 65535.0f);
 #endif
 }
 
@@ -652,6 +652,9 @@ struct pixel_context {
 	uint32_t tid, code_cursor, term_cursor;
 	bool light_has_terms;
 	uint32_t queue;
+	// this thread's column of the LDS tables of the prepared polygons (strategies with two
+	// techniques per light: 2 x kPsaTableSlots(V) slots, [slot][thread]), else NULL
+	float2* psa_tables;
 };
 
 // get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231, without
@@ -1060,43 +1063,69 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 		}
 		else {
 			// both techniques are prepared by the same code path (:506-547)
-			psa_polygon<V> pd, ps;
+			if constexpr (ERROR == kErrorDiffuse || ERROR == kErrorSpecular) {
+				psa_polygon<V> pd, ps;
+				ps.total = 0.0f;
+				ps.vertex_count = 0;
+				ps.inner_ellipse_0 = mk2(0.0f, 0.0f);
+				bool specular_culled = false;
+#pragma unroll
+				for (int t = 0; t != 2; ++t) {
+					const m43& to_local = (t == 0) ? world_to_shading : world_to_cosine;
+					if (t > 0) pd = ps;
+					f3 vl[V];
+#pragma unroll
+					for (int j = 0; j < V - 1; ++j) vl[j] = mul_point(to_local, light_vertex(light, min((uint32_t) j, p.max_light_vertex_count - 1)));
+					vl[V - 1] = zero;
+					uint32_t clipped = clip_polygon<V>(count, vl);
+					if (clipped == 0 && t == 0) return zero;
+					else if (clipped == 0) { specular_culled = true; break; }
+					prepare_psa<V, kBiased>(ps, clipped, vl);
+				}
+				if (specular_culled) ps.total = 0.0f;
+				if (pd.total == 0.0f) return zero;
+				if constexpr (ERROR == kErrorDiffuse) return display_sampling_error<V, kBiased>(p, pd, noise);
+				if (ps.total > 0.0f) return display_sampling_error<V, kBiased>(p, ps, noise);
+				return zero;
+			}
+			// The prepared polygons live in LDS (psa_compact, polygon_sampling.h): the diffuse one
+			// first, then the specular one
+			psa_compact<V> pd, ps;
 			ps.total = 0.0f;
 			ps.vertex_count = 0;
-			ps.inner_ellipse_0 = mk2(0.0f, 0.0f);
-			bool specular_culled = false;
+			ps.inner_slots = 0; ps.outer_slots = 0;
+#pragma unroll
+			for (int i = 0; i < V; ++i) ps.sector[i] = 0.0f;
+			float2* const tables_d = ctx.psa_tables;
+			float2* const tables_s = ctx.psa_tables + kPsaTableSlots(V) * kPsaTableStride;
 #pragma unroll
 			for (int t = 0; t != 2; ++t) {
 				const m43& to_local = (t == 0) ? world_to_shading : world_to_cosine;
-				if (t > 0) pd = ps;
 				f3 vl[V];
 #pragma unroll
 				for (int j = 0; j < V - 1; ++j) vl[j] = mul_point(to_local, light_vertex(light, min((uint32_t) j, p.max_light_vertex_count - 1)));
 				vl[V - 1] = zero;
 				uint32_t clipped = clip_polygon<V>(count, vl);
 				if (clipped == 0 && t == 0) return zero;
-				else if (clipped == 0) { specular_culled = true; break; }
-				prepare_psa<V, kBiased>(ps, clipped, vl);
+				else if (clipped == 0) break;  // the specular polygon is below the horizon: ps.total stays 0
+				psa_polygon<V> prepared;
+				prepare_psa<V, kBiased>(prepared, clipped, vl);
+				if (t == 0) store_psa_tables<V>(pd, tables_d, prepared);
+				else store_psa_tables<V>(ps, tables_s, prepared);
 			}
-			if (specular_culled) ps.total = 0.0f;
 			if (pd.total == 0.0f) return zero;
 			float specular_albedo = ltc_in.albedo;
 			float specular_weight = specular_albedo * ps.total;
-			if constexpr (ERROR == kErrorDiffuse) return display_sampling_error<V, kBiased>(p, pd, noise);
-			if constexpr (ERROR == kErrorSpecular) {
-				if (ps.total > 0.0f) return display_sampling_error<V, kBiased>(p, ps, noise);
-				return zero;
-			}
 			if constexpr (STRATEGY == kStrategySeparately) {
 				for (uint32_t s = 0; s != S; ++s) {
-					f3 dd = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
+					f3 dd = sample_psa_tables<V, kBiased>(pd, tables_d, next_noise_2(p, noise));
 					dd = mul_transposed(world_to_shading, dd);
 					float lambert;
 					bool candidate;
 					f3 rb = radiance_brdf<true, false, kTextured>(p, lambert, candidate, dd, sd, light);
 					accumulate<RAYS>(ctx, result, candidate, rb * pd.total, zero * pd.total, dd, sd, light);
 					if (ps.total > 0.0f) {
-						f3 dc = sample_psa<V, kBiased>(ps, next_noise_2(p, noise));
+						f3 dc = sample_psa_tables<V, kBiased>(ps, tables_s, next_noise_2(p, noise));
 						f3 ds = normalize(cosine_to_shading(ltc_in, dc));
 						float ltc_density = evaluate_ltc_density(ltc_in, ds, 1.0f);
 						f3 dw = mul_transposed(world_to_shading, ds);
@@ -1130,10 +1159,10 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					specular_weight_rgb = specular_weight_rgb * radiance_over_pi;
 				}
 				for (uint32_t s = 0; s != S; ++s) {
-					f3 dir_d = sample_psa<V, kBiased>(pd, next_noise_2(p, noise));
+					f3 dir_d = sample_psa_tables<V, kBiased>(pd, tables_d, next_noise_2(p, noise));
 					f3 dir_s = zero;
 					if (ps.total > 0.0f) {
-						dir_s = sample_psa<V, kBiased>(ps, next_noise_2(p, noise));
+						dir_s = sample_psa_tables<V, kBiased>(ps, tables_s, next_noise_2(p, noise));
 						dir_s = normalize(cosine_to_shading(ltc_in, dir_s));
 					}
 					for (uint32_t j = 0; j != technique_count; ++j) {
@@ -1174,7 +1203,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					bool specular_selected = u.x >= diffuse_ratio;
 					float offset = specular_selected ? 1.0f : 0.0f;
 					u.x = divide(u.x - offset, diffuse_ratio - offset);
-					f3 ds = specular_selected ? sample_psa<V, kBiased>(ps, u) : sample_psa<V, kBiased>(pd, u);
+					f3 ds = specular_selected ? sample_psa_tables<V, kBiased>(ps, tables_s, u) : sample_psa_tables<V, kBiased>(pd, tables_d, u);
 					if (specular_selected) ds = normalize(cosine_to_shading(ltc_in, ds));
 					float lambert = ds.z;
 					float dens_d = lambert * diffuse_albedo;
@@ -1262,18 +1291,30 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 #define VKR_MODE_NAMESPACE exact_math
 #endif
 inline namespace VKR_MODE_NAMESPACE {
+// Occupancy.  With the polygon tables in LDS (two-technique strategies) the kernel needs 168 - 179
+// VGPRs up to V = 6, the one-technique variants 160 - 175; asking for three workgroups per CU makes
+// the register allocator stop at 168 without scratch (checked for every variant by
+// profiles/tools/kernel_resources.sh), which is the third wave per SIMD.  From V = 7 on the tables
+// of three workgroups no longer fit into the 160 KB of LDS and the allocator would have to spill.
+constexpr bool has_psa_tables(int strategy, int technique, int error) {
+	return strategy >= kStrategySeparately && (technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular;
+}
+// (Rays traced inside the kernel bring the traversal's registers with them: those variants would spill.)
+constexpr int shade_min_workgroups(int technique, int v, int rays, int error) {
+	return ((technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular && v <= 6 && rays != kRaysInline) ? 3 : 1;
+}
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
-#ifndef VKR_SHADE_BOUNDS
-#define VKR_SHADE_BOUNDS 256
-#endif
-__global__ void __launch_bounds__(VKR_SHADE_BOUNDS) shade_pixels(const shade_params p) {
+__global__ void __launch_bounds__(256, shade_min_workgroups(TECHNIQUE, V, RAYS, ERROR)) shade_pixels(const shade_params p) {
 	uint32_t px, py;
 	size_t out_index;
 	bool inside = locate_pixel(p, px, py, out_index);
 	// ray queue of this wave: workgroup b runs on XCD b % 8 and uses one of the 64 queues
 	// of that XCD, so a queue counter's cache line is only ever touched from one L2
 	uint32_t queue = (blockIdx.x & 7u) * 64u + (((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)) & 63u);
-	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false, queue};
+	// the polygon tables exist for the techniques that prepare two polygons per light in registers
+	constexpr bool kTables = has_psa_tables(STRATEGY, TECHNIQUE, ERROR);
+	__shared__ float2 psa_tables[kTables ? 2 * kPsaTableSlots(V) * kPsaTableStride : 1];
+	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		volatile uint32_t* state = ray_block_state();

@@ -975,6 +975,42 @@ __global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh,
 	atomicAdd(out + 3, blocked_rays); atomicAdd(out + 4, wave_steps); atomicAdd(out + 6, boxes);
 }
 
+// evaluate_device_arithmetic(): the primitives as the shading kernels use them (this translation unit
+// is compiled in exact mode, -ffp-contract=off)
+__global__ void __launch_bounds__(256) k_evaluate_arithmetic(uint32_t operation, const float* a, const float* b, float* out, uint32_t count) {
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= count) return;
+	float x = a[i], y = b ? b[i] : 0.0f;
+	switch (operation) {
+	case 0: out[i] = divide(x, y); break;
+	case 1: out[i] = square_root(x); break;
+	case 2: out[i] = rsqrt(x); break;
+	case 3: out[i] = x / y; break;
+	default: out[i] = sqrtf(x); break;
+	}
+}
+
+extern "C" int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count) {
+	if (!device || !a || !out || operation > 4 || ((operation == 0 || operation == 3) && !b)) {
+		printf("evaluate_device_arithmetic() needs a device, operands and an operation in 0 ... 4.\n");
+		return 1;
+	}
+	if (!count) return 0;
+	hipStream_t stream = (hipStream_t) device->stream;
+	float* buffers = NULL;
+	size_t bytes = sizeof(float) * (size_t) count;
+	if (hip_failed(hipMalloc(&buffers, 3 * bytes), "allocating the operands")) return 1;
+	int failed = hip_failed(hipMemcpyAsync(buffers, a, bytes, hipMemcpyHostToDevice, stream), "uploading the operands")
+		|| (b && hip_failed(hipMemcpyAsync(buffers + count, b, bytes, hipMemcpyHostToDevice, stream), "uploading the operands"));
+	if (!failed) {
+		k_evaluate_arithmetic<<<(count + 255u) / 256u, 256, 0, stream>>>(operation, buffers, b ? buffers + count : NULL, buffers + 2 * (size_t) count, count);
+		failed = hip_failed(hipMemcpyAsync(out, buffers + 2 * (size_t) count, bytes, hipMemcpyDeviceToHost, stream), "reading the results back")
+			|| hip_failed(hipStreamSynchronize(stream), "evaluating the arithmetic");
+	}
+	(void) hipFree(buffers);
+	return failed;
+}
+
 extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]) {
 	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
