@@ -344,13 +344,14 @@ def run_workload(job, config, primary):
                                "note": "inside the timed region %d frames share the GPU: the bracket of one frame's shade_pixels then spans time in which the other frames' trace and resolve kernels run too, so it can exceed ms_per_step; it is not used for `achieved`" % frames_in_flight},
                 "note": "nominal roofline (SURVEY.md 8d): the pass is bound by FP32 VALU issue and BVH latency, not by HBM"}
     if pmc and pmc.get("valu_floor_us"):
-        # the bound that actually holds: wave64 VALU instructions counted by the PMC pass in profiles/
-        # x 4 clocks / 1024 SIMDs / 2.4 GHz, per kernel of the pass
+        # the bound that actually holds: wave64 VALU instructions per class, counted by the PMC passes in
+        # profiles/, priced with the issue cost measured per class on this GPU (profiles/tools/valu_rate.hip:
+        # 2.5 clocks add / mul / fma, 8.2 transcendental, 2.5 - 4.3 the rest; the mid-point is used), on 1024 SIMDs at 2.4 GHz
         floors = {k: v for k, v in pmc["valu_floor_us"].items() if isinstance(v, (int, float))}
         roofline["valu_issue"] = {"shade_pixels_floor_ms": round(floors.get("shade_pixels", 0.0) * 1e-3, 4),
                                   "shade_pixels_frac": round(floors.get("shade_pixels", 0.0) * 1e-3 / kernel_ms, 4),
                                   "floor_ms_per_pass": round(sum(floors.values()) * 1e-3, 4), "frac_of_ms_per_step": round(sum(floors.values()) * 1e-3 / ms_per_step, 4),
-                                  "source": "instruction counts from %s (rocprofv3 --pmc, not measured in this run), times live" % pmc.get("source", "profiles/pmc_traffic.json")}
+                                  "source": "per-class instruction counts from %s (rocprofv3 --pmc, not measured in this run) x issue clocks per class from profiles/r02d_valu_rate.txt; times live" % pmc.get("source", "profiles/pmc_traffic.json")}
 
     result = {
         "metric": "Msamples/s (pixels x spp / s), shading pass", "value": round(value, 3), "unit": "Msamples/s",

@@ -25,6 +25,9 @@ for CFG in 2 3; do
 	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/cfg${CFG}_pmc3 -o pmc -- $B > $O/cfg${CFG}_pmc3.log 2>&1
 	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/cfg${CFG}_pmc4 -o pmc -- $B > $O/cfg${CFG}_pmc4.log 2>&1
 	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS -d $O/cfg${CFG}_pmc5 -o pmc -- $B > $O/cfg${CFG}_pmc5.log 2>&1
+	# instruction classes: the VALU issue cost differs by class (profiles/tools/valu_rate.hip)
+	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 -d $O/cfg${CFG}_pmc6 -o pmc -- $B > $O/cfg${CFG}_pmc6.log 2>&1
+	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64 SQ_INSTS_SMEM -d $O/cfg${CFG}_pmc7 -o pmc -- $B > $O/cfg${CFG}_pmc7.log 2>&1
 	# the bench line itself, un-profiled, for the record
 	timeout 300 python $R/bench.py --config $CFG --no-secondary > $O/cfg${CFG}_bench.json 2> $O/cfg${CFG}_bench.err
 done

@@ -69,7 +69,7 @@ def main():
                 serial_us[row["Name"].split("(")[0]] = float(row["AverageNs"]) / 1e3
             lines.append("")
         merged, meta = {}, {}
-        for p in (1, 2, 3, 4, 5):
+        for p in (1, 2, 3, 4, 5, 6, 7):
             c, m = counters(os.path.join(base, "cfg%d_pmc%d" % (cfg, p)))
             for k, v in c.items():
                 merged.setdefault(k, {}).update(v)
@@ -89,13 +89,29 @@ def main():
                               100 * 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (simds * cycles), 100 * c.get("SQ_THREAD_CYCLES_VALU", 0) / max(64 * c.get("SQ_ACTIVE_INST_VALU", 1), 1)),
                           "- wave time: %.1f %% issuing, %.1f %% waiting on memory (s_waitcnt), %.1f %% issue stalls" % (
                               100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"])]
-            if "SQ_ACTIVE_INST_VALU" in c:
-                # a wave64 VALU instruction occupies its SIMD for one quad-cycle (4 clocks): the
-                # kernel cannot finish before all of them have issued on the 1024 SIMDs
-                floor_us = 4 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / 2400.0
+            if "SQ_INSTS_VALU" in c:
+                # What a wave64 VALU instruction costs its SIMD was measured per class on this GPU
+                # (profiles/tools/valu_rate.hip, profiles/r02d_valu_rate.txt): v_fma / v_mul / v_add / v_mov
+                # and the plain integer ALU ops 2.5 clocks, conversions, compares, selects, min / max,
+                # shifts, v_perm and the v_div_* helpers 4.3, v_rcp / v_rsq / v_sqrt 8.2.  The counters
+                # separate ADD, MUL, FMA and the transcendental instructions; the rest is a mixture of
+                # 2.5-clock (v_mov, v_and, v_add_u32) and 4.3-clock instructions, so the floor is a range.
+                total = c["SQ_INSTS_VALU"]
                 alone = serial_us.get(kernel)
-                lines.append("- VALU issue floor at 2.4 GHz: %.3g wave instructions on 1024 SIMDs = %.1f us%s" % (
-                    c.get("SQ_INSTS_VALU", c["SQ_ACTIVE_INST_VALU"]), floor_us, (" = %.0f %% of the %.1f us the kernel takes alone (un-profiled)" % (100 * floor_us / alone, alone)) if alone else ""))
+                if "SQ_INSTS_VALU_FMA_F32" in c:
+                    full = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_FMA_F32"]
+                    trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                    rest = max(total - full - trans, 0.0)
+                    low = (2.5 * full + 8.2 * trans + 2.5 * rest) / 1024.0 / 2400.0
+                    high = (2.5 * full + 8.2 * trans + 4.3 * rest) / 1024.0 / 2400.0
+                    lines.append("- VALU instruction mix: %.3g wave instructions = %.0f %% add / mul / fma (2.5 clocks each), %.1f %% transcendental (8.2), %.0f %% other (2.5 - 4.3)" % (
+                        total, 100 * full / total, 100 * trans / total, 100 * rest / total))
+                    lines.append("- VALU issue floor at 2.4 GHz on 1024 SIMDs with the measured issue costs: %.1f - %.1f us%s" % (
+                        low, high, (" = %.0f - %.0f %% of the %.1f us the kernel takes alone (un-profiled)" % (100 * low / alone, 100 * high / alone, alone)) if alone else ""))
+                    floor_us = 0.5 * (low + high)
+                else:
+                    floor_us = 4 * c.get("SQ_ACTIVE_INST_VALU", total) / 1024.0 / 2400.0
+                    lines.append("- VALU issue floor at 4 clocks per instruction: %.1f us" % floor_us)
                 if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel:
                     valu_floor = traffic.setdefault("config%d_exact_valu_floor_us" % cfg, {})
                     valu_floor[kernel.split("::")[-1].split("<")[0]] = round(floor_us, 2)
