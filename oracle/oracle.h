@@ -110,6 +110,8 @@ const float* oracle_srgb_table(void);
  * vec4(final_color * exposure, 1), reference shading_pass.frag.glsl:866).
  * thread_count <= 0 uses all OpenMP threads. */
 void oracle_shade_rows(const oracle_frame_t* frame, float* out_rgba, uint32_t y0, uint32_t y1, int thread_count);
+/* One pixel of the frame (debugging aid) */
+void oracle_shade_pixel(const oracle_frame_t* frame, uint32_t x, uint32_t y, float out_rgba[4]);
 /* Number of shadow rays traced by the last oracle_shade_rows call */
 uint64_t oracle_last_ray_count(void);
 /* 0 = libm transcendental functions, 1 = the polynomial forms shared with the GPU */

@@ -2134,6 +2134,13 @@ void oracle_shade_rows(const oracle_frame_t* frame, float* out_rgba, uint32_t y0
 	g_ray_count = rays;
 }
 
+/* one pixel (debugging aid: oracle/tools/nan_origin.py runs it with floating point traps) */
+void oracle_shade_pixel(const oracle_frame_t* frame, uint32_t x, uint32_t y, float out_rgba[4]) {
+	frame_constants_t k = read_frame_constants(frame->constants);
+	pixel_ctx_t ctx = {frame, &k, 0};
+	shade_pixel(&ctx, x, y, out_rgba);
+}
+
 void oracle_primary_visibility(const uint8_t* constants, const void* bvh, uint32_t width, uint32_t height, float near, float far, uint32_t* out) {
 	frame_constants_t k = read_frame_constants(constants);
 #pragma omp parallel for schedule(dynamic, 4)
