@@ -108,6 +108,12 @@ enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2, kRaysDeferredBlocks = 
 constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == kRaysDeferredBlocks; }
 // codes of the per-thread term stream written in deferred mode
 enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5 };
+// Byte index of code `cursor` of thread `tid`: four consecutive codes of a thread share one 32-bit
+// word ([cursor / 4][thread] words), so that the resolve kernel fetches four codes per load and can
+// request their terms together instead of walking a chain of dependent one-byte loads
+VKR_DEV size_t code_slot(uint32_t thread_count, uint32_t cursor, uint32_t tid) {
+	return (((size_t) (cursor >> 2) * thread_count + tid) << 2) | (cursor & 3u);
+}
 
 VKR_DEV float load_f(const uint8_t* base, uint32_t offset) { return *(const float*) (base + offset); }
 VKR_DEV uint32_t load_u(const uint8_t* base, uint32_t offset) { return *(const uint32_t*) (base + offset); }
@@ -758,7 +764,7 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		bool needs_ray = candidate && (hidden_matters || !all_zero(visible_term));
 		bool is_final = !candidate && !all_zero(visible_term);
 		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
-			size_t code_index = (size_t) ctx.code_cursor * p.thread_count + ctx.tid;
+			size_t code_index = code_slot(p.thread_count, ctx.code_cursor, ctx.tid);
 			size_t term_index = ((size_t) ctx.term_cursor * p.thread_count + ctx.tid) * 3;
 			p.codes[code_index] = (uint8_t) (is_final ? kCodeFinal : (hidden_matters ? kCodePendingWithHidden : kCodePending));
 			p.terms_visible[term_index] = visible_term.x; p.terms_visible[term_index + 1] = visible_term.y; p.terms_visible[term_index + 2] = visible_term.z;
@@ -1245,7 +1251,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 	if constexpr (is_deferred(RAYS)) {
 		// close this light's run of terms; the resolve kernel scales by 1 / S and adds it
 		if (ctx.light_has_terms && ctx.code_cursor + 1 < p.max_codes) {
-			p.codes[(size_t) ctx.code_cursor * p.thread_count + ctx.tid] = (uint8_t) kCodeEndOfLight;
+			p.codes[code_slot(p.thread_count, ctx.code_cursor, ctx.tid)] = (uint8_t) kCodeEndOfLight;
 			++ctx.code_cursor;
 			ctx.light_has_terms = false;
 		}
@@ -1361,7 +1367,7 @@ __global__ void __launch_bounds__(256, shade_min_workgroups(TECHNIQUE, V, RAYS, 
 			// hand over to trace_shadow_rays / resolve_shadow_terms: the colour so far
 			// (light display) and the terminated term stream
 			p.base_color[ctx.tid] = make_float4(color.x, color.y, color.z, 0.0f);
-			p.codes[(size_t) ctx.code_cursor * p.thread_count + ctx.tid] = (uint8_t) kCodeEnd;
+			p.codes[code_slot(p.thread_count, ctx.code_cursor, ctx.tid)] = (uint8_t) kCodeEnd;
 		}
 		else
 			store_final_color(p, out_index, color);

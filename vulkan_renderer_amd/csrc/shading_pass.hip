@@ -208,14 +208,15 @@ static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_
 	free_wavefront_buffers(w);
 	w->thread_count = thread_count; w->max_terms = max_terms; w->max_codes = max_codes;
 	size_t terms = (size_t) max_terms * thread_count;
-	if (terms >= 0xFFFFFFFFull || (size_t) max_codes * thread_count >= 0xFFFFFFFFull) {
+	if (terms >= 0xFFFFFFFFull || (size_t) (max_codes + 3u) * thread_count >= 0xFFFFFFFFull) {
 		printf("The wavefront ray queue would need more than 2^32 entries (%u threads x %u terms); render in tiles or use inline rays.\n", thread_count, max_terms);
 		return 1;
 	}
 	// a queue sees every 512th wave (8 XCDs x 64 queues, waves dealt round-robin), every
 	// lane of which may emit max_terms rays
 	w->queue_capacity = ((thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * (64u * max_terms + ray_block_size(max_terms));
-	if (hipMalloc(&w->codes, (size_t) max_codes * thread_count) != hipSuccess
+	// (codes are stored four to a word per thread: code_slot() in shading_kernel.h)
+	if (hipMalloc(&w->codes, (size_t) ((max_codes + 3u) & ~3u) * thread_count) != hipSuccess
 		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
 		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
 		|| hipMalloc(&w->base_color, sizeof(float4) * (size_t) thread_count) != hipSuccess

@@ -155,8 +155,17 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
 	wide_ray ray = {o, o, 0u, 0u, 0u};
 	float t_max = 0.0f;
-	uint32_t item = kIdle, code_index = 0, depth = 0;
-	uint32_t* my_stack = stack + threadIdx.x;
+	uint32_t item = kIdle, code_index = 0;
+	// The stack pointer is the lane's LDS address itself (entries are 256 lanes x 4 bytes apart), so
+	// that a push is a store and a conditional add; entries beyond the LDS part only exist as a
+	// depth (`top` then points behind the LDS part and is never dereferenced)
+	// (as 32-bit LDS byte addresses: generic pointers make the compiler do the arithmetic in 64 bits)
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	constexpr uint32_t kEntry = 256u * 4u;
+	const uint32_t my_stack = (uint32_t) (uintptr_t) (lds_u32*) (stack + threadIdx.x);
+	const uint32_t lds_end = my_stack + kWideStackLds * kEntry;
+	uint32_t top = my_stack;
+#define VKR_STACK_AT(address) (*(lds_u32*) (uintptr_t) (address))
 	uint32_t* my_spill = spill + (size_t) blockIdx.x * 256u + threadIdx.x;
 	const size_t spill_stride = (size_t) gridDim.x * 256u;
 	while (true) {
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 				code_index = __float_as_uint(b.w);
 				ray = make_wide_ray(make_grid_ray(bvh, o, d));
 				item = 0;
-				depth = 0;
+				top = my_stack;
 				if (!(t_max >= 1.0e-3f)) {
 					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
 					item = kIdle;
@@ -209,13 +218,13 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 				bool h1 = wide_ray_box(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
 				bool h2 = wide_ray_box(qx.z, qy.z, qz.z, ray, 1.0e-3f, t_max);
 				bool h3 = wide_ray_box(qx.w, qy.w, qz.w, ray, 1.0e-3f, t_max);
-				if (depth + 4u <= kWideStackLds) {
+				if (top + 4u * kEntry <= lds_end) {
 					// (the last child first: the first one comes off the stack first, the order of
 					// the scheme with a register for the next item)
-					my_stack[depth * 256u] = link.w; depth += h3 ? 1u : 0u;
-					my_stack[depth * 256u] = link.z; depth += h2 ? 1u : 0u;
-					my_stack[depth * 256u] = link.y; depth += h1 ? 1u : 0u;
-					my_stack[depth * 256u] = link.x; depth += h0 ? 1u : 0u;
+					VKR_STACK_AT(top) = link.w; top += h3 ? kEntry : 0u;
+					VKR_STACK_AT(top) = link.z; top += h2 ? kEntry : 0u;
+					VKR_STACK_AT(top) = link.y; top += h1 ? kEntry : 0u;
+					VKR_STACK_AT(top) = link.x; top += h0 ? kEntry : 0u;
 				}
 				else {
 					const bool hits[4] = {h3, h2, h1, h0};
@@ -223,9 +232,9 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 #pragma unroll
 					for (int c = 0; c != 4; ++c) {
 						if (!hits[c]) continue;
-						if (depth < kWideStackLds) my_stack[depth * 256u] = links[c];
-						else my_spill[(size_t) (depth - kWideStackLds) * spill_stride] = links[c];
-						++depth;
+						if (top < lds_end) VKR_STACK_AT(top) = links[c];
+						else my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride] = links[c];
+						top += kEntry;
 					}
 				}
 				pop = true;
@@ -236,22 +245,24 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 				float dist;
 				bool blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
 				// a blocked ray is done: its term keeps the code the shading kernel gave it
-				if (blocked) { item = kIdle; depth = 0; }
+				if (blocked) { item = kIdle; top = my_stack; }
 				else pop = true;
 			}
 			if (pop) {
-				if (depth == 0) {
+				if (top == my_stack) {
 					codes[code_index] = (uint8_t) kCodeVisible;
 					item = kIdle;
 				}
 				else {
-					--depth;
-					item = depth < kWideStackLds ? my_stack[depth * 256u] : my_spill[(size_t) (depth - kWideStackLds) * spill_stride];
+					top -= kEntry;
+					item = top < lds_end ? VKR_STACK_AT(top) : my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride];
 				}
 			}
 		}
 	}
 }
+
+#undef VKR_STACK_AT
 
 // Replays every pixel's sums in the order of the shading program: terms of one light
 // are added one after the other, the light's sum is scaled by 1 / SAMPLE_COUNT and
@@ -266,20 +277,40 @@ VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 	f3 sum = mk3(0.0f, 0.0f, 0.0f);
 	float rcp_samples = 1.0f / (float) p.sample_count;
 	uint32_t term = 0;
-	for (uint32_t k = 0; k < p.max_codes; ++k) {
-		uint32_t code = p.codes[(size_t) k * p.thread_count + tid];
-		if (code == kCodeEnd) break;
-		if (code == kCodeEndOfLight) {
-			color = color + sum * rcp_samples;
-			sum = mk3(0.0f, 0.0f, 0.0f);
-			continue;
+	// Four codes per load (code_slot); the terms of a group are requested together - which ones is
+	// known from the codes alone - and then added in program order.  (Adding the +0 of a term that
+	// contributes nothing leaves the sum as it is: the sum starts at +0 and never becomes -0.)
+	const uint32_t* code_words = (const uint32_t*) p.codes;
+	const uint32_t groups = (p.max_codes + 3u) >> 2;
+	bool ended = false;
+	for (uint32_t g = 0; g < groups && !ended; ++g) {
+		uint32_t word = code_words[(size_t) g * p.thread_count + tid];
+		f3 value[4];
+		uint32_t code[4];
+		bool live = true;
+#pragma unroll
+		for (int j = 0; j != 4; ++j) {
+			code[j] = (word >> (8 * j)) & 0xFFu;
+			live = live && code[j] != kCodeEnd;
+			bool is_term = live && code[j] != kCodeEndOfLight;
+			size_t index = ((size_t) term * p.thread_count + tid) * 3;
+			term += is_term ? 1u : 0u;
+			value[j] = mk3(0.0f, 0.0f, 0.0f);
+			if (is_term && (code[j] == kCodeVisible || code[j] == kCodeFinal))
+				value[j] = mk3(p.terms_visible[index], p.terms_visible[index + 1], p.terms_visible[index + 2]);
+			else if (is_term && code[j] == kCodePendingWithHidden)
+				value[j] = mk3(p.terms_hidden[index], p.terms_hidden[index + 1], p.terms_hidden[index + 2]);
 		}
-		size_t index = ((size_t) term * p.thread_count + tid) * 3;
-		++term;
-		if (code == kCodeVisible || code == kCodeFinal)
-			sum = sum + mk3(p.terms_visible[index], p.terms_visible[index + 1], p.terms_visible[index + 2]);
-		else if (code == kCodePendingWithHidden)
-			sum = sum + mk3(p.terms_hidden[index], p.terms_hidden[index + 1], p.terms_hidden[index + 2]);
+#pragma unroll
+		for (int j = 0; j != 4; ++j) {
+			if (ended) continue;
+			if (code[j] == kCodeEnd) ended = true;
+			else if (code[j] == kCodeEndOfLight) {
+				color = color + sum * rcp_samples;
+				sum = mk3(0.0f, 0.0f, 0.0f);
+			}
+			else sum = sum + value[j];
+		}
 	}
 	store_final_color(p, out_index, color);
 }
