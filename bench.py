@@ -436,8 +436,46 @@ def run_workload(job, config, primary):
                             "sample_pixels": sample_pixels, "pixels_differing": mismatched, "pixels_over_1e-2": flipped,
                             "rmse_without_those": math.sqrt(sq_without_flips / max(cnt, 1)),
                             "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
+    if primary and rank == 0 and world == 1 and not distributed and args.mode == "exact" and not args.no_fast_mode and not args.inline_rays and not args.no_rays:
+        r.close()
+        result["fast_mode"] = fast_mode_companion(job, config, gpu_image, width, height, sample_count, max(20, min(steps, 200)))
+        return result
     r.close()
     return result
+
+
+def fast_mode_companion(job, config, exact_image, width, height, sample_count, steps):
+    """The same workload in the fast arithmetic mode (v_rcp / v_rsq / v_sqrt, contraction), timed the
+    same way and compared with the exact-mode frame of this run (which is the oracle's, bit for bit).
+    Reported next to the headline, never as the headline: DESIGN.md section 2 explains the pixels
+    where approximate arithmetic leaves the stated tolerance."""
+    from vulkan_renderer_amd import renderer
+    args, torch = job.args, job.torch
+    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, fast_math=True, timing_stride=args.timing_stride, frames_in_flight=args.frames_in_flight)
+    renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh)
+    r.set_tiles(16, 0, 1, slab_layout=False)
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    for _ in range(max(8, steps // 10)):
+        r.render()
+    r.finish_frames()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render()
+    r.finish_frames()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    image = r.read_radiance()
+    r.close()
+    d = image[..., :3].astype(np.float64) - exact_image[..., :3].astype(np.float64)
+    per_pixel = np.abs(d).max(axis=-1)
+    flipped = per_pixel > 1e-2
+    return {"mode": "fast", "value": round(width * height * sample_count / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "steps": steps,
+            "rmse_vs_exact_mode": float(np.sqrt((d ** 2).mean())), "pixels_over_1e-2": int(flipped.sum()),
+            "rmse_without_those": float(np.sqrt((d[~flipped] ** 2).sum() / d.size)), "nan": int(np.isnan(image).sum()), "tolerance_rmse": 1e-4,
+            "note": "approximate reciprocals / roots and contraction; the pixels over 1e-2 are NaN-guard pixels of IEEE arithmetic (degenerate sectors) and samples next to a shadow edge, DESIGN.md section 2"}
 
 
 def parse_config(text):
@@ -465,6 +503,7 @@ def main():
     ap.add_argument("--no-rays", action="store_true", help="disable shadow rays (TRACE_SHADOW_RAYS=0) for experiments")
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-mode", action="store_true", help="do not also measure the workload in the fast arithmetic mode (reported as \"fast_mode\" next to the exact headline)")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")

@@ -53,6 +53,24 @@ def test_every_builder_and_both_trees_give_the_oracle_frame(dataset, builder, bi
     assert wide["deepest_stack"] <= stack_need
 
 
+def test_rays_whose_stack_leaves_lds_give_the_same_frame(dataset, monkeypatch):
+    """trace_shadow_rays_wide keeps 16 stack entries per lane in LDS and spills deeper ones to global
+    memory on a slow path that ordinary scenes hardly reach.  With only four entries in LDS most
+    rays go through it; the frame must stay the oracle's, bit for bit."""
+    r, image = render_config(dataset, 3, 256, 144)
+    deepest = r.traversal_statistics(True)["deepest_stack"]
+    visibility = r.read_visibility()
+    cpu, _, _ = oracle_render(r, visibility=visibility, math_mode=1)
+    r.close()
+    monkeypatch.setenv("VKR_WIDE_STACK_LDS", "4")
+    r, spilled = render_config(dataset, 3, 256, 144)
+    r.close()
+    # (the walk pushes all hit children before it takes one off again: one entry more than the statistics' scheme)
+    assert deepest + 1 > 4, "the scene is too shallow to leave four LDS entries"
+    assert np.array_equal(image.view(np.uint32), cpu.view(np.uint32))
+    assert np.array_equal(spilled.view(np.uint32), image.view(np.uint32))
+
+
 @pytest.mark.parametrize("builder", BUILDERS)
 def test_primary_visibility_does_not_depend_on_the_builder(dataset, builder):
     import oracle

@@ -188,8 +188,17 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 // queues many rays; with one or two per lane the unused slots would outnumber the rays.
 static uint32_t ray_block_size(uint32_t max_terms) { return max_terms >= 8 ? 256u : 0u; }
 
+// Stack entries per lane that trace_shadow_rays_wide keeps in LDS: kWideStackLds, or fewer when
+// VKR_WIDE_STACK_LDS says so (tests: the spill path must give the same frames)
+static uint32_t wide_stack_lds_entries() {
+	const char* knob = getenv("VKR_WIDE_STACK_LDS");
+	int value = knob ? atoi(knob) : (int) kWideStackLds;
+	return (uint32_t) (value < 4 ? 4 : (value > (int) kWideStackLds ? (int) kWideStackLds : value));
+}
+
 static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t trace_threads) {
-	size_t entries = stack_need > kWideStackLds ? (size_t) (stack_need - kWideStackLds) * trace_threads : 0;
+	uint32_t in_lds = wide_stack_lds_entries();
+	size_t entries = stack_need > in_lds ? (size_t) (stack_need - in_lds) * trace_threads : 0;
 	if (entries <= w->spill_entries) return 0;
 	// (frees while other frames may be in flight: hipFree waits for the device)
 	(void) hipFree(w->spill);
@@ -764,7 +773,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			// tuning knob: lanes that must have a triangle waiting before the wave tests triangles
 			const char* batch = getenv("VKR_LEAF_BATCH");
 			trace_shadow_rays_wide<<<trace_blocks, 256, 0, stream>>>(p.bvh, (const uint4*) app->scene.acceleration_structure.wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
-				p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, batch ? (uint32_t) atoi(batch) : 16u);
+				p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, batch ? (uint32_t) atoi(batch) : 16u, wide_stack_lds_entries());
 		}
 		else
 			trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 #ifndef VKR_TRACE_BOUNDS
 #define VKR_TRACE_BOUNDS 256, 8
 #endif
-__global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch) {
+__global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
 	__shared__ uint32_t stack[kWideStackLds * 256];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t xcd = blockIdx.x & 7u;
@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 	typedef __attribute__((address_space(3))) uint32_t lds_u32;
 	constexpr uint32_t kEntry = 256u * 4u;
 	const uint32_t my_stack = (uint32_t) (uintptr_t) (lds_u32*) (stack + threadIdx.x);
-	const uint32_t lds_end = my_stack + kWideStackLds * kEntry;
+	// (lds_entries <= kWideStackLds: tests shrink the LDS part to drive rays through the spill path)
+	const uint32_t lds_end = my_stack + lds_entries * kEntry;
 	uint32_t top = my_stack;
 #define VKR_STACK_AT(address) (*(lds_u32*) (uintptr_t) (address))
 	uint32_t* my_spill = spill + (size_t) blockIdx.x * 256u + threadIdx.x;
