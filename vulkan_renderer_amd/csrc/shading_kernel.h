@@ -1259,18 +1259,19 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 	return result * (1.0f / (float) S);
 }
 
-// Maps the launch grid to a pixel and its output slot.  Workgroups are 16x16
-// pixel blocks of the tiles this rank owns; a wave is an 8x8 patch.
-VKR_DEV bool locate_pixel(const shade_params& p, uint32_t& px, uint32_t& py, size_t& out_index) {
+// Maps a thread of the frame to a pixel and its output slot.  `block` counts the 16x16 pixel
+// blocks of the tiles this rank owns, `thread` the 256 pixels of a block; a wave is an 8x8 patch.
+// Thread number block * 256 + thread is what the per-thread wavefront buffers are indexed by.
+VKR_DEV bool locate_pixel(const shade_params& p, uint32_t block, uint32_t thread, uint32_t& px, uint32_t& py, size_t& out_index) {
 	uint32_t blocks_per_side = p.tile_size >> 4;
 	uint32_t blocks_per_tile = blocks_per_side * blocks_per_side;
-	uint32_t local_tile = blockIdx.x / blocks_per_tile;
-	uint32_t block_in_tile = blockIdx.x - local_tile * blocks_per_tile;
+	uint32_t local_tile = block / blocks_per_tile;
+	uint32_t block_in_tile = block - local_tile * blocks_per_tile;
 	uint32_t tile = local_tile * p.rank_count + p.rank;
 	if (tile >= p.tile_count) return false;
 	uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
 	uint32_t by = block_in_tile / blocks_per_side, bx = block_in_tile - by * blocks_per_side;
-	uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint32_t wave = thread >> 6, lane = thread & 63;
 	uint32_t ix = (bx << 4) + ((wave & 1) << 3) + (lane & 7);
 	uint32_t iy = (by << 4) + ((wave >> 1) << 3) + (lane >> 3);
 	px = tx * p.tile_size + ix;
@@ -1302,6 +1303,9 @@ inline namespace VKR_MODE_NAMESPACE {
 // the register allocator stop at 168 without scratch (checked for every variant by
 // profiles/tools/kernel_resources.sh), which is the third wave per SIMD.  From V = 7 on the tables
 // of three workgroups no longer fit into the 160 KB of LDS and the allocator would have to spill.
+constexpr uint32_t kShadeThreads = 64;
+// Workgroups to launch for `blocks` 16x16 pixel blocks (whole groups of 8 blocks x 4 patches)
+inline uint32_t shade_grid_size(uint32_t blocks) { return ((blocks + 7u) / 8u) * 32u; }
 constexpr bool has_psa_tables(int strategy, int technique, int error) {
 	return strategy >= kStrategySeparately && (technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular;
 }
@@ -1310,17 +1314,25 @@ constexpr int shade_min_workgroups(int technique, int v, int rays, int error) {
 	return ((technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular && v <= 6 && rays != kRaysInline) ? 3 : 1;
 }
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
-__global__ void __launch_bounds__(256, shade_min_workgroups(TECHNIQUE, V, RAYS, ERROR)) shade_pixels(const shade_params p) {
+__global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(TECHNIQUE, V, RAYS, ERROR)) shade_pixels(const shade_params p) {
+	// A workgroup is ONE wave: the four 8x8 patches of a 16x16 block differ a lot in cost (background,
+	// culled lights), and a wave that is done early gives its registers and LDS back at once instead
+	// of waiting for its block (mean resident waves per SIMD 2.3 -> see profiles/).  Workgroup b runs
+	// on XCD b % 8; the four patches of a block are the workgroups b, b + 8, b + 16, b + 24 of a
+	// group of 32, so they share that XCD's L2.
+	const uint32_t b = blockIdx.x;
+	const uint32_t block = ((b >> 5) << 3) | (b & 7u);
+	const uint32_t thread = (((b >> 3) & 3u) << 6) | threadIdx.x;
 	uint32_t px, py;
 	size_t out_index;
-	bool inside = locate_pixel(p, px, py, out_index);
-	// ray queue of this wave: workgroup b runs on XCD b % 8 and uses one of the 64 queues
-	// of that XCD, so a queue counter's cache line is only ever touched from one L2
-	uint32_t queue = (blockIdx.x & 7u) * 64u + (((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)) & 63u);
+	bool inside = locate_pixel(p, block, thread, px, py, out_index);
+	// ray queue of this wave: one of the 64 queues of its XCD, so a queue counter's cache line is
+	// only ever touched from one L2
+	uint32_t queue = (b & 7u) * 64u + ((b >> 3) & 63u);
 	// the polygon tables exist for the techniques that prepare two polygons per light in registers
 	constexpr bool kTables = has_psa_tables(STRATEGY, TECHNIQUE, ERROR);
 	__shared__ float2 psa_tables[kTables ? 2 * kPsaTableSlots(V) * kPsaTableStride : 1];
-	pixel_context ctx = {p, 0, blockIdx.x * 256u + threadIdx.x, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
+	pixel_context ctx = {p, 0, block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		volatile uint32_t* state = ray_block_state();

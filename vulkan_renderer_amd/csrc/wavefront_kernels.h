@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 	uint32_t px, py;
 	size_t out_index;
-	if (!locate_pixel(p, px, py, out_index)) return;
+	if (!locate_pixel(p, blockIdx.x, threadIdx.x, px, py, out_index)) return;
 	uint32_t tid = blockIdx.x * 256u + threadIdx.x;
 	float4 base = p.base_color[tid];
 	f3 color = mk3(base.x, base.y, base.z);
