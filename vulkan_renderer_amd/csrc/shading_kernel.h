@@ -115,8 +115,15 @@ VKR_DEV size_t code_slot(uint32_t thread_count, uint32_t cursor, uint32_t tid) {
 	return (((size_t) (cursor >> 2) * thread_count + tid) << 2) | (cursor & 3u);
 }
 
-VKR_DEV float load_f(const uint8_t* base, uint32_t offset) { return *(const float*) (base + offset); }
-VKR_DEV uint32_t load_u(const uint8_t* base, uint32_t offset) { return *(const uint32_t*) (base + offset); }
+// Reads of the constant buffer (frame constants and light records; written by the host before the
+// launch, never by a kernel) go through the constant address space: the compiler may then use scalar
+// loads for the wave-uniform addresses and keep or re-load the values as it likes.  As plain global
+// loads they became vector loads with a full s_waitcnt inside the sampling loops - after the first
+// store of a term nothing proves to the compiler that the buffer is still what it was.
+typedef const __attribute__((address_space(4))) float* constant_float_pointer;
+typedef const __attribute__((address_space(4))) uint32_t* constant_uint_pointer;
+VKR_DEV float load_f(const uint8_t* base, uint32_t offset) { return *(constant_float_pointer) (uintptr_t) (base + offset); }
+VKR_DEV uint32_t load_u(const uint8_t* base, uint32_t offset) { return *(constant_uint_pointer) (uintptr_t) (base + offset); }
 VKR_DEV f3 load_f3(const uint8_t* base, uint32_t offset) { return mk3(load_f(base, offset), load_f(base, offset + 4), load_f(base, offset + 8)); }
 
 VKR_DEV float unorm16(uint32_t v) {
