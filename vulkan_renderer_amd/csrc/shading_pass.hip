@@ -153,7 +153,19 @@ struct frame_pipeline {
 	uint32_t next;            // context of the next pipelined frame
 	uint32_t last;            // context of the most recent frame
 	uint32_t depth;           // frames in flight of the most recent pipelined frame
+	// tuning / test knobs, read from the environment once when the pipeline is created:
+	// VKR_WIDE_STACK_LDS (stack entries per lane that trace_shadow_rays_wide keeps in LDS: tests shrink
+	// it to drive rays through the spill path), VKR_LEAF_BATCH (lanes that must have a triangle waiting
+	// before a wave tests triangles), VKR_REFILL_THRESHOLD (binary walk)
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold;
 };
+
+static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
+	const char* text = getenv(name);
+	if (!text || !text[0]) return fallback;
+	long value = strtol(text, NULL, 10);
+	return (uint32_t) (value < (long) low ? (long) low : (value > (long) high ? (long) high : value));
+}
 
 static void destroy_wavefront(shading_pass_t* pass) {
 	frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
@@ -181,6 +193,9 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 		destroy_wavefront(pass);
 		return NULL;
 	}
+	frames->wide_stack_lds = environment_knob("VKR_WIDE_STACK_LDS", kWideStackLds, 4u, kWideStackLds);
+	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
+	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	return frames;
 }
 
@@ -188,16 +203,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 // queues many rays; with one or two per lane the unused slots would outnumber the rays.
 static uint32_t ray_block_size(uint32_t max_terms) { return max_terms >= 8 ? 256u : 0u; }
 
-// Stack entries per lane that trace_shadow_rays_wide keeps in LDS: kWideStackLds, or fewer when
-// VKR_WIDE_STACK_LDS says so (tests: the spill path must give the same frames)
-static uint32_t wide_stack_lds_entries() {
-	const char* knob = getenv("VKR_WIDE_STACK_LDS");
-	int value = knob ? atoi(knob) : (int) kWideStackLds;
-	return (uint32_t) (value < 4 ? 4 : (value > (int) kWideStackLds ? (int) kWideStackLds : value));
-}
-
-static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t trace_threads) {
-	uint32_t in_lds = wide_stack_lds_entries();
+static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t in_lds, uint32_t trace_threads) {
 	size_t entries = stack_need > in_lds ? (size_t) (stack_need - in_lds) * trace_threads : 0;
 	if (entries <= w->spill_entries) return 0;
 	// (frees while other frames may be in flight: hipFree waits for the device)
@@ -705,15 +711,14 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			}
 		}
 		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
-		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, trace_blocks * 256u)) return 1;
+		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
 		const wavefront_buffers* w = &frame->buffers;
 		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden; p.base_color = w->base_color;
 		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
 		p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
 		p.ray_queue_capacity = w->queue_capacity;
 		p.ray_block = ray_mode == kRaysDeferredBlocks ? ray_block_size(max_terms) : 0u;
-		const char* knob = getenv("VKR_REFILL_THRESHOLD");
-		p.refill_threshold = knob ? (uint32_t) atoi(knob) : 0u;
+		p.refill_threshold = frames->refill_threshold;
 	}
 	else if (finish_frames(app)) return 1;
 	pass->last_frame_traced_rays = ray_mode != kRaysNone;
@@ -770,10 +775,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
 	if (status == 0 && is_deferred(ray_mode)) {
 		if (use_wide_tree) {
-			// tuning knob: lanes that must have a triangle waiting before the wave tests triangles
-			const char* batch = getenv("VKR_LEAF_BATCH");
+			const frame_pipeline* knobs = (const frame_pipeline*) pass->wavefront;
 			trace_shadow_rays_wide<<<trace_blocks, 256, 0, stream>>>(p.bvh, (const uint4*) app->scene.acceleration_structure.wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
-				p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, batch ? (uint32_t) atoi(batch) : 16u, wide_stack_lds_entries());
+				p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);
 		}
 		else
 			trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
