@@ -1,10 +1,10 @@
 // The per-pixel shading program as a HIP kernel for gfx950 (CDNA4).
 //
-// One lane per pixel; a wave64 covers an 8x8 pixel patch and a 256-thread
-// workgroup a 16x16 block, so neighbouring lanes read neighbouring triangles,
+// One lane per pixel; a workgroup is one wave64 and covers an 8x8 pixel patch (the four patches
+// of a 16x16 block run on the same XCD), so neighbouring lanes read neighbouring triangles,
 // LTC texels and noise texels and mostly agree on the clipping / sector branches.
-// All uniform inputs (frame constants, light records) are read through
-// wave-uniform addresses and end up in SGPRs.
+// All uniform inputs (frame constants, light records) are read through wave-uniform
+// addresses in the constant address space and end up in SGPRs.
 //
 // Follows reference src/shaders/shading_pass.frag.glsl (main :824-866,
 // evaluate_polygonal_light_shading :329-711, get_shading_data :721-822) with the
