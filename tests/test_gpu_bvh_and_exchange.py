@@ -113,6 +113,27 @@ def test_full_size_config_3_is_bit_exact(big_dataset):
     assert stats["bit_exact"] and stats["nan"] == 0, stats
 
 
+def test_bands_of_full_size_config_4_are_bit_exact(big_dataset):
+    """BASELINE config 4 at its full size (3840x2160, 8 lights of 3 ... 6 vertices, 8 spp per technique,
+    478 M shadow rays): the V = 7 kernel, whose polygon tables leave room for two waves per SIMD only.
+    The oracle shades three bands of 16 rows (a whole frame would take it minutes)."""
+    import oracle
+    r, image = render_config(big_dataset, 4, 3840, 2160)
+    assert r.app.shading_pass.max_polygon_vertex_count == 7
+    inputs = r.host_inputs(r.read_visibility())
+    bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
+    frame = oracle.make_frame(inputs, r.oracle_settings(), bvh)
+    oracle.set_math_mode(1)
+    try:
+        for y0 in (600, 1272, 2000):
+            cpu = oracle.shade(frame, y0, y0 + 16)
+            assert np.array_equal(image[y0:y0 + 16].view(np.uint32), cpu[y0:y0 + 16].view(np.uint32)), y0
+    finally:
+        oracle.set_math_mode(0)
+        r.close()
+    assert not np.isnan(image).any()
+
+
 def test_error_display_frame_reports_no_rays_and_bad_settings_are_caught_at_render_time(dataset):
     r = renderer.Renderer()
     renderer.setup_config(r, 3, dataset, width=128, height=72, acceleration_structure=True)
