@@ -776,8 +776,16 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	if (status == 0 && is_deferred(ray_mode)) {
 		if (use_wide_tree) {
 			const frame_pipeline* knobs = (const frame_pipeline*) pass->wavefront;
-			trace_shadow_rays_wide<<<trace_blocks, 256, 0, stream>>>(p.bvh, (const uint4*) app->scene.acceleration_structure.wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
-				p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);
+			const uint4* wide_nodes = (const uint4*) app->scene.acceleration_structure.wide_nodes;
+			// single-wave workgroups where a lane queues many rays and the shading kernel runs three waves
+			// per SIMD (wavefront_kernels.h has the measurements)
+			bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 6;
+			if (single_waves)
+				trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
+					p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);
+			else
+				trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
+					p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);
 		}
 		else
 			trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);

@@ -123,11 +123,14 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 // build's worst case acceleration_structure_t.wide_stack_need).  A lane whose next item is a
 // triangle waits until `leaf_batch` lanes of the wave have one (or no lane has a node left), so
 // that the triangle test runs with many lanes: the two kinds of work do not share every step.
-#ifndef VKR_TRACE_BOUNDS
-#define VKR_TRACE_BOUNDS 256, 8
-#endif
-__global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
-	__shared__ uint32_t stack[kWideStackLds * 256];
+// THREADS: 256, or 64 - one wave per workgroup, which then leaves on its own when it finds no more
+// chunks and fits into whatever a SIMD has free.  Measured (profiles/): with the three-wave shading
+// kernels and many rays (config 3) single waves overlap the neighbouring frame's shading better
+// (-2.6 %); with few rays (config 2) or the two-wave V >= 7 shading kernels (config 4) launching
+// four times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
+template <uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
+	__shared__ uint32_t stack[kWideStackLds * THREADS];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t xcd = blockIdx.x & 7u;
 	const uint32_t my_queue = xcd * 64u + lane;
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 	uint32_t xcd_rays = my_size;
 #pragma unroll
 	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
-	const uint32_t xcd_waves = (gridDim.x / 8u) * 4u;
+	const uint32_t xcd_waves = (gridDim.x / 8u) * (THREADS / 64u);
 	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
 	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
 	uint32_t inclusive = my_chunks;
@@ -156,19 +159,19 @@ __global__ void __launch_bounds__(VKR_TRACE_BOUNDS) trace_shadow_rays_wide(bvh_v
 	wide_ray ray = {o, o, 0u, 0u, 0u};
 	float t_max = 0.0f;
 	uint32_t item = kIdle, code_index = 0;
-	// The stack pointer is the lane's LDS address itself (entries are 256 lanes x 4 bytes apart), so
+	// The stack pointer is the lane's LDS address itself (entries are THREADS x 4 bytes apart), so
 	// that a push is a store and a conditional add; entries beyond the LDS part only exist as a
 	// depth (`top` then points behind the LDS part and is never dereferenced)
 	// (as 32-bit LDS byte addresses: generic pointers make the compiler do the arithmetic in 64 bits)
 	typedef __attribute__((address_space(3))) uint32_t lds_u32;
-	constexpr uint32_t kEntry = 256u * 4u;
+	constexpr uint32_t kEntry = THREADS * 4u;
 	const uint32_t my_stack = (uint32_t) (uintptr_t) (lds_u32*) (stack + threadIdx.x);
 	// (lds_entries <= kWideStackLds: tests shrink the LDS part to drive rays through the spill path)
 	const uint32_t lds_end = my_stack + lds_entries * kEntry;
 	uint32_t top = my_stack;
 #define VKR_STACK_AT(address) (*(lds_u32*) (uintptr_t) (address))
-	uint32_t* my_spill = spill + (size_t) blockIdx.x * 256u + threadIdx.x;
-	const size_t spill_stride = (size_t) gridDim.x * 256u;
+	uint32_t* my_spill = spill + (size_t) blockIdx.x * THREADS + threadIdx.x;
+	const size_t spill_stride = (size_t) gridDim.x * THREADS;
 	while (true) {
 		// ---- hand new rays to idle lanes (as in trace_shadow_rays) --------------------------
 		uint64_t idle = __ballot(item == kIdle);
