@@ -157,7 +157,8 @@ struct frame_pipeline {
 	// VKR_WIDE_STACK_LDS (stack entries per lane that trace_shadow_rays_wide keeps in LDS: tests shrink
 	// it to drive rays through the spill path), VKR_LEAF_BATCH (lanes that must have a triangle waiting
 	// before a wave tests triangles), VKR_REFILL_THRESHOLD (binary walk)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold;
+	// VKR_TRACE_WAVES: persistent waves per SIMD of the tracing kernels (1 ... 8)
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -196,6 +197,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->wide_stack_lds = environment_knob("VKR_WIDE_STACK_LDS", kWideStackLds, 4u, kWideStackLds);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
+	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 8u, 1u, 8u);
 	return frames;
 }
 
@@ -667,7 +669,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	frame_context* frame = NULL;
 	bool pipelined = false;
 	// the tracing kernels are persistent: 8 waves per SIMD on every CU, each lane strides over the queues
-	const uint32_t trace_blocks = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256) * 8u;
+	// (8 by default; the count is a knob of the frame pipeline)
+	const uint32_t compute_units = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256);
+	uint32_t trace_blocks = compute_units * 8u;
 	const bool use_wide_tree = app->scene.acceleration_structure.wide_nodes && !pass->binary_traversal;
 	if (ray_mode == kRaysDeferred) {
 		uint32_t max_rays_per_lane = 2u * p.light_count * p.sample_count;
@@ -710,6 +714,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				pass->inputs_changed = 0;
 			}
 		}
+		trace_blocks = compute_units * frames->trace_waves;
 		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
 		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
 		const wavefront_buffers* w = &frame->buffers;
