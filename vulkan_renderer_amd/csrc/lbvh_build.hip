@@ -355,6 +355,50 @@ __global__ void __launch_bounds__(256) k_sah_bin(build_params p, const uint32_t*
 	}
 }
 
+// The same for the first levels, where a few open nodes hold all triangles and every atomic above
+// lands on one of a few dozen addresses (level 0: 2.8 M atomics on 48 bins, 11 ms of a 38 ms build):
+// the workgroup bins in LDS first and sends one atomic per non-empty bin and field.  The result
+// is the same: counts add up and the bounds are minima / maxima.
+constexpr uint32_t kSahSharedNodes = 8;
+__global__ void __launch_bounds__(256) k_sah_bin_shared(build_params p, const uint32_t* triangle_node, const sah_open_node* open, uint32_t open_count, sah_bin* bins) {
+	__shared__ sah_bin shared_bins[kSahSharedNodes * 3 * kSahBinCount];
+	const uint32_t bin_count = open_count * 3u * kSahBinCount;
+	for (uint32_t i = threadIdx.x; i < bin_count; i += 256u) {
+		shared_bins[i].count = 0;
+		for (int a = 0; a != 3; ++a) { shared_bins[i].lo[a] = 0xFFFFFFFFu; shared_bins[i].hi[a] = 0u; }
+	}
+	__syncthreads();
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t id = t < p.triangle_count ? triangle_node[t] : kSahDone;
+	if (id != kSahDone) {
+		const sah_open_node* node = open + id;
+		f3 v[3], lo, hi;
+		triangle_bounds(p, t, v, lo, hi);
+		const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+		for (int j = 0; j != 3; ++j) {
+			float c_lo = unordered(node->centroid_bounds[j]), c_hi = unordered(node->centroid_bounds[3 + j]);
+			float scale = sah_bin_scale(c_lo, c_hi);
+			if (!(scale > 0.0f)) continue;
+			int k = sah_bin_index(0.5f * (l[j] + h[j]), c_lo, scale);
+			sah_bin* bin = shared_bins + ((size_t) id * 3 + j) * kSahBinCount + k;
+			atomicAdd(&bin->count, 1u);
+			for (int a = 0; a != 3; ++a) {
+				atomicMin(&bin->lo[a], ordered(l[a]));
+				atomicMax(&bin->hi[a], ordered(h[a]));
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < bin_count; i += 256u) {
+		if (!shared_bins[i].count) continue;
+		atomicAdd(&bins[i].count, shared_bins[i].count);
+		for (int a = 0; a != 3; ++a) {
+			atomicMin(&bins[i].lo[a], shared_bins[i].lo[a]);
+			atomicMax(&bins[i].hi[a], shared_bins[i].hi[a]);
+		}
+	}
+}
+
 struct sah_box {
 	float lo[3], hi[3];
 };
@@ -642,7 +686,8 @@ static int build_sah_on_device(acceleration_structure_t* structure, const device
 			sah_open_node *now = open[level & 1], *next = open[(level + 1) & 1];
 			uint32_t bin_count = open_count * 3u * kSahBinCount;
 			k_sah_clear_bins<<<(bin_count + 255) / 256, 256, 0, stream>>>(bins, bin_count);
-			k_sah_bin<<<blocks, 256, 0, stream>>>(p, triangle_node, now, bins);
+			if (open_count <= kSahSharedNodes) k_sah_bin_shared<<<blocks, 256, 0, stream>>>(p, triangle_node, now, open_count, bins);
+			else k_sah_bin<<<blocks, 256, 0, stream>>>(p, triangle_node, now, bins);
 			k_sah_split<<<(open_count + 63) / 64, 64, 0, stream>>>(now, open_count, bins, next, counters, (float4*) structure->nodes, p.pad);
 			k_sah_assign<<<blocks, 256, 0, stream>>>(p, triangle_node, now, next, (float4*) structure->nodes, (float4*) structure->triangle_vertices);
 			uint32_t next_count = 0, zero = 0;
