@@ -98,12 +98,21 @@ class Job:
             raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the shading pass")
+        # VKR_BENCH_DEVICE / VKR_BENCH_BACKEND=gloo: several ranks on ONE GPU with a CPU process group, to
+        # exercise the N > 1 code paths of this file on a single-GPU box (profiles/tools/two_ranks_one_gpu.sh)
+        if os.environ.get("VKR_BENCH_DEVICE"):
+            self.local_rank = int(os.environ["VKR_BENCH_DEVICE"])
+        self.backend = os.environ.get("VKR_BENCH_BACKEND", "nccl")
+        self.collective_device = "cuda" if self.backend == "nccl" else "cpu"
         torch.cuda.set_device(self.local_rank)
         self.process_group = self.world > 1
         if self.process_group:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % self.rank)
         from vulkan_renderer_amd import synthetic
         # ground plane of 2 x 256^2 triangles + 64 boxes, LTC tables with R = 64, 51 layers
@@ -119,7 +128,7 @@ class Job:
     def max_over_ranks(self, value):
         if not self.process_group:
             return float(value)
-        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.collective_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -127,7 +136,7 @@ class Job:
         """-> list over ranks of lists"""
         if not self.process_group:
             return [list(values)]
-        t = self.torch.tensor(list(values), dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.collective_device)
         out = [self.torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return [[float(v) for v in o.tolist()] for o in out]
@@ -136,7 +145,7 @@ class Job:
         """rank 0's bytes on every rank (the rendezvous token of the C-side communicator)"""
         if not self.process_group:
             return payload
-        t = self.torch.zeros(count, dtype=self.torch.uint8, device="cuda")
+        t = self.torch.zeros(count, dtype=self.torch.uint8, device=self.collective_device)
         if self.rank == 0:
             t.copy_(self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8))
         self.dist.broadcast(t, src=0)
