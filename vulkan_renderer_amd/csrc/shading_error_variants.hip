@@ -17,11 +17,11 @@ using namespace vkr;
 template <int STRATEGY, int TECHNIQUE, int ERROR>
 static int launch_capacity(int capacity, const shade_params& p, dim3 grid, hipStream_t stream) {
 	switch (capacity) {
-	case 4: shade_pixels<STRATEGY, TECHNIQUE, 4, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p); break;
-	case 5: shade_pixels<STRATEGY, TECHNIQUE, 5, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p); break;
-	case 6: shade_pixels<STRATEGY, TECHNIQUE, 6, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p); break;
-	case 7: shade_pixels<STRATEGY, TECHNIQUE, 7, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p); break;
-	case 8: shade_pixels<STRATEGY, TECHNIQUE, 8, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p); break;
+	case 4: shade_pixels<STRATEGY, TECHNIQUE, 4, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(STRATEGY, TECHNIQUE, 4, ERROR), stream>>>(p); break;
+	case 5: shade_pixels<STRATEGY, TECHNIQUE, 5, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(STRATEGY, TECHNIQUE, 5, ERROR), stream>>>(p); break;
+	case 6: shade_pixels<STRATEGY, TECHNIQUE, 6, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(STRATEGY, TECHNIQUE, 6, ERROR), stream>>>(p); break;
+	case 7: shade_pixels<STRATEGY, TECHNIQUE, 7, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(STRATEGY, TECHNIQUE, 7, ERROR), stream>>>(p); break;
+	case 8: shade_pixels<STRATEGY, TECHNIQUE, 8, kRaysNone, ERROR><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(STRATEGY, TECHNIQUE, 8, ERROR), stream>>>(p); break;
 	default: return -1;
 	}
 	return hipGetLastError() != hipSuccess;

@@ -1305,11 +1305,11 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 #define VKR_MODE_NAMESPACE exact_math
 #endif
 inline namespace VKR_MODE_NAMESPACE {
-// Occupancy.  With the polygon tables in LDS (two-technique strategies) the kernel needs 168 - 179
-// VGPRs up to V = 6, the one-technique variants 160 - 175; asking for three workgroups per CU makes
+// Occupancy.  With the polygon tables in LDS (two-technique strategies) the kernel needs 163 - 171
+// VGPRs up to V = 7, the one-technique variants 160 - 175; asking for three waves per SIMD makes
 // the register allocator stop at 168 without scratch (checked for every variant by
-// profiles/tools/kernel_resources.sh), which is the third wave per SIMD.  From V = 7 on the tables
-// of three workgroups no longer fit into the 160 KB of LDS and the allocator would have to spill.
+// profiles/tools/kernel_resources.sh).  Up to V = 6 the tables of twelve waves fit the 160 KB of
+// LDS of a CU, at V = 7 those of ten (three waves on two of the four SIMDs); V = 8 would spill.
 constexpr uint32_t kShadeThreads = 64;
 // Workgroups to launch for `blocks` 16x16 pixel blocks (whole groups of 8 blocks x 4 patches)
 inline uint32_t shade_grid_size(uint32_t blocks) { return ((blocks + 7u) / 8u) * 32u; }
@@ -1317,11 +1317,16 @@ constexpr bool has_psa_tables(int strategy, int technique, int error) {
 	return strategy >= kStrategySeparately && (technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular;
 }
 // (Rays traced inside the kernel bring the traversal's registers with them: those variants would spill.)
-constexpr int shade_min_workgroups(int technique, int v, int rays, int error) {
-	return ((technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular && v <= 6 && rays != kRaysInline) ? 3 : 1;
+constexpr int shade_min_workgroups(int strategy, int technique, int v, int rays, int error) {
+	return ((technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular
+		&& v <= (has_psa_tables(strategy, technique, error) ? 7 : 6) && rays != kRaysInline) ? 3 : 1;
+}
+// bytes of dynamic LDS of a shading workgroup: the polygon tables
+constexpr uint32_t shade_lds_bytes(int strategy, int technique, int v, int error) {
+	return has_psa_tables(strategy, technique, error) ? 2u * (2u * (uint32_t) v + 1u) * kShadeThreads * 8u : 0u;
 }
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
-__global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(TECHNIQUE, V, RAYS, ERROR)) shade_pixels(const shade_params p) {
+__global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, TECHNIQUE, V, RAYS, ERROR)) shade_pixels(const shade_params p) {
 	// A workgroup is ONE wave: the four 8x8 patches of a 16x16 block differ a lot in cost (background,
 	// culled lights), and a wave that is done early gives its registers and LDS back at once instead
 	// of waiting for its block (mean resident waves per SIMD 2.3 -> see profiles/).  Workgroup b runs
@@ -1338,7 +1343,10 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(TECHNIQUE,
 	uint32_t queue = (b & 7u) * 64u + ((b >> 3) & 63u);
 	// the polygon tables exist for the techniques that prepare two polygons per light in registers
 	constexpr bool kTables = has_psa_tables(STRATEGY, TECHNIQUE, ERROR);
-	__shared__ float2 psa_tables[kTables ? 2 * kPsaTableSlots(V) * kPsaTableStride : 1];
+	// (dynamic LDS, shade_lds_bytes() at the launch: a static array would let the compiler conclude from
+	// its size that a third wave cannot fit and drop the register limit that goes with three - at V = 7 ten
+	// waves fit a CU, i.e. three on two of the four SIMDs)
+	extern __shared__ float2 psa_tables[];
 	pixel_context ctx = {p, 0, block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)

@@ -158,7 +158,8 @@ struct frame_pipeline {
 	// it to drive rays through the spill path), VKR_LEAF_BATCH (lanes that must have a triangle waiting
 	// before a wave tests triangles), VKR_REFILL_THRESHOLD (binary walk)
 	// VKR_TRACE_WAVES: persistent waves per SIMD of the tracing kernels (1 ... 8)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves;
+	// VKR_TRACE_SINGLE_WAVES: 0 / 1 overrides the choice of the tracing kernel's workgroup size (2: automatic)
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -198,6 +199,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 8u, 1u, 8u);
+	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
 	return frames;
 }
 
@@ -784,7 +786,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			const uint4* wide_nodes = (const uint4*) app->scene.acceleration_structure.wide_nodes;
 			// single-wave workgroups where a lane queues many rays and the shading kernel runs three waves
 			// per SIMD (wavefront_kernels.h has the measurements)
-			bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 6;
+			bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 7;
+			if (knobs->trace_single_waves != 2u) single_waves = knobs->trace_single_waves != 0u;
 			if (single_waves)
 				trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
 					p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);

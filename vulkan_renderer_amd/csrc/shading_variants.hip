@@ -36,16 +36,16 @@ using namespace vkr;
 
 template <int TECHNIQUE, int V>
 static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
-	if (rays == kRaysDeferred) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferred, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p);
+	if (rays == kRaysDeferred) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferred, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(VKR_STRATEGY, TECHNIQUE, V, VKR_MODE), stream>>>(p);
 #if VKR_STRATEGY >= 2
 	// block-wise reservation of queue slots: built for the strategies that sample two techniques
 	// per light and sample, where a lane queues many rays (the host picks it from 8 rays per lane)
-	else if (rays == kRaysDeferredBlocks) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferredBlocks, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p);
+	else if (rays == kRaysDeferredBlocks) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferredBlocks, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(VKR_STRATEGY, TECHNIQUE, V, VKR_MODE), stream>>>(p);
 #else
 	else if (rays == kRaysDeferredBlocks) return -1;
 #endif
-	else if (rays == kRaysInline) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysInline, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p);
-	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysNone, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, 0, stream>>>(p);
+	else if (rays == kRaysInline) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysInline, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(VKR_STRATEGY, TECHNIQUE, V, VKR_MODE), stream>>>(p);
+	else shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysNone, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(VKR_STRATEGY, TECHNIQUE, V, VKR_MODE), stream>>>(p);
 	return hipGetLastError() != hipSuccess;
 }
 

@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 // THREADS: 256, or 64 - one wave per workgroup, which then leaves on its own when it finds no more
 // chunks and fits into whatever a SIMD has free.  Measured (profiles/): with the three-wave shading
 // kernels and many rays (config 3) single waves overlap the neighbouring frame's shading better
-// (-2.6 %); with few rays (config 2) or the two-wave V >= 7 shading kernels (config 4) launching
-// four times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
+// (-2.6 %, config 4 -0.9 %); with few rays (config 2) or two-wave shading kernels launching four
+// times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
 template <uint32_t THREADS>
 __global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
 	__shared__ uint32_t stack[kWideStackLds * THREADS];
