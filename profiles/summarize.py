@@ -112,7 +112,7 @@ def main():
                 else:
                     floor_us = 4 * c.get("SQ_ACTIVE_INST_VALU", total) / 1024.0 / 2400.0
                     lines.append("- VALU issue floor at 4 clocks per instruction: %.1f us" % floor_us)
-                if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel:
+                if ("shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel) and "fast_math" not in kernel:
                     valu_floor = traffic.setdefault("config%d_exact_valu_floor_us" % cfg, {})
                     valu_floor[kernel.split("::")[-1].split("<")[0]] = round(floor_us, 2)
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -121,7 +121,7 @@ def main():
                     c["FETCH_SIZE"] / 1024, 2 * c["FETCH_SIZE"] / 1024, c["WRITE_SIZE"] / 1024, raw / 1e6)]
                 if "TCC_HIT_sum" in c:
                     lines.append("- L2 hit rate %.1f %%" % (100 * c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)))
-                if "shade_pixels" in kernel:
+                if "shade_pixels" in kernel and "fast_math" not in kernel:
                     w, h = (1920, 1080)
                     traffic["config%d_exact" % cfg] = {"width": w, "height": h, "hbm_bytes_per_launch": int(raw), "source": "profiles/%s_summary.md" % tag}
             lines.append("")
