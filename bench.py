@@ -178,10 +178,11 @@ def run_workload(job, config, primary):
     if not primary:
         steps, warmup = max(4, min(steps, 25)), max(1, min(warmup, 5))
     timing_stride = 1 if steps < 4 * args.timing_stride else args.timing_stride
+    frames_in_flight_requested = args.frames_in_flight or (2 if config == 4 else 3)
 
     # ---- set-up (untimed, reported separately: BASELINE.md section 3) -------------------------
     r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays,
-                          timing_stride=timing_stride, frames_in_flight=args.frames_in_flight, binary_traversal=args.binary_traversal)
+                          timing_stride=timing_stride, frames_in_flight=frames_in_flight_requested, binary_traversal=args.binary_traversal)
     t = time.perf_counter()
     renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh,
                           trace_shadow_rays=settings["trace_shadow_rays"])
@@ -447,20 +448,20 @@ def run_workload(job, config, primary):
                             "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
     if primary and rank == 0 and world == 1 and not distributed and args.mode == "exact" and not args.no_fast_mode and not args.inline_rays and not args.no_rays:
         r.close()
-        result["fast_mode"] = fast_mode_companion(job, config, gpu_image, width, height, sample_count, max(20, min(steps, 200)))
+        result["fast_mode"] = fast_mode_companion(job, config, gpu_image, width, height, sample_count, max(20, min(steps, 200)), frames_in_flight_requested)
         return result
     r.close()
     return result
 
 
-def fast_mode_companion(job, config, exact_image, width, height, sample_count, steps):
+def fast_mode_companion(job, config, exact_image, width, height, sample_count, steps, frames_in_flight):
     """The same workload in the fast arithmetic mode (v_rcp / v_rsq / v_sqrt, contraction), timed the
     same way and compared with the exact-mode frame of this run (which is the oracle's, bit for bit).
     Reported next to the headline, never as the headline: DESIGN.md section 2 explains the pixels
     where approximate arithmetic leaves the stated tolerance."""
     from vulkan_renderer_amd import renderer
     args, torch = job.args, job.torch
-    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, fast_math=True, timing_stride=args.timing_stride, frames_in_flight=args.frames_in_flight)
+    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, fast_math=True, timing_stride=args.timing_stride, frames_in_flight=frames_in_flight)
     renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh)
     r.set_tiles(16, 0, 1, slab_layout=False)
     r.create_targets()
@@ -514,7 +515,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-mode", action="store_true", help="do not also measure the workload in the fast arithmetic mode (reported as \"fast_mode\" next to the exact headline)")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2, 3, 4), help="n >= 2: n consecutive frames overlap on the device's frame streams (like the reference's frame queue)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, choices=(1, 2, 3, 4),
+                    help="n >= 2: n consecutive frames overlap on the device's frame streams, like the frames of the reference's frame queue, which is as deep as "
+                         "its swapchain (main.c:1498: typically 3).  Default: 3, and 2 for config 4, whose wavefront buffers are 47 GB per frame in flight")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")
     ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")
