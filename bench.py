@@ -517,7 +517,7 @@ def main():
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=(1, 2, 3, 4),
                     help="n >= 2: n consecutive frames overlap on the device's frame streams, like the frames of the reference's frame queue, which is as deep as "
-                         "its swapchain (main.c:1498: typically 3).  Default: 3, and 2 for config 4, whose wavefront buffers are 47 GB per frame in flight")
+                         "its swapchain (main.c:1498: typically 3).  Default: 3, and 2 for config 4, whose wavefront buffers are 60 GB per frame in flight")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")
     ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")
