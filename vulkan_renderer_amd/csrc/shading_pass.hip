@@ -157,7 +157,9 @@ struct frame_pipeline {
 	// VKR_WIDE_STACK_LDS (stack entries per lane that trace_shadow_rays_wide keeps in LDS: tests shrink
 	// it to drive rays through the spill path), VKR_LEAF_BATCH (lanes that must have a triangle waiting
 	// before a wave tests triangles), VKR_REFILL_THRESHOLD (binary walk)
-	// VKR_TRACE_WAVES: persistent waves per SIMD of the tracing kernels (1 ... 8)
+	// VKR_TRACE_WAVES: persistent waves per SIMD of the tracing kernels (1 ... 8; 0: eight where a lane
+	// queues eight rays or more, four otherwise - measured at config 2, whose 0.9 M rays are a batch or
+	// two per wave: 0.129 -> 0.121 ms per frame)
 	// VKR_TRACE_SINGLE_WAVES: 0 / 1 overrides the choice of the tracing kernel's workgroup size (2: automatic)
 	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves;
 };
@@ -198,7 +200,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->wide_stack_lds = environment_knob("VKR_WIDE_STACK_LDS", kWideStackLds, 4u, kWideStackLds);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
-	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 8u, 1u, 8u);
+	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
 	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
 	return frames;
 }
@@ -716,7 +718,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				pass->inputs_changed = 0;
 			}
 		}
-		trace_blocks = compute_units * frames->trace_waves;
+		trace_blocks = compute_units * (frames->trace_waves ? frames->trace_waves : (max_terms >= 8u ? 8u : 4u));
 		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
 		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
 		const wavefront_buffers* w = &frame->buffers;
