@@ -181,7 +181,7 @@ def run_workload(job, config, primary):
     frames_in_flight_requested = args.frames_in_flight or (2 if config == 4 else 3)
 
     # ---- set-up (untimed, reported separately: BASELINE.md section 3) -------------------------
-    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, fast_math=(args.mode == "fast"), inline_rays=args.inline_rays,
+    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=args.mode, inline_rays=args.inline_rays,
                           timing_stride=timing_stride, frames_in_flight=frames_in_flight_requested, binary_traversal=args.binary_traversal)
     t = time.perf_counter()
     renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh,
@@ -403,9 +403,10 @@ def run_workload(job, config, primary):
         # the frame for ~12 s of CPU time.
         band = int(min(height, max(24, cores)))
         mid = max(0, height // 2 - band // 2)
-        # exact mode is compared with the oracle's matching polynomial math (bit-comparable),
-        # fast mode with the libm oracle
-        oracle.set_math_mode(1 if args.mode == "exact" else 0)
+        # libm mode (the default) is compared with the oracle's libm mode - the arithmetic that is pinned
+        # against the reference's shader source -, the polynomial "exact" mode with the oracle's
+        # matching polynomial mode, fast mode with the libm oracle
+        oracle.set_math_mode(renderer.ORACLE_MATH_MODE[args.mode])
         oracle.shade(frame_o, mid, mid + band, cores)
         t = time.perf_counter()
         oracle.shade(frame_o, mid, mid + band, cores)
@@ -439,14 +440,15 @@ def run_workload(job, config, primary):
             passes += 1
         result["cpu_baseline"] = {"value": round(passes * sample_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores,
                                   "kind": "port", "seconds": round(cpu_time, 2),
-                                  "sample": "%d pass(es) over %d band(s) of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP over 64-pixel chunks, %s)" % (passes, len(starts), band, sample_pixels, total_pixels, "deterministic polynomial math" if args.mode == "exact" else "libm")}
+                                  "sample": "%d pass(es) over %d band(s) of %d rows (%d of %d pixels), CPU oracle (C99 restatement of the reference GLSL, OpenMP over 64-pixel chunks, %s)" % (passes, len(starts), band, sample_pixels, total_pixels, "deterministic polynomial math" if args.mode == "exact" else "libm math")}
         result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
         oracle.set_math_mode(0)
         result["parity"] = {"rmse_vs_oracle": math.sqrt(sq / max(cnt, 1)), "max_abs": worst, "nan": nan, "tolerance_rmse": 1e-4,
                             "sample_pixels": sample_pixels, "pixels_differing": mismatched, "pixels_over_1e-2": flipped,
                             "rmse_without_those": math.sqrt(sq_without_flips / max(cnt, 1)),
-                            "oracle_math": "polynomial (bit-comparable)" if args.mode == "exact" else "libm"}
-    if primary and rank == 0 and world == 1 and not distributed and args.mode == "exact" and not args.no_fast_mode and not args.inline_rays and not args.no_rays:
+                            "oracle_math": "polynomial (oracle math mode 1, bit-comparable with --mode exact)" if args.mode == "exact"
+                            else "libm (oracle math mode 0: bit-identical to the reference's GLSL compiled as C++, tests/test_reference_live.py; bit-comparable with --mode libm)"}
+    if primary and rank == 0 and world == 1 and not distributed and args.mode != "fast" and not args.no_fast_mode and not args.inline_rays and not args.no_rays:
         r.close()
         result["fast_mode"] = fast_mode_companion(job, config, gpu_image, width, height, sample_count, max(20, min(steps, 200)), frames_in_flight_requested)
         return result
@@ -499,8 +501,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed frames right before the timed ones (default: a tenth of the steps); --prewarm-frames come before them")
     ap.add_argument("--config", type=parse_config, default=3, choices=[1, 2, 3, 4, "target"], help="BASELINE.json configuration (default 3, the heaviest 1080p one); target = 1920x1080, 4 spp, 1 light")
     ap.add_argument("--no-secondary", action="store_true", help="do not also measure BASELINE config 4 (3840x2160, 8 spp, 8 lights)")
-    ap.add_argument("--mode", default="exact", choices=["fast", "exact"],
-                    help="exact: IEEE arithmetic, bit-identical to the CPU oracle (default); fast: approximate reciprocals + contraction")
+    ap.add_argument("--mode", default="libm", choices=["libm", "exact", "fast"],
+                    help="libm: IEEE arithmetic with glibc's transcendentals, bit-identical to the CPU oracle in the mode that is pinned against the reference shader (default); "
+                         "exact: IEEE arithmetic with polynomial transcendentals, bit-identical to the oracle's polynomial mode; fast: approximate reciprocals + contraction")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed frame is cut into tiles (default); weak = the frame height grows with N")
     ap.add_argument("--exchange", choices=("rgba32f", "rgb8", "none"), default="rgba32f",
                     help="N > 1: all-gather of the tile slabs per frame as float radiance (default) or as packed RGB8 of the encoded output, then the scatter into the frame on every rank; none leaves every rank's slab in its HBM")

@@ -135,6 +135,24 @@ typedef struct tile_schedule_s {
 	VkBool32 slab_layout;
 } tile_schedule_t;
 
+/*! How the kernels evaluate what GLSL leaves to the driver (division, sqrt, inversesqrt and the
+	transcendental functions; the reference notes the freedom at polygon_sampling.glsl:79-82).
+	All three run the same program.
+	- libm (0, the default): IEEE division and square roots, no contraction, inversesqrt as
+	  1 / sqrt, atan / acos / sin / cos / log2 / pow with the operations of glibc 2.35 - the
+	  arithmetic of the CPU oracle in its libm mode, which is pinned bit for bit against the
+	  reference's shader source compiled as C++.  Frames equal that oracle's in every bit.
+	- fast (1): approximate reciprocals and roots (1 ulp), contraction.
+	- polynomial (2): IEEE operations with cheaper polynomial transcendentals (the oracle's
+	  "deterministic" math mode mirrors it bit for bit).  A handful of pixels per frame that sit
+	  on a discontinuity of the shader (its NaN guard, a shadow edge) differ from libm. */
+typedef enum arithmetic_mode_e {
+	arithmetic_mode_libm = 0,
+	arithmetic_mode_fast = 1,
+	arithmetic_mode_polynomial = 2,
+	arithmetic_mode_count
+} arithmetic_mode_t;
+
 /*! Replaces shading_pass_t (reference main.h:278-285).  The "pipeline" is a
 	pre-compiled kernel variant chosen on the same axes as the reference's
 	preprocessor defines (main.c:752-792). */
@@ -151,9 +169,8 @@ typedef struct shading_pass_s {
 	size_t constants_size;
 	/*! ring of constant buffers, one per set of constants in flight */
 	void* constants_ring;
-	/*! arithmetic mode: 0 = exact (IEEE division/sqrt, no contraction; bit-comparable
-		with the CPU oracle), 1 = fast (approximate reciprocals, contraction) */
-	int32_t fast_math;
+	/*! arithmetic mode, an arithmetic_mode_t; set before create_shading_pass */
+	int32_t arithmetic_mode;
 	/*! shadow rays: 0 = wavefront (shade -> compacted ray queue -> trace kernel ->
 		ordered resolve; default), 1 = every lane walks the BVH inside the shading
 		kernel.  Both give identical results. */
@@ -188,14 +205,14 @@ typedef struct shading_pass_s {
 	void* timing_ring;
 	uint32_t timing_ring_size, timing_cursor;
 	/*! time every timing_stride-th frame only (0 or 1: every frame; set before
-		create_shading_pass like fast_math); frames rendered so far */
+		create_shading_pass like arithmetic_mode); frames rendered so far */
 	uint32_t timing_stride, frame_counter;
 	/*! 1 if the most recent render_shading_pass() traced shadow rays (an error display frame
 		does not, whatever the settings say): get_last_ray_count() reports 0 otherwise */
 	uint32_t last_frame_traced_rays;
 	/*! 1: the wavefront kernel walks the binary tree even if the scene has the four-wide one
 		(acceleration_structure_t.wide_nodes), for comparisons; results are identical.  Set before
-		create_shading_pass like fast_math. */
+		create_shading_pass like arithmetic_mode. */
 	int32_t binary_traversal;
 } shading_pass_t;
 

@@ -1,21 +1,29 @@
 // Device-side arithmetic for the shading kernels (gfx950).
 //
-// Two arithmetic modes, selected at compile time per translation unit:
-//   VKR_FAST_MATH == 0  "exact": IEEE division and square roots, no contraction
-//                       (-ffp-contract=off), polynomial atan/acos/sincos with
-//                       explicit FMAs.  Every operation is correctly rounded, so the
-//                       result is reproducible on any IEEE machine.
-//   VKR_FAST_MATH == 1  "fast": v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and
-//                       -ffp-contract=fast; same algorithms.
+// Three arithmetic modes, selected at compile time per translation unit (VKR_MATH_MODE):
+//   2  "libm" (the default of the pass): IEEE division and square roots, no contraction
+//      (-ffp-contract=off), inversesqrt as 1 / sqrt, and atan / acos / sin / cos / log2 / pow as
+//      glibc 2.35 evaluates them (glibc_math.h) - operation for operation what the CPU oracle does
+//      in its math mode 0, the mode that is pinned bit for bit against the reference's shader
+//      source compiled as C++.  Frames equal that oracle's in every bit.
+//   0  "exact": the same IEEE operations with cheaper transcendentals: polynomial
+//      atan / acos / sincos / log2 / exp2 with explicit FMAs, one division per arctangent of a
+//      ratio, a seed + Newton inversesqrt.  Every operation is correctly rounded, so the result
+//      is reproducible on any IEEE machine (oracle math mode 1 mirrors it), but a few pixels per
+//      frame land on the other side of a discontinuity (NaN guard, shadow edge) than in mode 2.
+//   1  "fast": v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and -ffp-contract=fast; the
+//      algorithms of mode 0.
 // The reference leaves these precisions to the GLSL driver
 // (src/shaders/polygon_sampling.glsl:79-82).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef VKR_FAST_MATH
-#define VKR_FAST_MATH 0
+#ifndef VKR_MATH_MODE
+#define VKR_MATH_MODE 0
 #endif
+#define VKR_FAST_MATH (VKR_MATH_MODE == 1)
+#define VKR_LIBM_MATH (VKR_MATH_MODE == 2)
 
 #define VKR_DEV __device__ __forceinline__
 
@@ -110,6 +118,10 @@ VKR_DEV float square_root(float x) {
 VKR_DEV float rsqrt(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_rsqf(x);
+#elif VKR_LIBM_MATH
+	// two correctly rounded operations, as the oracle's math mode 0 (and the reference shader
+	// compiled as C++) evaluates inversesqrt
+	return divide(1.0f, square_root(x));
 #else
 	float hx = 0.5f * x;
 	float y = __uint_as_float(0x5F3759DFu - (__float_as_uint(x) >> 1));
@@ -153,6 +165,16 @@ VKR_DEV f3 mul_direction(const m43& m, f3 p) {
 }
 VKR_DEV f3 mul_transposed(const m43& m, f3 d) { return mk3(dot(m.c[0], d), dot(m.c[1], d), dot(m.c[2], d)); }
 
+}  // namespace vkr
+
+// glibc's float functions with this file's division and square root (IEEE inside the exponent
+// range documented at divide())
+#define GM_DIVF(a, b) vkr::divide((a), (b))
+#define GM_SQRTF(x) vkr::square_root(x)
+#include "glibc_math.h"
+
+namespace vkr {
+
 // ---- polynomial transcendentals (coefficients: oracle/tools/fit_math.py) -------
 
 VKR_DEV float atan_unit(float z) {
@@ -170,6 +192,9 @@ VKR_DEV float atan_unit(float z) {
 }
 
 VKR_DEV float arctan(float t) {
+#if VKR_LIBM_MATH
+	return gm_atanf(t);
+#endif
 	float a = fabsf(t);
 	bool big = a > 1.0f;
 	float z = big ? rcp(a) : a;
@@ -183,6 +208,11 @@ VKR_DEV float arctan(float t) {
 // instead of forming the quotient and then its reciprocal.  Operation by operation the mode-1
 // o_positive_atan_ratio of oracle/oracle_math.h (which documents the special cases).
 VKR_DEV float arctan_ratio_positive(float n, float d) {
+#if VKR_LIBM_MATH
+	// as the shader words it: the quotient, its arctangent, pi for a negative quotient
+	float tangent = divide(n, d);
+	return gm_atanf(tangent) + ((tangent < 0.0f) ? kPi : 0.0f);
+#endif
 	float a = fabsf(n), b = fabsf(d);
 	bool big = a > b;
 	float z = divide(big ? b : a, big ? a : b);
@@ -205,6 +235,9 @@ VKR_DEV float asin_tail(float z, float s) {
 
 // acos for arguments already clamped to [0, 1]
 VKR_DEV float arccos_unit(float x) {
+#if VKR_LIBM_MATH
+	return gm_acosf(x);
+#endif
 	if (x <= 0.5f) {
 		float s = x * x;
 		return (kHalfPi - x) - asin_tail(x, s);
@@ -215,13 +248,20 @@ VKR_DEV float arccos_unit(float x) {
 }
 
 // acos on [-1, 1] (o_acos of oracle/oracle_math.h in math mode 1)
-VKR_DEV float arccos(float x) { return (x < 0.0f) ? (kPi - arccos_unit(-x)) : arccos_unit(x); }
+VKR_DEV float arccos(float x) {
+#if VKR_LIBM_MATH
+	return gm_acosf(x);
+#endif
+	return (x < 0.0f) ? (kPi - arccos_unit(-x)) : arccos_unit(x);
+}
 
 // log2 of a positive normal number: exponent + odd series of the mantissa in
 // [sqrt(1/2), sqrt(2)]; same operations as vkr_log2f in oracle/oracle_math.h
 VKR_DEV float log2_poly(float x) {
 #if VKR_FAST_MATH
 	return __log2f(x);
+#elif VKR_LIBM_MATH
+	return gm_log2f(x);
 #else
 	uint32_t bits = __float_as_uint(x);
 	int e = (int) (bits >> 23) - 127;
@@ -256,6 +296,8 @@ VKR_DEV float exp2_poly(float t) {
 VKR_DEV float cube_root_positive(float x) {
 #if VKR_FAST_MATH
 	return __powf(x, 1.0f / 3.0f);
+#elif VKR_LIBM_MATH
+	return gm_powf(x, 1.0f / 3.0f);
 #else
 	if (!(x > 0.0f)) return x;
 	return exp2_poly(log2_poly(x) * (1.0f / 3.0f));
@@ -265,6 +307,8 @@ VKR_DEV float arctan(float t);
 VKR_DEV float arctan2(float y, float x) {
 #if VKR_FAST_MATH
 	return atan2f(y, x);
+#elif VKR_LIBM_MATH
+	return gm_atan2f(y, x);
 #else
 	float a = arctan(divide(y, x));
 	if (x < 0.0f) a += (y >= 0.0f) ? kPi : -kPi;
@@ -273,6 +317,10 @@ VKR_DEV float arctan2(float y, float x) {
 }
 
 VKR_DEV void sincos_poly(float x, float& out_sin, float& out_cos) {
+#if VKR_LIBM_MATH
+	gm_sincosf(x, &out_sin, &out_cos);
+	return;
+#endif
 	const float two_over_pi = 0.63661977236758134308f;
 	const float pio2_hi = 1.57079637050628662109375f;
 	const float pio2_lo = -4.37113882867379e-8f;

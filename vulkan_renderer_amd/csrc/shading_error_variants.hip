@@ -8,8 +8,13 @@
 
 #if VKR_FAST_MATH
 #define VKR_ERROR_LAUNCH_NAME vkr_launch_error_display_fast
+#define VKR_RESOLVE_LAUNCH_NAME vkr_launch_resolve_materials_fast
+#elif VKR_LIBM_MATH
+#define VKR_ERROR_LAUNCH_NAME vkr_launch_error_display_libm
+#define VKR_RESOLVE_LAUNCH_NAME vkr_launch_resolve_materials_libm
 #else
 #define VKR_ERROR_LAUNCH_NAME vkr_launch_error_display_exact
+#define VKR_RESOLVE_LAUNCH_NAME vkr_launch_resolve_materials_exact
 #endif
 
 using namespace vkr;
@@ -46,4 +51,37 @@ extern "C" int VKR_ERROR_LAUNCH_NAME(int combined_path, int technique, int capac
 	if (combined_path && error_mode == kErrorDiffuse) return launch_technique<kStrategyMis, kErrorDiffuse>(technique, capacity, *p, grid, s);
 	if (combined_path && error_mode == kErrorSpecular) return launch_technique<kStrategyMis, kErrorSpecular>(technique, capacity, *p, grid, s);
 	return -1;
+}
+
+// ---- material resolve (textured scenes), in this unit's arithmetic ------------------------------
+
+// One lane per pixel of the frame: the three texture reads of get_shading_data
+// (shading_pass.frag.glsl:754-785) with their screen-space derivatives, written as the eight
+// numbers of a constant material so that the shading kernels stay as they are.
+inline namespace VKR_MODE_NAMESPACE {
+__global__ void __launch_bounds__(256) k_resolve_materials(const shade_params p, float* pixel_materials) {
+	uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint32_t px = blockIdx.x * 16 + ((wave & 1) << 3) + (lane & 7);
+	uint32_t py = blockIdx.y * 16 + ((wave >> 1) << 3) + (lane >> 3);
+	if (px >= p.width || py >= p.height) return;
+	uint32_t primitive = p.visibility[(size_t) py * p.width + px];
+	if (primitive == 0xFFFFFFFFu) return;
+	const uint8_t* c = p.constants;
+	float fx = (float) (int32_t) px, fy = (float) (int32_t) py;
+	f3 ray = mk3(
+		(load_f(c, 96) * fx + load_f(c, 100) * fy) + load_f(c, 104) * 1.0f,
+		(load_f(c, 112) * fx + load_f(c, 116) * fy) + load_f(c, 120) * 1.0f,
+		(load_f(c, 128) * fx + load_f(c, 132) * fy) + load_f(c, 136) * 1.0f);
+	float values[8];
+	resolve_material(p, primitive, ray, values);
+	float4* out = (float4*) (pixel_materials + 8 * ((size_t) py * p.width + px));
+	out[0] = make_float4(values[0], values[1], values[2], values[3]);
+	out[1] = make_float4(values[4], values[5], values[6], values[7]);
+}
+}
+
+extern "C" int VKR_RESOLVE_LAUNCH_NAME(const shade_params* p, float* pixel_materials, void* stream) {
+	dim3 grid((p->width + 15) / 16, (p->height + 15) / 16);
+	k_resolve_materials<<<grid, 256, 0, (hipStream_t) stream>>>(*p, pixel_materials);
+	return hipGetLastError() != hipSuccess;
 }

@@ -1301,6 +1301,8 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 // stubs would be merged by the linker (one mode would silently run for both).
 #if VKR_FAST_MATH
 #define VKR_MODE_NAMESPACE fast_math
+#elif VKR_LIBM_MATH
+#define VKR_MODE_NAMESPACE libm_math
 #else
 #define VKR_MODE_NAMESPACE exact_math
 #endif

@@ -9,21 +9,27 @@
 using namespace vkr;
 
 #define VKR_DECLARE_LAUNCH(mode, s) extern "C" int vkr_launch_shade_##mode##_##s(int technique, int capacity, int rays, const shade_params* p, unsigned int grid_x, void* stream);
-VKR_DECLARE_LAUNCH(exact, 0) VKR_DECLARE_LAUNCH(exact, 1) VKR_DECLARE_LAUNCH(exact, 2) VKR_DECLARE_LAUNCH(exact, 3) VKR_DECLARE_LAUNCH(exact, 4)
-VKR_DECLARE_LAUNCH(fast, 0) VKR_DECLARE_LAUNCH(fast, 1) VKR_DECLARE_LAUNCH(fast, 2) VKR_DECLARE_LAUNCH(fast, 3) VKR_DECLARE_LAUNCH(fast, 4)
-VKR_DECLARE_LAUNCH(textured_exact, 0) VKR_DECLARE_LAUNCH(textured_exact, 1) VKR_DECLARE_LAUNCH(textured_exact, 2) VKR_DECLARE_LAUNCH(textured_exact, 3) VKR_DECLARE_LAUNCH(textured_exact, 4)
-VKR_DECLARE_LAUNCH(textured_fast, 0) VKR_DECLARE_LAUNCH(textured_fast, 1) VKR_DECLARE_LAUNCH(textured_fast, 2) VKR_DECLARE_LAUNCH(textured_fast, 3) VKR_DECLARE_LAUNCH(textured_fast, 4)
+#define VKR_DECLARE_LAUNCHES(mode) VKR_DECLARE_LAUNCH(mode, 0) VKR_DECLARE_LAUNCH(mode, 1) VKR_DECLARE_LAUNCH(mode, 2) VKR_DECLARE_LAUNCH(mode, 3) VKR_DECLARE_LAUNCH(mode, 4)
+VKR_DECLARE_LAUNCHES(libm) VKR_DECLARE_LAUNCHES(fast) VKR_DECLARE_LAUNCHES(exact)
+VKR_DECLARE_LAUNCHES(textured_libm) VKR_DECLARE_LAUNCHES(textured_fast) VKR_DECLARE_LAUNCHES(textured_exact)
 
-extern "C" int vkr_launch_error_display_exact(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
+typedef int (*error_launch_function_t)(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
+extern "C" int vkr_launch_error_display_libm(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
 extern "C" int vkr_launch_error_display_fast(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
+extern "C" int vkr_launch_error_display_exact(int combined_path, int technique, int capacity, int error_mode, const shade_params* p, unsigned int grid_x, void* stream);
+typedef int (*resolve_launch_function_t)(const shade_params* p, float* pixel_materials, void* stream);
+extern "C" int vkr_launch_resolve_materials_libm(const shade_params* p, float* pixel_materials, void* stream);
+extern "C" int vkr_launch_resolve_materials_fast(const shade_params* p, float* pixel_materials, void* stream);
+extern "C" int vkr_launch_resolve_materials_exact(const shade_params* p, float* pixel_materials, void* stream);
 typedef int (*launch_function_t)(int, int, int, const shade_params*, unsigned int, void*);
-// [arithmetic mode + 2 * light textures][strategy]
-static const launch_function_t g_launchers[4][5] = {
-	{vkr_launch_shade_exact_0, vkr_launch_shade_exact_1, vkr_launch_shade_exact_2, vkr_launch_shade_exact_3, vkr_launch_shade_exact_4},
-	{vkr_launch_shade_fast_0, vkr_launch_shade_fast_1, vkr_launch_shade_fast_2, vkr_launch_shade_fast_3, vkr_launch_shade_fast_4},
-	{vkr_launch_shade_textured_exact_0, vkr_launch_shade_textured_exact_1, vkr_launch_shade_textured_exact_2, vkr_launch_shade_textured_exact_3, vkr_launch_shade_textured_exact_4},
-	{vkr_launch_shade_textured_fast_0, vkr_launch_shade_textured_fast_1, vkr_launch_shade_textured_fast_2, vkr_launch_shade_textured_fast_3, vkr_launch_shade_textured_fast_4},
+// [arithmetic_mode_t + 3 * light textures][strategy]
+#define VKR_LAUNCHER_ROW(mode) {vkr_launch_shade_##mode##_0, vkr_launch_shade_##mode##_1, vkr_launch_shade_##mode##_2, vkr_launch_shade_##mode##_3, vkr_launch_shade_##mode##_4}
+static const launch_function_t g_launchers[6][5] = {
+	VKR_LAUNCHER_ROW(libm), VKR_LAUNCHER_ROW(fast), VKR_LAUNCHER_ROW(exact),
+	VKR_LAUNCHER_ROW(textured_libm), VKR_LAUNCHER_ROW(textured_fast), VKR_LAUNCHER_ROW(textured_exact),
 };
+static const error_launch_function_t g_error_launchers[3] = {vkr_launch_error_display_libm, vkr_launch_error_display_fast, vkr_launch_error_display_exact};
+static const resolve_launch_function_t g_resolve_launchers[3] = {vkr_launch_resolve_materials_libm, vkr_launch_resolve_materials_fast, vkr_launch_resolve_materials_exact};
 
 // Events that order streams of one device: a device-scope release is all they need.  The default
 // (system-scope fence: L2 write-back and invalidation at every record) is paid by whatever runs
@@ -482,13 +488,17 @@ static int create_timing_ring(shading_pass_t* pass) {
 }
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
-	int32_t fast_math = pass->fast_math, inline_rays = pass->inline_rays, binary_traversal = pass->binary_traversal;
+	int32_t arithmetic_mode = pass->arithmetic_mode, inline_rays = pass->inline_rays, binary_traversal = pass->binary_traversal;
 	uint32_t timing_stride = pass->timing_stride, frames_in_flight = pass->frames_in_flight;
 	memset(pass, 0, sizeof(*pass));
 	pass->timing_stride = timing_stride;
 	pass->frames_in_flight = frames_in_flight;
 	pass->inputs_changed = 1;
-	pass->fast_math = fast_math ? 1 : 0;
+	if (arithmetic_mode < 0 || arithmetic_mode >= arithmetic_mode_count) {
+		printf("Invalid arithmetic mode %d (0: libm, 1: fast, 2: polynomial).\n", arithmetic_mode);
+		return 1;
+	}
+	pass->arithmetic_mode = arithmetic_mode;
 	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->binary_traversal = binary_traversal ? 1 : 0;
 	pass->variant = -1;
@@ -536,31 +546,6 @@ extern "C" uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank
 	uint32_t grid_blocks = 0;
 	fill_tile_schedule(p, &copy, grid_blocks);
 	return (uint64_t) grid_blocks * 256;
-}
-
-// ---- material resolve (textured scenes) ----------------------------------------------
-
-// One lane per pixel of the frame: the three texture reads of get_shading_data
-// (shading_pass.frag.glsl:754-785) with their screen-space derivatives, written as the eight
-// numbers of a constant material so that the shading kernels stay as they are.
-__global__ void __launch_bounds__(256) k_resolve_materials(const shade_params p, float* pixel_materials) {
-	uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	uint32_t px = blockIdx.x * 16 + ((wave & 1) << 3) + (lane & 7);
-	uint32_t py = blockIdx.y * 16 + ((wave >> 1) << 3) + (lane >> 3);
-	if (px >= p.width || py >= p.height) return;
-	uint32_t primitive = p.visibility[(size_t) py * p.width + px];
-	if (primitive == 0xFFFFFFFFu) return;
-	const uint8_t* c = p.constants;
-	float fx = (float) (int32_t) px, fy = (float) (int32_t) py;
-	f3 ray = mk3(
-		(load_f(c, 96) * fx + load_f(c, 100) * fy) + load_f(c, 104) * 1.0f,
-		(load_f(c, 112) * fx + load_f(c, 116) * fy) + load_f(c, 120) * 1.0f,
-		(load_f(c, 128) * fx + load_f(c, 132) * fy) + load_f(c, 136) * 1.0f);
-	float values[8];
-	resolve_material(p, primitive, ray, values);
-	float4* out = (float4*) (pixel_materials + 8 * ((size_t) py * p.width + px));
-	out[0] = make_float4(values[0], values[1], values[2], values[3]);
-	out[1] = make_float4(values[4], values[5], values[6], values[7]);
 }
 
 __global__ void k_encode_output_rgb8(const float4* radiance, uint32_t* packed, uint64_t quad_count, uint32_t frame_bits, int output_linear_rgb);
@@ -763,8 +748,10 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	if (upload_constants(app, stream)) return 1;
 	p.constants = (const uint8_t*) pass->constants_device;
 	if (textured) {
-		dim3 resolve_grid((p.width + 15) / 16, (p.height + 15) / 16);
-		k_resolve_materials<<<resolve_grid, 256, 0, stream>>>(p, (float*) pass->pixel_materials);
+		if (g_resolve_launchers[pass->arithmetic_mode](&p, (float*) pass->pixel_materials, stream)) {
+			printf("Launching the material resolve kernel failed.\n");
+			return 1;
+		}
 		p.pixel_materials = (const float*) pass->pixel_materials;
 	}
 	int strategy = (int) app->render_settings.sampling_strategies;
@@ -779,8 +766,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	++pass->frame_counter;
 	if (timed) (void) hipEventRecord(ring[3 * slot], stream);
 	int status = error_mode != kErrorNone
-		? (pass->fast_math ? vkr_launch_error_display_fast : vkr_launch_error_display_exact)(strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
-		: g_launchers[(pass->fast_math ? 1 : 0) + (p.light_texture_descriptors ? 2 : 0)][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
+		? g_error_launchers[pass->arithmetic_mode](strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
+		: g_launchers[pass->arithmetic_mode + (p.light_texture_descriptors ? 3 : 0)][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
 	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
 	if (status == 0 && is_deferred(ray_mode)) {
 		if (use_wide_tree) {

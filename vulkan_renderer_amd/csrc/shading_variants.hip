@@ -1,6 +1,6 @@
 // Instantiates the shade_pixels variants of one sampling strategy and one
-// arithmetic mode.  Built once per (VKR_STRATEGY, VKR_FAST_MATH) pair so that the
-// translation units compile in parallel; the exact-mode units are compiled with
+// arithmetic mode.  Built once per (VKR_STRATEGY, VKR_MATH_MODE) pair so that the
+// translation units compile in parallel; the libm- and exact-mode units are compiled with
 // -ffp-contract=off, the fast-mode units with -ffp-contract=fast.
 #include "shading_kernel.h"
 
@@ -20,6 +20,8 @@
 #define VKR_MODE kLightTextures
 #if VKR_FAST_MATH
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_fast_, VKR_STRATEGY, , )
+#elif VKR_LIBM_MATH
+#define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_libm_, VKR_STRATEGY, , )
 #else
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_exact_, VKR_STRATEGY, , )
 #endif
@@ -27,6 +29,8 @@
 #define VKR_MODE kErrorNone
 #if VKR_FAST_MATH
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_fast_, VKR_STRATEGY, , )
+#elif VKR_LIBM_MATH
+#define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_libm_, VKR_STRATEGY, , )
 #else
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_exact_, VKR_STRATEGY, , )
 #endif

@@ -21,6 +21,9 @@ TECHNIQUE = {"baseline": 0, "area_turk": 1, "rectangle_solid_angle_urena": 2, "s
              "projected_solid_angle_arvo": 10, "solid_angle": 4, "clipped_solid_angle": 5, "projected_solid_angle": 11,
              "projected_solid_angle_biased": 12}
 NOISE = {"white": 0, "blue": 1, "ahmed": 2}
+# arithmetic_mode_t; and the math mode of the CPU oracle that evaluates the same operations
+ARITHMETIC_MODES = {"libm": 0, "fast": 1, "exact": 2}
+ORACLE_MATH_MODE = {"libm": 0, "fast": 0, "exact": 1}
 # acceleration_structure_builder_t (include/vkr_scene.h); True selects the default (HIP kernels, binned SAH)
 BVH_BUILDER = {False: 0, None: 0, True: 1, "sah_device": 1, "lbvh_device": 2, "sah_host": 3}
 BVH_BUILDER_NAME = {0: "none", 1: "binned SAH built by HIP kernels", 2: "Morton-code LBVH built by HIP kernels", 3: "binned SAH built on the host"}
@@ -228,7 +231,7 @@ class HostScene:
 class Renderer(HostScene):
     """The shading pass on one MI355X."""
 
-    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1, binary_traversal=False):
+    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1, binary_traversal=False, arithmetic=None):
         super().__init__()
         self.binary_traversal = binary_traversal
         self.exchange = None
@@ -237,7 +240,10 @@ class Renderer(HostScene):
         if self.lib.create_hip_device(C.byref(self.app.device), hip_device, stream):
             raise RuntimeError("no usable HIP device: the shading pass has no CPU fallback")
         self._device = True
-        self.fast_math = fast_math
+        # arithmetic_mode_t of include/vkr_shading_pass.h: "libm" (default; equals the oracle's
+        # math mode 0 bit for bit), "fast", "exact" (polynomial; equals the oracle's math mode 1)
+        self.arithmetic = arithmetic if arithmetic is not None else ("fast" if fast_math else "libm")
+        self.fast_math = self.arithmetic == "fast"
         self.inline_rays = inline_rays
 
     def create_targets(self):
@@ -249,7 +255,7 @@ class Renderer(HostScene):
     def create_pass(self):
         if self.app.shading_pass.constants_device:
             self.lib.destroy_shading_pass(C.byref(self.app.shading_pass), self._dev())
-        self.app.shading_pass.fast_math = int(self.fast_math)
+        self.app.shading_pass.arithmetic_mode = ARITHMETIC_MODES[self.arithmetic]
         self.app.shading_pass.inline_rays = int(self.inline_rays)
         self.app.shading_pass.timing_stride = int(self.timing_stride)
         self.app.shading_pass.frames_in_flight = int(self.frames_in_flight)
