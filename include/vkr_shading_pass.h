@@ -214,6 +214,14 @@ typedef struct shading_pass_s {
 		(acceleration_structure_t.wide_nodes), for comparisons; results are identical.  Set before
 		create_shading_pass like arithmetic_mode. */
 	int32_t binary_traversal;
+	/*! hipEvent_t or NULL: the next render_shading_pass() makes the stream it runs the frame on wait
+		for this event before its first kernel, then clears the field.  For callers that hand the
+		frame a target which earlier work on another stream still reads (the slab exchange): only the
+		pass knows which stream the frame will take. */
+	void* wait_before_next_frame;
+	/*! hipStream_t the most recent render_shading_pass() queued its kernels on (device->stream or
+		one of the frame streams) */
+	void* last_frame_stream;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
@@ -371,10 +379,12 @@ VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics
 VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]);
 
 /*! Diagnostics for the arithmetic contract of the kernels (csrc/device_math.h, mirrored by
-	oracle/oracle_math.h): evaluates one primitive of the exact arithmetic mode element-wise on the
-	device.  operation 0: divide(a, b), 1: square_root(a), 2: rsqrt(a), 3: the compiler's IEEE a / b,
-	4: the compiler's IEEE sqrtf(a).  a, b (may be NULL for unary operations) and out are host
-	arrays of `count` floats.  0 on success. */
+	oracle/oracle_math.h): evaluates one primitive of the IEEE arithmetic modes element-wise on the
+	device.  operation 0: divide(a, b), 1: square_root(a), 2: rsqrt(a) of the polynomial mode, 3: the
+	compiler's IEEE a / b, 4: the compiler's IEEE sqrtf(a); the functions of the libm mode
+	(csrc/glibc_math.h): 5 atanf, 6 acosf, 7 sinf, 8 cosf, 9 log2f, 10 powf(a, b), 11 atan2f(a, b),
+	12 inversesqrt as 1 / sqrt.  a, b (may be NULL for unary operations) and out are host arrays of
+	`count` floats.  0 on success. */
 VKR_API int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count);
 
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,

@@ -39,9 +39,23 @@ typedef struct slab_exchange_id_s {
 	char bytes[128];
 } slab_exchange_id_t;
 
+/*! The collective behind the exchange: rank-major concatenation of every rank's `send_bytes` bytes
+	at `send` into `gathered` on EVERY rank, queued on hipStream_t `stream`; `set` is the buffer set
+	of the frame (slab_exchange_t.gathered[set] == gathered).  Called once per frame by every rank.
+	The default is ncclAllGather (create_slab_exchange); create_slab_exchange_with_gather() takes any
+	other transport, create_local_slab_exchange() one made of device-to-device copies for ranks that
+	live in one process.  Returns 0 on success. */
+typedef int (*slab_gather_function_t)(void* context, uint32_t rank, uint32_t set, const void* send, void* gathered, uint64_t send_bytes, void* stream);
+
+/*! Ranks of one process that exchange their slabs with plain copies (opaque; see create_local_slab_group) */
+typedef struct local_slab_group_s local_slab_group_t;
+
 typedef struct slab_exchange_s {
-	/*! RCCL binding and communicator (internal) */
+	/*! RCCL binding and communicator (internal; NULL with a caller-supplied gather) */
 	void* binding;
+	/*! the collective and its context */
+	slab_gather_function_t gather;
+	void* gather_context;
 	uint32_t rank, rank_count;
 	slab_format_t format;
 	/*! pixels of one rank's slab (get_slab_pixel_count(app, 0): all slabs are padded to it)
@@ -79,6 +93,19 @@ VKR_API int get_slab_exchange_id(slab_exchange_id_t* id);
 	app->tile_schedule.slab_layout must be set.  Several ranks in one process: call from one
 	thread per GPU.  0 on success; prints the reason and cleans up otherwise. */
 VKR_API int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const slab_exchange_id_t* id, slab_format_t format);
+/*! The same with the collective supplied by the caller (no RCCL is loaded): `gather` is called from
+	render_and_exchange_frame() on every rank, once per frame */
+VKR_API int create_slab_exchange_with_gather(slab_exchange_t* exchange, application_t* app, slab_gather_function_t gather, void* gather_context, slab_format_t format);
+/*! Ranks that live in ONE process (one thread per rank, each with its own application_t, on one
+	device or on devices with peer access): the "collective" is rank_count device-to-device copies
+	per rank and frame, ordered by events, with a host-side rendezvous of the ranks' threads per
+	frame where RCCL's kernels would meet on the device.  What it is for: running the whole N-rank
+	schedule - tiles, slabs, buffer sets, overlap with the next frame, scatter - where RCCL cannot (RCCL
+	refuses two ranks on one device), e.g. on a single-GPU machine.  Create the group once, then one
+	exchange per rank from that rank's thread; every rank must submit the same number of frames. */
+VKR_API local_slab_group_t* create_local_slab_group(uint32_t rank_count);
+VKR_API void destroy_local_slab_group(local_slab_group_t* group);
+VKR_API int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, local_slab_group_t* group, slab_format_t format);
 VKR_API void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app);
 /*! One frame of the multi-GPU pass, queued asynchronously: render_shading_pass() of this rank's
 	tiles into a slab (encoded on the same stream for rgb8), ncclAllGather of the slabs on the
@@ -86,8 +113,9 @@ VKR_API void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app
 	render_targets.encoded for rgb8).  The collective and the scatter of frame k overlap the
 	shading of frame k + 1; frames complete in order. */
 VKR_API int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, void* out_frame);
-/*! The collective alone: ncclAllGather of `send_bytes` bytes per rank from `send` into
-	`gathered` (rank-major) on hipStream_t `stream`, for callers that schedule the steps themselves */
+/*! The collective alone (ncclAllGather unless the exchange was created with another one):
+	`send_bytes` bytes per rank from `send` into `gathered` (rank-major) on hipStream_t `stream`, for
+	callers that schedule the steps themselves */
 VKR_API int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered, void* stream);
 /*! Makes app->device.stream wait (on the device) for every frame submitted so far to be
 	assembled.  read_back_radiance() / read_back_encoded() / encode_output() then see that frame. */

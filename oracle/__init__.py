@@ -27,7 +27,7 @@ def build(force=False):
     """Compiles liboracle.so (and oracle/_ref when /root/reference exists)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("oracle_shading.c", "oracle_bvh.c", "oracle.h", "oracle_math.h")):
+            for f in ("oracle_shading.c", "oracle_bvh.c", "oracle_libm.c", "oracle.h", "oracle_math.h", os.path.join("..", "vulkan_renderer_amd", "csrc", "glibc_math.h"))):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -98,6 +98,9 @@ def lib():
         L.oracle_shading_data.argtypes = [C.POINTER(Frame), C.c_uint32, C.c_uint32, fp]
         L.oracle_evaluate_brdf.argtypes = [fp, fp, C.c_int, C.c_int, fp]
         L.oracle_noise_stream.argtypes = [C.POINTER(Frame), C.c_uint32, C.c_uint32, C.c_uint32, fp]
+        L.oracle_libm_evaluate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_libm_count_mismatches.restype = C.c_size_t
+        L.oracle_libm_count_mismatches.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_float, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -112,6 +115,27 @@ def _f32(a):
 
 def set_math_mode(mode):
     lib().oracle_set_math_mode(int(mode))
+
+
+# operation codes of oracle_libm.c == evaluate_device_arithmetic (include/vkr_shading_pass.h)
+LIBM_OPERATIONS = {"atan": 5, "acos": 6, "sin": 7, "cos": 8, "log2": 9, "pow": 10, "atan2": 11, "inverse_sqrt": 12}
+
+
+def libm_evaluate(operation, a, b=None, port=False):
+    """f(a, b) elementwise by this machine's C library (or, port=True, by the restatement of glibc
+    2.35 in vulkan_renderer_amd/csrc/glibc_math.h compiled for the host)"""
+    a = np.ascontiguousarray(a, np.float32)
+    b = None if b is None else np.ascontiguousarray(b, np.float32)
+    out = np.zeros_like(a)
+    lib().oracle_libm_evaluate(LIBM_OPERATIONS[operation], int(port), a.ctypes.data, None if b is None else b.ctypes.data, out.ctypes.data, a.size)
+    return out
+
+
+def libm_count_mismatches(operation, first_bits, stride, count, second_argument=0.0):
+    """-> (arguments for which the restatement and the C library differ, bits of one of them)"""
+    bad = C.c_uint32(0)
+    n = lib().oracle_libm_count_mismatches(LIBM_OPERATIONS[operation], first_bits, stride, count, second_argument, C.byref(bad))
+    return int(n), int(bad.value)
 
 
 def clip_polygon(vertices, max_count=None, min_count=3):

@@ -5,12 +5,13 @@
 set -e
 TAG=$1; UNIT=$2; EXTRA=$3
 cd "$(dirname "$0")/../../vulkan_renderer_amd/csrc"
-make -s -j 32 all > /dev/null
+make -s -j 8 all > /dev/null
 SRC=shading_variants.hip; DEFS=""
 case $UNIT in
-	shade_exact_*) DEFS="-ffp-contract=off -DVKR_FAST_MATH=0 -DVKR_STRATEGY=${UNIT##*_}";;
-	shade_fast_*) DEFS="-ffp-contract=fast -DVKR_FAST_MATH=1 -DVKR_STRATEGY=${UNIT##*_}";;
-	shading_pass) SRC=shading_pass.hip; DEFS="-ffp-contract=off -DVKR_FAST_MATH=0";;
+	shade_libm_*) DEFS="-ffp-contract=off -DVKR_MATH_MODE=2 -DVKR_STRATEGY=${UNIT##*_}";;
+	shade_exact_*) DEFS="-ffp-contract=off -DVKR_MATH_MODE=0 -DVKR_STRATEGY=${UNIT##*_}";;
+	shade_fast_*) DEFS="-ffp-contract=fast -DVKR_MATH_MODE=1 -DVKR_STRATEGY=${UNIT##*_}";;
+	shading_pass) SRC=shading_pass.hip; DEFS="-ffp-contract=off -DVKR_MATH_MODE=0";;
 	*) echo "unknown unit $UNIT"; exit 1;;
 esac
 mkdir -p build/ab

@@ -25,4 +25,4 @@ def big_dataset(tmp_path_factory):
     """The benchmark scene (2 * 256^2 ground triangles + 64 boxes)."""
     from vulkan_renderer_amd import synthetic
     d = tmp_path_factory.mktemp("big_dataset")
-    return synthetic.write_dataset(str(d), grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51)
+    return synthetic.write_dataset(str(d), grid=256, box_count=64, seed=1234, ltc_resolution=64, fresnel_count=51)

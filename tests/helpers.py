@@ -74,3 +74,49 @@ class DeviceBuffer:
         if self.ptr:
             DeviceBuffer._hip.hipFree(self.ptr)
             self.ptr = None
+
+
+# ---- pixels on a discontinuity of the shader ---------------------------------------------------
+#
+# Two arithmetics that agree to a few ulp per operation (libm vs polynomial transcendentals, IEEE vs
+# approximate reciprocals) produce frames that agree to ~1e-5 everywhere except at pixels where a
+# last-bit difference is pushed through a discontinuity of the shader itself:
+#   guard        the NaN guard of the reference (src/shaders/shading_pass.frag.glsl:861-864): a sliver
+#                sector makes normalize_approx_and_flip(0) = NaN ("undefined if rhs is zero",
+#                polygon_sampling.glsl:597-611) and the pixel is painted (1, 0, 0.8); whether a sample
+#                lands in such a sector is decided by the last bits of the sector areas
+#   silhouette   a shadow ray whose direction differs in the last bits passes a triangle edge on the
+#                other side: one whole estimator term appears or disappears (ray query, :120-138).
+#                Recognised mechanically: the two frames agree at that pixel when rendered WITHOUT
+#                shadow rays
+#   other        anything else - must not exist
+GUARD_COLOR = np.array([1.0, 0.0, 0.8])
+
+
+def is_guard_pixel(image):
+    return np.abs(image[..., :3].astype(np.float64) - GUARD_COLOR).max(axis=-1) < 1.0e-5
+
+
+def classify_outliers(a, b, a_without_rays=None, b_without_rays=None, threshold=1.0e-2):
+    """Statistics of frame `a` against frame `b` (same scene and settings, two arithmetics) with
+    every pixel that differs by more than `threshold` put into one of the classes above.
+    The frames without shadow rays are only needed if such pixels exist outside the guard class."""
+    da = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+    per_pixel = np.abs(np.nan_to_num(da, nan=1.0e3)).max(axis=-1)
+    outlier = per_pixel > threshold
+    guard = outlier & (is_guard_pixel(a) | is_guard_pixel(b))
+    rest = outlier & ~guard
+    silhouette = np.zeros_like(rest)
+    if rest.any() and a_without_rays is not None and b_without_rays is not None:
+        dn = np.abs(a_without_rays[..., :3].astype(np.float64) - b_without_rays[..., :3].astype(np.float64)).max(axis=-1)
+        silhouette = rest & (dn <= threshold)
+    other = rest & ~silhouette
+    inlier = ~outlier
+    return {
+        "rmse": float(np.sqrt((np.nan_to_num(da, nan=1.0e3) ** 2).mean())),
+        "rmse_without_outliers": float(np.sqrt((da[inlier] ** 2).sum() / da.size)),
+        "pixels_over_threshold": int(outlier.sum()), "threshold": threshold,
+        "guard_pixels": int(guard.sum()), "silhouette_pixels": int(silhouette.sum()), "other_pixels": int(other.sum()),
+        "guard_pixels_in_a": int(is_guard_pixel(a).sum()), "guard_pixels_in_b": int(is_guard_pixel(b).sum()),
+        "other_coordinates": [tuple(int(v) for v in yx) for yx in np.argwhere(other)[:8]],
+    }

@@ -1,0 +1,104 @@
+"""The restatement of glibc 2.35's float functions (vulkan_renderer_amd/csrc/glibc_math.h) that the
+"libm" arithmetic mode of the kernels evaluates.
+
+CPU: the restatement, compiled for the host into liboracle.so, against this machine's C library on
+every 64th float of the whole range plus the ranges the shading pass lives in taken densely
+(oracle/tools/check_glibc_math.c is the exhaustive form: all 2^32 arguments of every function,
+result in profiles/r03a/glibc_math_exhaustive.txt).
+GPU: the same functions evaluated on the device through the C-ABI (evaluate_device_arithmetic)
+against the C library of the host, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+UNARY = ["atan", "acos", "sin", "cos", "log2", "inverse_sqrt"]
+
+
+@pytest.mark.parametrize("operation", UNARY + ["pow"])
+def test_restatement_equals_the_c_library_on_the_cpu(operation):
+    second = {"pow": 1.0 / 3.0}.get(operation, 0.0)
+    # every 64th bit pattern of the whole range ...
+    n, bad = oracle.libm_count_mismatches(operation, 17, 64, 1 << 26, second)
+    assert n == 0, (operation, n, hex(bad))
+    # ... and all floats of [2^-4, 8) (tangents, cosines, angles), both signs
+    for first in (0x3D800000, 0xBD800000):
+        n, bad = oracle.libm_count_mismatches(operation, first, 1, 0x41000000 - 0x3D800000, second)
+        assert n == 0, (operation, n, hex(bad))
+    if operation == "pow":
+        for exponent in (2.4, 1.0 / 2.4, 0.5, -1.5, 7.0):
+            n, bad = oracle.libm_count_mismatches("pow", 3, 257, 1 << 24, exponent)
+            assert n == 0, (exponent, n, hex(bad))
+
+
+def special_and_random_pairs(rng, count):
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, -2.0, 3.0, np.inf, -np.inf, np.nan, 1.0e-40, -1.0e-40, 1.1754944e-38, 3.4028235e38, 1.0 / 3.0, 2.4, 1.0e-30, 1.0e30],
+                       np.float32)
+    a, b = np.meshgrid(special, special)
+    bits = rng.integers(0, 1 << 32, (2, count), dtype=np.uint64).astype(np.uint32)
+    moderate = ((bits & 0x807FFFFF) | ((110 + ((bits >> 23) & 31)) << 23)).astype(np.uint32)
+    return (np.concatenate([a.ravel(), bits[0].view(np.float32), moderate[0].view(np.float32)]),
+            np.concatenate([b.ravel(), bits[1].view(np.float32), moderate[1].view(np.float32)]))
+
+
+@pytest.mark.parametrize("operation", ["atan2", "pow"])
+def test_two_argument_functions_equal_the_c_library_on_the_cpu(operation):
+    a, b = special_and_random_pairs(np.random.default_rng(11), 1 << 22)
+    ours, theirs = oracle.libm_evaluate(operation, a, b, port=True), oracle.libm_evaluate(operation, a, b)
+    same = (ours.view(np.uint32) == theirs.view(np.uint32)) | (np.isnan(ours) & np.isnan(theirs))
+    assert same.all(), (operation, int((~same).sum()), a[~same][:4], b[~same][:4])
+
+
+@pytest.fixture(scope="module")
+def device():
+    from vulkan_renderer_amd import renderer
+    r = renderer.Renderer()
+    yield r
+    r.close()
+
+
+def on_device(r, operation, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.zeros_like(a)
+    fp = C.POINTER(C.c_float)
+    b_pointer = None if b is None else np.ascontiguousarray(b, np.float32).ctypes.data_as(fp)
+    assert r.lib.evaluate_device_arithmetic(C.byref(r.app.device), oracle.LIBM_OPERATIONS[operation], a.ctypes.data_as(fp), b_pointer, out.ctypes.data_as(fp), a.size) == 0
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("operation", UNARY)
+def test_device_functions_equal_the_c_library_of_the_host(operation, device):
+    """2^26 bit patterns spread over the whole range (every 64th float) and the dense range
+    [2^-4, 8) with both signs: 2^27 arguments per function"""
+    for chunk in range(4):
+        bits = (np.arange(1 << 24, dtype=np.uint64) * 64 + 17 + (chunk << 30)).astype(np.uint32)
+        x = bits.view(np.float32)
+        if operation == "inverse_sqrt":
+            # the documented window of the kernels' division and square root (csrc/device_math.h)
+            x = np.where((np.abs(x) >= 1.0e-30) & (np.abs(x) <= 1.0e30), x, np.float32(2.0)).astype(np.float32)
+        gpu, cpu = on_device(device, operation, x), oracle.libm_evaluate(operation, x)
+        same = (gpu.view(np.uint32) == cpu.view(np.uint32)) | (np.isnan(gpu) & np.isnan(cpu))
+        assert same.all(), (operation, int((~same).sum()), x[~same][:4], gpu[~same][:4], cpu[~same][:4])
+    dense = np.arange(0x3D800000, 0x41000000, dtype=np.uint32)
+    for sign in (0, 0x80000000):
+        x = (dense | np.uint32(sign)).view(np.float32)
+        gpu, cpu = on_device(device, operation, x), oracle.libm_evaluate(operation, x)
+        same = (gpu.view(np.uint32) == cpu.view(np.uint32)) | (np.isnan(gpu) & np.isnan(cpu))
+        assert same.all(), (operation, sign, int((~same).sum()), x[~same][:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("operation", ["atan2", "pow"])
+def test_two_argument_device_functions_equal_the_c_library_of_the_host(operation, device):
+    a, b = special_and_random_pairs(np.random.default_rng(12), 1 << 23)
+    gpu, cpu = on_device(device, operation, a, b), oracle.libm_evaluate(operation, a, b)
+    same = (gpu.view(np.uint32) == cpu.view(np.uint32)) | (np.isnan(gpu) & np.isnan(cpu))
+    # (atan2 divides y by x with the kernels' division: operands at the ends of the exponent range are outside its window)
+    if operation == "atan2":
+        window = (np.abs(a) >= 1.0e-30) & (np.abs(a) <= 1.0e30) & (np.abs(b) >= 1.0e-30) & (np.abs(b) <= 1.0e30)
+        special = ~np.isfinite(a) | ~np.isfinite(b) | (a == 0) | (b == 0)
+        same = same | ~(window | special)
+    assert same.all(), (operation, int((~same).sum()), a[~same][:4], b[~same][:4], gpu[~same][:4], cpu[~same][:4])

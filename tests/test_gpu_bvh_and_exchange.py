@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 BUILDERS = ["sah_device", "lbvh_device", "sah_host"]
 
 
-def render_config(dataset, config, width, height, builder="sah_device", binary_traversal=False, frames_in_flight=1, **overrides):
-    r = renderer.Renderer(binary_traversal=binary_traversal, frames_in_flight=frames_in_flight)
+def render_config(dataset, config, width, height, builder="sah_device", binary_traversal=False, frames_in_flight=1, arithmetic="libm", **overrides):
+    r = renderer.Renderer(binary_traversal=binary_traversal, frames_in_flight=frames_in_flight, arithmetic=arithmetic)
     renderer.setup_config(r, config, dataset, width=width, height=height, acceleration_structure=builder, **overrides)
     r.create_targets()
     r.create_pass()
@@ -40,7 +40,7 @@ def test_every_builder_and_both_trees_give_the_oracle_frame(dataset, builder, bi
     assert 3 <= structure.wide_stack_need <= 128
     visibility = r.read_visibility()
     rays = r.last_ray_count()
-    cpu, inputs, bvh = oracle_render(r, visibility=visibility, math_mode=1)
+    cpu, inputs, bvh = oracle_render(r, visibility=visibility, math_mode=renderer.ORACLE_MATH_MODE[r.arithmetic])
     stats = compare(image, cpu)
     # the same rays through both layouts: the wide tree must be a collapse of the binary one
     wide, binary = r.traversal_statistics(True), r.traversal_statistics(False)
@@ -60,7 +60,7 @@ def test_rays_whose_stack_leaves_lds_give_the_same_frame(dataset, monkeypatch):
     r, image = render_config(dataset, 3, 256, 144)
     deepest = r.traversal_statistics(True)["deepest_stack"]
     visibility = r.read_visibility()
-    cpu, _, _ = oracle_render(r, visibility=visibility, math_mode=1)
+    cpu, _, _ = oracle_render(r, visibility=visibility, math_mode=renderer.ORACLE_MATH_MODE[r.arithmetic])
     r.close()
     monkeypatch.setenv("VKR_WIDE_STACK_LDS", "4")
     r, spilled = render_config(dataset, 3, 256, 144)
@@ -104,10 +104,11 @@ def test_device_sah_tree_is_as_good_as_the_host_tree_and_wide_visits_are_few(big
     assert per_ray["lbvh_device"][0] > per_ray["sah_device"][0], per_ray
 
 
-def test_full_size_config_3_is_bit_exact(big_dataset):
-    """BASELINE config 3 at its full size (1920x1080, 4 lights, 4 spp per technique, shadow rays)"""
-    r, image = render_config(big_dataset, 3, 1920, 1080, frames_in_flight=2)
-    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+def test_full_size_config_3_is_bit_exact_in_the_polynomial_mode_too(big_dataset):
+    """BASELINE config 3 at its full size (1920x1080, 4 lights, 4 spp per technique, shadow rays);
+    tests/test_gpu_full_size.py has the libm mode"""
+    r, image = render_config(big_dataset, 3, 1920, 1080, frames_in_flight=2, arithmetic="exact")
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=renderer.ORACLE_MATH_MODE[r.arithmetic])
     r.close()
     stats = compare(image, cpu)
     assert stats["bit_exact"] and stats["nan"] == 0, stats
@@ -123,7 +124,7 @@ def test_bands_of_full_size_config_4_are_bit_exact(big_dataset):
     inputs = r.host_inputs(r.read_visibility())
     bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
     frame = oracle.make_frame(inputs, r.oracle_settings(), bvh)
-    oracle.set_math_mode(1)
+    oracle.set_math_mode(renderer.ORACLE_MATH_MODE[r.arithmetic])
     try:
         for y0 in (600, 1272, 2000):
             cpu = oracle.shade(frame, y0, y0 + 16)
@@ -226,6 +227,101 @@ def test_slab_exchange_with_one_rank_reproduces_the_frame(dataset, slab_format):
         assert np.array_equal(out, expected[3.0])
     stages = r.exchange_ms()
     assert stages is not None and all(ms >= 0.0 for ms in stages)
+    r.destroy_exchange()
+    r.close()
+
+
+@pytest.mark.parametrize("slab_format", ["rgba32f", "rgb8"])
+@pytest.mark.parametrize("rank_count, tile_size, frames_in_flight", [(2, 32, 3), (2, 16, 2), (4, 64, 3), (3, 32, 1)])
+def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_count, tile_size, frames_in_flight, slab_format):
+    """render_and_exchange_frame() with rank_count > 1 on ONE device: every rank is an application_t of its
+    own, driven by its own thread; the collective is the local one (device-to-device copies with a
+    host-side rendezvous, create_local_slab_exchange) where RCCL would refuse two ranks on one
+    device.  Tile schedule, slabs, buffer sets, the overlap with the next frames, event order and
+    scatter are the code that runs on N GPUs.  The VERY FIRST frame of every fresh pass goes into a
+    buffer of its own and must be complete (the pass picks the stream of a frame; the exchange used to
+    guess it and guessed wrong for the first frame), and so must every later one, on every rank."""
+    import threading
+    width, height = 200, 120
+    single, _ = render_config(dataset, 3, width, height)
+    exposures = [1.0, 2.0, 3.0, 2.0, 1.0, 3.0, 2.0]
+    expected = {}
+    for exposure in sorted(set(exposures)):
+        single.app.render_settings.exposure_factor = exposure
+        single.render()
+        expected[exposure] = single.read_radiance() if slab_format == "rgba32f" else single.read_encoded(False, 0)
+    single.close()
+    lib = renderer.capi.load()
+    group = lib.create_local_slab_group(rank_count)
+    assert group
+    bytes_per_pixel = 16 if slab_format == "rgba32f" else 4
+    results, errors = {}, []
+
+    def run_rank(rank):
+        try:
+            r = renderer.Renderer(frames_in_flight=frames_in_flight)
+            renderer.setup_config(r, 3, dataset, width=width, height=height, acceleration_structure="sah_device")
+            r.set_tiles(tile_size, rank, rank_count, slab_layout=True)
+            r.create_targets()
+            r.create_pass()
+            r.render_visibility()
+            r.create_local_exchange(group, slab_format)
+            assert r.exchange.rank == rank and r.exchange.rank_count == rank_count
+            frames = [DeviceBuffer(width * height * bytes_per_pixel) for _ in exposures]
+            for exposure, frame in zip(exposures, frames):  # no synchronisation in between; the first call is the first frame of the pass
+                r.app.render_settings.exposure_factor = exposure
+                r.render_and_exchange(frame.ptr.value)
+            r.finish_exchange()
+            r.sync()
+            results[rank] = [frame.download((height, width, 4), np.float32 if slab_format == "rgba32f" else np.uint8) for frame in frames]
+            for frame in frames:
+                frame.free()
+            r.destroy_exchange()
+            r.close()
+        except Exception as error:  # (a rank that dies would leave its peers in the rendezvous)
+            errors.append((rank, repr(error)))
+            raise
+
+    threads = [threading.Thread(target=run_rank, args=(rank,)) for rank in range(rank_count)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank is stuck in the exchange"
+    lib.destroy_local_slab_group(group)
+    for rank in range(rank_count):
+        for index, exposure in enumerate(exposures):
+            got, want = results[rank][index], expected[exposure]
+            same = np.array_equal(got.view(np.uint32), want.view(np.uint32)) if slab_format == "rgba32f" else np.array_equal(got, want)
+            assert same, (rank, index, exposure, int((got != want).any(axis=-1).sum()))
+
+
+def test_exchange_through_a_gather_function_of_the_caller(dataset):
+    """create_slab_exchange_with_gather(): the collective is a function pointer; here a Python callback that
+    copies the one rank's slab (hipMemcpyAsync on the stream it is given)"""
+    r, _ = render_config(dataset, 3, 200, 120, frames_in_flight=2)
+    r.render()
+    expected = r.read_radiance()
+    r.set_tiles(32, 0, 1, slab_layout=True)
+    hip = C.CDLL("libamdhip64.so")
+    calls = []
+    GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+    @GATHER
+    def gather(context, rank, buffer_set, send, gathered, send_bytes, stream):
+        calls.append((rank, buffer_set, send_bytes))
+        return hip.hipMemcpyAsync(C.c_void_p(gathered), C.c_void_p(send), C.c_size_t(send_bytes), 3, C.c_void_p(stream))
+
+    exchange = renderer.capi.SlabExchange()
+    assert r.lib.create_slab_exchange_with_gather(C.byref(exchange), C.byref(r.app), C.cast(gather, C.c_void_p), None, 0) == 0
+    r.exchange = exchange
+    for _ in range(4):
+        r.render_and_exchange(None)
+    r.finish_exchange()
+    assert np.array_equal(r.read_radiance().view(np.uint32), expected.view(np.uint32))
+    assert len(calls) == 4 and [c[1] for c in calls] == [0, 1, 0, 1] and calls[0][2] == r.slab_pixel_count(0) * 16
+    assert r.lib.create_slab_exchange_with_gather(C.byref(renderer.capi.SlabExchange()), C.byref(r.app), None, None, 0) == 1
     r.destroy_exchange()
     r.close()
 

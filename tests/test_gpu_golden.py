@@ -27,8 +27,10 @@ def frames():
     return np.load(os.path.join(GOLDEN, "frames.npz"))
 
 
-def render_case(case, dataset, fast_math, width=golden_cases.WIDTH, height=golden_cases.HEIGHT, frames_in_flight=1):
-    r = renderer.Renderer(fast_math=fast_math, frames_in_flight=frames_in_flight)
+def render_case(case, dataset, arithmetic, width=golden_cases.WIDTH, height=golden_cases.HEIGHT, frames_in_flight=1):
+    if isinstance(arithmetic, bool):
+        arithmetic = "fast" if arithmetic else "libm"
+    r = renderer.Renderer(arithmetic=arithmetic, frames_in_flight=frames_in_flight)
     golden_cases.apply_case(r, case, dataset, width, height)
     r.create_targets()
     r.create_pass()
@@ -41,11 +43,27 @@ LINEAR_CASES = [c for c in golden_cases.FRAME_CASES if c.get("output_linear_rgb"
 
 
 @pytest.mark.parametrize("case", LINEAR_CASES, ids=[c["key"] for c in LINEAR_CASES])
+def test_libm_mode_reproduces_the_frames_of_the_reference_shader_bit_for_bit(case, golden_dataset, frames):
+    """The golden frames are outputs of the reference's own GLSL (compiled as C++ by
+    oracle/ref_stubs, tests/golden/make_golden.py) with this image's C library behind atan / acos /
+    sin / cos / pow.  The libm arithmetic mode of the kernels evaluates the same operations: every
+    pixel of every variant - the fragile ones too (Hart's biquadratic warp, Arvo's projected
+    solid angle sampler, the error displays) - must come out identical."""
+    r, image = render_case(case, golden_dataset, "libm")
+    r.close()
+    golden = frames[case["key"]].astype(np.float32)
+    stats = compare(image, golden)
+    print(case["key"], stats)
+    assert stats["nan"] == 0
+    assert np.array_equal(image[..., :3].view(np.uint32), golden[..., :3].view(np.uint32)), stats
+
+
+@pytest.mark.parametrize("case", LINEAR_CASES, ids=[c["key"] for c in LINEAR_CASES])
 @pytest.mark.parametrize("fast_math", [False, True], ids=["exact", "fast"])
 def test_golden_frames_of_the_reference_shader(case, fast_math, golden_dataset, frames):
-    """The golden frames were computed with libm transcendentals; the kernels use
-    their own polynomials, so the comparison is by tolerance, not by bits."""
-    r, image = render_case(case, golden_dataset, fast_math)
+    """The golden frames were computed with libm transcendentals; the polynomial and the fast
+    mode use their own forms, so their comparison is by tolerance, not by bits."""
+    r, image = render_case(case, golden_dataset, "fast" if fast_math else "exact")
     r.close()
     stats = compare(image, frames[case["key"]])
     print(case["key"], "fast" if fast_math else "exact", stats)
@@ -83,9 +101,10 @@ def test_golden_frames_of_the_reference_shader(case, fast_math, golden_dataset, 
 
 
 @pytest.mark.parametrize("case", LINEAR_CASES, ids=[c["key"] for c in LINEAR_CASES])
-def test_exact_mode_equals_oracle_bit_for_bit(case, golden_dataset):
-    r, image = render_case(case, golden_dataset, False, 96, 64)
-    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+@pytest.mark.parametrize("arithmetic", ["libm", "exact"])
+def test_ieee_modes_equal_their_oracle_bit_for_bit(case, arithmetic, golden_dataset):
+    r, image = render_case(case, golden_dataset, arithmetic, 96, 64)
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=renderer.ORACLE_MATH_MODE[arithmetic])
     r.close()
     stats = compare(image, cpu)
     assert stats["bit_exact"], stats

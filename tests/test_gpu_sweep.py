@@ -1,7 +1,9 @@
 """Randomised parity sweep: every axis of the kernel variant space (strategy, MIS heuristic,
 technique, light count, polygon sizes 3..7, sample count, shadow rays, light display, error
-display, roughness factor, camera) is drawn from a seeded generator and the exact-mode
-frame must equal the oracle's polynomial-mode frame bit for bit.  Plus the edge cases of
+display, roughness factor, camera) is drawn from a seeded generator and the frame must equal
+the oracle's bit for bit - in the libm arithmetic mode (the default of the pass) against the oracle's
+libm mode, which is the arithmetic pinned against the reference shader, and in the polynomial
+("exact") mode against the oracle's polynomial mode.  Plus the edge cases of
 the domain: no lights, lights below the horizon of every pixel, grazing and huge lights,
 many lights, many samples, a frame smaller than a workgroup."""
 import ctypes as C
@@ -69,8 +71,8 @@ def random_case(seed):
                             vertical_fov=rng.uniform(0.25, 0.4) * math.pi))
 
 
-def render_and_compare(case, dataset, width=WIDTH, height=HEIGHT, inline_rays=False, frames_in_flight=1):
-    r = renderer.Renderer(inline_rays=inline_rays, frames_in_flight=frames_in_flight)
+def render_and_compare(case, dataset, width=WIDTH, height=HEIGHT, inline_rays=False, frames_in_flight=1, arithmetic="libm"):
+    r = renderer.Renderer(inline_rays=inline_rays, frames_in_flight=frames_in_flight, arithmetic=arithmetic)
     r.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=True)
     r.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
     r.load_noise_table("white")
@@ -90,7 +92,7 @@ def render_and_compare(case, dataset, width=WIDTH, height=HEIGHT, inline_rays=Fa
     for _ in range(frames_in_flight + 1 if frames_in_flight > 1 else 1):  # several frames so that all contexts are used
         r.render()
     image = r.read_radiance()
-    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=renderer.ORACLE_MATH_MODE[arithmetic])
     rays = r.last_ray_count()
     r.close()
     return compare(image, cpu), image, rays
@@ -98,10 +100,11 @@ def render_and_compare(case, dataset, width=WIDTH, height=HEIGHT, inline_rays=Fa
 
 # VKR_SWEEP_SEEDS=n widens the sweeps (round 1 ran 600 seeds here and 200 with textures once, round 2 - LDS polygon
 # tables, the short exact division, the four-wide tree - 1200 and 400 with the final kernels: all 1608 bit-exact)
+@pytest.mark.parametrize("arithmetic", ["libm", "exact"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_SWEEP_SEEDS", "48"))))
-def test_random_configuration_is_bit_exact(seed, dataset):
+def test_random_configuration_is_bit_exact(seed, arithmetic, dataset):
     case = random_case(seed)
-    stats, image, _ = render_and_compare(case, dataset, inline_rays=(seed % 5 == 4), frames_in_flight=1 + seed % 4)
+    stats, image, _ = render_and_compare(case, dataset, inline_rays=(seed % 5 == 4), frames_in_flight=1 + seed % 4, arithmetic=arithmetic)
     summary = {k: case[k] for k in ("strategy", "technique", "heuristic", "samples", "rays", "show_lights", "error_display")}
     summary["vertex_counts"] = [len(l["vertices_plane_space"]) for l in case["lights"]]
     assert stats["nan"] == 0 and stats["bit_exact"], (summary, stats)
@@ -130,8 +133,9 @@ def test_grazing_and_huge_lights(dataset):
         synthetic.light_spec(synthetic.QUAD, (-12.0, 12.0, 4.0), (math.pi, 0.0, 0.0), (40, 40, 40), (24.0, 24.0)),
     ]
     for strategy, heuristic in ((0, 0), (3, 3), (3, 4), (2, 0), (4, 0)):
-        stats, _, _ = render_and_compare(dict(lights=lights, strategy=strategy, heuristic=heuristic, samples=2, rays=True), dataset)
-        assert stats["nan"] == 0 and stats["bit_exact"], (strategy, heuristic, stats)
+        for arithmetic in ("libm", "exact"):
+            stats, _, _ = render_and_compare(dict(lights=lights, strategy=strategy, heuristic=heuristic, samples=2, rays=True), dataset, arithmetic=arithmetic)
+            assert stats["nan"] == 0 and stats["bit_exact"], (strategy, heuristic, arithmetic, stats)
 
 
 def test_many_lights_and_many_samples(dataset):
@@ -156,8 +160,9 @@ def textured_dataset(tmp_path_factory):
     return synthetic.write_dataset(str(tmp_path_factory.mktemp("sweep_textured")), **golden_cases.TEXTURED_DATASET)
 
 
+@pytest.mark.parametrize("arithmetic", ["libm", "exact"])
 @pytest.mark.parametrize("seed", range(100, 100 + max(16, int(os.environ.get("VKR_SWEEP_SEEDS", "48")) // 3)))
-def test_random_configuration_with_textures_is_bit_exact(seed, dataset, textured_dataset):
+def test_random_configuration_with_textures_is_bit_exact(seed, arithmetic, dataset, textured_dataset):
     """The sweep once more with a random texturing technique per light (area, light probe, IES
     profile or none) and, for every second seed, textured materials."""
     rng = np.random.default_rng(seed)
@@ -169,7 +174,7 @@ def test_random_configuration_with_textures_is_bit_exact(seed, dataset, textured
         if technique != "none":
             light["texturing_technique"] = technique
             light["texture_file_path"] = data["light_textures"][names[technique] if rng.random() < 0.8 else "portal_rgb16"]
-    stats, image, _ = render_and_compare(case, data, frames_in_flight=1 + seed % 3)
+    stats, image, _ = render_and_compare(case, data, frames_in_flight=1 + seed % 3, arithmetic=arithmetic)
     summary = {k: case[k] for k in ("strategy", "technique", "heuristic", "samples", "rays", "show_lights", "error_display")}
     summary["texturing"] = [l.get("texturing_technique", "none") for l in case["lights"]]
     assert stats["nan"] == 0 and stats["bit_exact"], (summary, stats)

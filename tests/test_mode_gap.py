@@ -1,0 +1,33 @@
+"""The link between the two arithmetics of the CPU oracle at BASELINE size (CPU only).
+
+Math mode 0 (libm) equals the reference's shader source compiled as C++ bit for bit
+(tests/test_reference_live.py, tests/test_oracle_golden.py) and is what the kernels' default "libm"
+mode reproduces bit for bit (tests/test_gpu_full_size.py).  Math mode 1 (polynomial transcendentals)
+is what the kernels' cheaper "exact" mode reproduces bit for bit.  This test states how far the two
+are apart on the full 1920x1080 frames: the tolerance of BASELINE.json (RMSE <= 1e-4 on
+exposure-scaled linear radiance) holds over all pixels that do not sit on a discontinuity of the
+shader, and every pixel that does is one of the classified kinds of tests/helpers.py (the shader's NaN
+guard, a shadow-ray silhouette) - an unclassified outlier fails the test."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "tools"))
+
+RMSE_TOLERANCE = 1.0e-4
+# most pixels on a discontinuity that a 1920x1080 frame may have (config 3: 20 guard pixels of 2 073 600)
+MAX_OUTLIERS = 48
+
+
+@pytest.mark.parametrize("config", [2, 3])
+def test_polynomial_mode_against_the_reference_pinned_libm_mode_at_full_size(config, big_dataset):
+    import mode_gap
+    stats = mode_gap.gap(config, 1920, 1080, big_dataset)
+    print(config, stats)
+    assert stats["other_pixels"] == 0, stats
+    assert stats["rmse_without_outliers"] <= RMSE_TOLERANCE, stats
+    assert stats["pixels_over_threshold"] <= MAX_OUTLIERS, stats
+    if config == 2:
+        # one light, one sample: no sliver sector is hit, the plain tolerance holds
+        assert stats["rmse"] <= RMSE_TOLERANCE, stats

@@ -187,7 +187,7 @@ def test_textured_frame_on_the_gpu_equals_the_oracle(case, textured_dataset):
     r.render()
     r.render()
     image = r.read_radiance()
-    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=1)
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=renderer.ORACLE_MATH_MODE[r.arithmetic])
     assert r.app.shading_pass.last_frame_in_flight == 0  # one per-pixel material buffer: one frame at a time
     r.close()
     stats = compare(image, cpu)
@@ -303,11 +303,12 @@ def test_light_textured_frame_matches_reference_shader(case, plain_dataset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fast", [False, True], ids=["exact", "fast"])
+@pytest.mark.parametrize("arithmetic", ["libm", "exact", "fast"])
 @pytest.mark.parametrize("case", golden_cases.LIGHT_TEXTURE_CASES, ids=[c["key"] for c in golden_cases.LIGHT_TEXTURE_CASES])
-def test_light_textured_frame_on_the_gpu_equals_the_oracle(case, fast, plain_dataset):
+def test_light_textured_frame_on_the_gpu_equals_the_oracle(case, arithmetic, plain_dataset):
     from helpers import compare, oracle_render
-    r = renderer.Renderer(frames_in_flight=2, fast_math=fast)
+    fast = arithmetic == "fast"
+    r = renderer.Renderer(frames_in_flight=2, arithmetic=arithmetic)
     golden_cases.apply_case(r, case, plain_dataset, 96, 64)
     r.create_targets()
     r.create_pass()
@@ -315,7 +316,7 @@ def test_light_textured_frame_on_the_gpu_equals_the_oracle(case, fast, plain_dat
     r.render()
     r.render()
     image = r.read_radiance()
-    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=0 if fast else 1)
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=renderer.ORACLE_MATH_MODE[r.arithmetic])
     r.close()
     stats = compare(image, cpu)
     if fast:

@@ -138,7 +138,8 @@ class ShadingPass(C.Structure):
     _fields_ = [("use_ray_tracing", C.c_uint32), ("variant", C.c_int32), ("max_polygon_vertex_count", C.c_uint32),
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t), ("constants_ring", C.c_void_p),
                 ("arithmetic_mode", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("last_frame_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("pixel_materials", C.c_void_p), ("pixel_materials_size", C.c_size_t), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
-                ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32), ("last_frame_traced_rays", C.c_uint32), ("binary_traversal", C.c_int32)]
+                ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32), ("last_frame_traced_rays", C.c_uint32), ("binary_traversal", C.c_int32),
+                ("wait_before_next_frame", C.c_void_p), ("last_frame_stream", C.c_void_p)]
 
 
 class Application(C.Structure):
@@ -167,7 +168,7 @@ class SlabExchangeId(C.Structure):
 
 
 class SlabExchange(C.Structure):
-    _fields_ = [("binding", C.c_void_p), ("rank", C.c_uint32), ("rank_count", C.c_uint32), ("format", C.c_int32),
+    _fields_ = [("binding", C.c_void_p), ("gather", C.c_void_p), ("gather_context", C.c_void_p), ("rank", C.c_uint32), ("rank_count", C.c_uint32), ("format", C.c_int32),
                 ("slab_pixel_count", C.c_uint64), ("send_bytes", C.c_uint64), ("set_count", C.c_uint32), ("next_set", C.c_uint32),
                 ("slab_radiance", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("send", C.c_void_p * MAX_FRAMES_IN_FLIGHT),
                 ("gathered", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("stream", C.c_void_p),
@@ -258,6 +259,10 @@ SIGNATURES = {
     "take_screenshot": (C.c_int, [P(Application), C.c_char_p, C.c_char_p]),
     "get_slab_exchange_id": (C.c_int, [P(SlabExchangeId)]),
     "create_slab_exchange": (C.c_int, [P(SlabExchange), P(Application), P(SlabExchangeId), C.c_int]),
+    "create_slab_exchange_with_gather": (C.c_int, [P(SlabExchange), P(Application), C.c_void_p, C.c_void_p, C.c_int]),
+    "create_local_slab_group": (C.c_void_p, [C.c_uint32]),
+    "destroy_local_slab_group": (None, [C.c_void_p]),
+    "create_local_slab_exchange": (C.c_int, [P(SlabExchange), P(Application), C.c_void_p, C.c_int]),
     "destroy_slab_exchange": (None, [P(SlabExchange), P(Application)]),
     "render_and_exchange_frame": (C.c_int, [P(Application), P(SlabExchange), C.c_void_p]),
     "all_gather_slabs": (C.c_int, [P(SlabExchange), C.c_void_p, C.c_void_p, C.c_void_p]),

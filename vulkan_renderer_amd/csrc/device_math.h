@@ -76,9 +76,24 @@ VKR_DEV float opaque(float x) { asm("" : "+v"(x)); return x; }
 // |a| >= 2^-103, |a / b| in [2^-126, 2^96) (tests/test_gpu_arithmetic.py pins that).  The operands
 // here are radiances, densities, areas and lengths of O(1e-10 ... 1e10); like square_root below
 // this gives up the last decades of the exponent range, nothing else.
+// The IEEE quotient over the whole exponent range: the compiler's own expansion with the two
+// v_div_scale_f32 and the v_div_fmas_f32 (40 clocks).  For quotients that may leave the window of
+// divide() - the tangent of an angle next to pi / 2, n / d with d -> 0.
+VKR_DEV float divide_full_range(float a, float b) {
+#if VKR_FAST_MATH
+	return a * __builtin_amdgcn_rcpf(b);
+#else
+	return __fdiv_rn(a, b);
+#endif
+}
+#ifndef VKR_IEEE_DIVISION_EVERYWHERE
+#define VKR_IEEE_DIVISION_EVERYWHERE 0
+#endif
 VKR_DEV float divide(float a, float b) {
 #if VKR_FAST_MATH
 	return a * __builtin_amdgcn_rcpf(b);
+#elif VKR_IEEE_DIVISION_EVERYWHERE
+	return __fdiv_rn(a, b);
 #else
 	float r = __builtin_amdgcn_rcpf(b);
 	r = fmaf(fmaf(-b, r, 1.0f), r, r);
@@ -210,7 +225,8 @@ VKR_DEV float arctan(float t) {
 VKR_DEV float arctan_ratio_positive(float n, float d) {
 #if VKR_LIBM_MATH
 	// as the shader words it: the quotient, its arctangent, pi for a negative quotient
-	float tangent = divide(n, d);
+	// (the quotient of an angle next to pi / 2 is as large as floats get)
+	float tangent = divide_full_range(n, d);
 	return gm_atanf(tangent) + ((tangent < 0.0f) ? kPi : 0.0f);
 #endif
 	float a = fabsf(n), b = fabsf(d);

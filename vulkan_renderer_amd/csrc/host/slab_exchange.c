@@ -13,6 +13,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <pthread.h>
 
 typedef struct rccl_binding_s {
 	void* library;
@@ -39,7 +40,8 @@ static int bind_rccl(rccl_binding_t* binding) {
 	for (uint32_t i = 0; i != VKR_COUNT_OF(candidates) && !binding->library; ++i)
 		if (candidates[i] && candidates[i][0]) binding->library = dlopen(candidates[i], RTLD_NOW | RTLD_LOCAL);
 	if (!binding->library) {
-		printf("The multi-GPU exchange needs RCCL, but librccl.so.1 could not be loaded (%s). Set VKR_RCCL_LIBRARY to its path.\n", dlerror());
+		const char* reason = dlerror();
+		printf("The multi-GPU exchange needs RCCL, but librccl.so.1 could not be loaded (%s). Set VKR_RCCL_LIBRARY to its path.\n", reason ? reason : "no loader message");
 		return 1;
 	}
 	*(void**) &binding->get_unique_id = dlsym(binding->library, "ncclGetUniqueId");
@@ -70,17 +72,105 @@ int get_slab_exchange_id(slab_exchange_id_t* id) {
 	_Static_assert(sizeof(ncclUniqueId) <= sizeof(slab_exchange_id_t), "slab_exchange_id_t must hold an ncclUniqueId");
 	int failed = rccl_failed(&binding, binding.get_unique_id(&unique), "creating the rendezvous token");
 	if (!failed) memcpy(id->bytes, &unique, sizeof(unique));
-	/* (the library stays loaded: RCCL keeps the bootstrap thread of the token alive in it) */
+	/* (on success the library stays loaded: RCCL keeps the bootstrap thread of the token alive in it) */
+	if (failed) dlclose(binding.library);
 	return failed;
 }
+
+/* the default collective */
+static int gather_with_rccl(void* context, uint32_t rank, uint32_t set, const void* send, void* gathered, uint64_t send_bytes, void* stream) {
+	rccl_binding_t* binding = (rccl_binding_t*) context;
+	(void) rank; (void) set;
+	/* bytes, so that both formats share one call; slabs are multiples of 256 pixels, i.e. of 16 bytes */
+	return rccl_failed(binding, binding->all_gather(send, gathered, (size_t) send_bytes, ncclUint8, binding->communicator, (hipStream_t) stream), "gathering the slabs");
+}
+
+/* ---- ranks of one process: copies instead of a collective ------------------------------------ */
+
+struct local_slab_group_s {
+	uint32_t rank_count, joined;
+	pthread_mutex_t mutex;
+	pthread_cond_t changed;
+	/* rendezvous of the ranks' threads: `generation` advances when the last rank arrives */
+	uint32_t waiting;
+	uint64_t generation;
+	/* per rank: its exchange (buffer sets, `assembled` events) and, per set, the event behind the
+	   copies that rank queued */
+	slab_exchange_t* exchanges[64];
+	hipEvent_t copied[64][VKR_MAX_FRAMES_IN_FLIGHT];
+	uint64_t frames[64];
+};
+
+local_slab_group_t* create_local_slab_group(uint32_t rank_count) {
+	if (rank_count == 0 || rank_count > 64) {
+		printf("A local slab group has 1 to 64 ranks.\n");
+		return NULL;
+	}
+	local_slab_group_t* group = (local_slab_group_t*) calloc(1, sizeof(local_slab_group_t));
+	if (!group) return NULL;
+	group->rank_count = rank_count;
+	pthread_mutex_init(&group->mutex, NULL);
+	pthread_cond_init(&group->changed, NULL);
+	return group;
+}
+
+void destroy_local_slab_group(local_slab_group_t* group) {
+	if (!group) return;
+	for (uint32_t r = 0; r != 64; ++r)
+		for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT; ++b)
+			if (group->copied[r][b]) (void) hipEventDestroy(group->copied[r][b]);
+	pthread_cond_destroy(&group->changed);
+	pthread_mutex_destroy(&group->mutex);
+	free(group);
+}
+
+/* all ranks' threads meet here */
+static void local_group_rendezvous(local_slab_group_t* group) {
+	pthread_mutex_lock(&group->mutex);
+	uint64_t generation = group->generation;
+	if (++group->waiting == group->rank_count) {
+		group->waiting = 0;
+		++group->generation;
+		pthread_cond_broadcast(&group->changed);
+	}
+	else
+		while (group->generation == generation) pthread_cond_wait(&group->changed, &group->mutex);
+	pthread_mutex_unlock(&group->mutex);
+}
+
+/* Rank r copies its slab into slot r of every rank's `gathered` buffer of this set - behind that
+   rank's scatter of the frame that used the set before -, marks the copies with an event, meets the
+   other ranks' threads (so that their events exist) and makes its stream wait for their copies. */
+static int gather_with_copies(void* context, uint32_t rank, uint32_t set, const void* send, void* gathered, uint64_t send_bytes, void* stream) {
+	local_slab_group_t* group = (local_slab_group_t*) context;
+	hipStream_t s = (hipStream_t) stream;
+	(void) gathered;
+	int failed = 0;
+	int reused = group->frames[rank] >= group->exchanges[rank]->set_count;
+	for (uint32_t q = 0; q != group->rank_count && !failed; ++q) {
+		const slab_exchange_t* peer = group->exchanges[q];
+		if (reused && q != rank) failed = hip_failed(hipStreamWaitEvent(s, (hipEvent_t) peer->assembled[set], 0), "waiting for a peer's scatter");
+		if (!failed) failed = hip_failed(hipMemcpyAsync((uint8_t*) peer->gathered[set] + (size_t) rank * send_bytes, send, (size_t) send_bytes, hipMemcpyDeviceToDevice, s), "copying a slab to a peer");
+	}
+	if (!failed) failed = hip_failed(hipEventRecord(group->copied[rank][set], s), "marking the copies");
+	++group->frames[rank];
+	/* (a rank that failed still has to show up, or its peers would wait forever) */
+	local_group_rendezvous(group);
+	for (uint32_t q = 0; q != group->rank_count && !failed; ++q)
+		if (q != rank) failed = hip_failed(hipStreamWaitEvent(s, group->copied[q][set], 0), "waiting for a peer's copies");
+	return failed;
+}
+
 
 void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
 	/* frames in flight and collectives still use the buffers that are freed below */
 	if (exchange->stream) (void) hipStreamSynchronize((hipStream_t) exchange->stream);
-	if (app && app->shading_pass.wavefront) (void) wait_for_device(&app->device);
+	/* (also frames without the wavefront pipeline - inline rays on device->stream - write the slabs) */
+	if (app) (void) wait_for_device(&app->device);
 	rccl_binding_t* binding = (rccl_binding_t*) exchange->binding;
 	if (binding) {
 		if (binding->communicator) (void) binding->comm_destroy(binding->communicator);
+		if (binding->library) dlclose(binding->library);
 		free(binding);
 	}
 	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT; ++b) {
@@ -96,12 +186,13 @@ void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
 	memset(exchange, 0, sizeof(*exchange));
 }
 
-int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const slab_exchange_id_t* id, slab_format_t format) {
+/* Everything of an exchange but its collective: ranks, format, buffer sets, stream, events */
+static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app, slab_format_t format) {
 	memset(exchange, 0, sizeof(*exchange));
 	const tile_schedule_t* schedule = &app->tile_schedule;
 	uint32_t rank_count = schedule->rank_count > 1 ? schedule->rank_count : 1;
 	if ((int) format < 0 || format >= slab_format_count || schedule->rank >= rank_count || (rank_count == 1 && !schedule->slab_layout)) {
-		printf("create_slab_exchange() needs a slab format, a rank below the rank count and, with a single rank, tile_schedule.slab_layout.\n");
+		printf("A slab exchange needs a slab format, a rank below the rank count and, with a single rank, tile_schedule.slab_layout.\n");
 		return 1;
 	}
 	exchange->rank = schedule->rank;
@@ -115,19 +206,6 @@ int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const sl
 	if (sets > VKR_MAX_FRAMES_IN_FLIGHT) sets = VKR_MAX_FRAMES_IN_FLIGHT;
 	exchange->set_count = sets;
 	if (hip_failed(hipSetDevice(app->device.hip_device), "selecting the device")) return 1;
-	rccl_binding_t* binding = (rccl_binding_t*) calloc(1, sizeof(rccl_binding_t));
-	exchange->binding = binding;
-	if (!binding || bind_rccl(binding)) {
-		destroy_slab_exchange(exchange, app);
-		return 1;
-	}
-	ncclUniqueId unique;
-	memcpy(&unique, id->bytes, sizeof(unique));
-	if (rccl_failed(binding, binding->comm_init_rank(&binding->communicator, (int) rank_count, unique, (int) exchange->rank), "joining the communicator")) {
-		binding->communicator = NULL;
-		destroy_slab_exchange(exchange, app);
-		return 1;
-	}
 	int failed = hip_failed(hipStreamCreateWithFlags((hipStream_t*) &exchange->stream, hipStreamNonBlocking), "creating the exchange stream");
 	for (uint32_t b = 0; b != sets && !failed; ++b) {
 		failed = hip_failed(hipMalloc(&exchange->slab_radiance[b], exchange->slab_pixel_count * 16u), "allocating a slab")
@@ -139,8 +217,10 @@ int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const sl
 		for (uint32_t i = 0; i != 5 && !failed; ++i)
 			failed = hip_failed(hipEventCreate((hipEvent_t*) &exchange->timing[b][i]), "creating timing events");
 		/* padding slots of the last tile row / column are never written by the kernels */
-		if (!failed) failed = hip_failed(hipMemset(exchange->slab_radiance[b], 0, exchange->slab_pixel_count * 16u), "clearing a slab");
+		if (!failed) failed = hip_failed(hipMemsetAsync(exchange->slab_radiance[b], 0, exchange->slab_pixel_count * 16u, (hipStream_t) exchange->stream), "clearing a slab");
 	}
+	/* the frames that write the slabs run on non-blocking streams, which nothing orders behind the clears */
+	if (!failed) failed = hip_failed(hipStreamSynchronize((hipStream_t) exchange->stream), "clearing the slabs");
 	if (failed) {
 		destroy_slab_exchange(exchange, app);
 		return 1;
@@ -148,18 +228,72 @@ int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const sl
 	return 0;
 }
 
-int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered, void* stream) {
-	rccl_binding_t* binding = (rccl_binding_t*) exchange->binding;
-	if (!binding || !binding->communicator) {
-		printf("all_gather_slabs() needs an exchange made by create_slab_exchange().\n");
+int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const slab_exchange_id_t* id, slab_format_t format) {
+	if (create_exchange_buffers(exchange, app, format)) return 1;
+	rccl_binding_t* binding = (rccl_binding_t*) calloc(1, sizeof(rccl_binding_t));
+	exchange->binding = binding;
+	if (!binding || bind_rccl(binding)) {
+		destroy_slab_exchange(exchange, app);
 		return 1;
 	}
-	/* bytes, so that both formats share one call; slabs are multiples of 256 pixels, i.e. of 16 bytes */
-	return rccl_failed(binding, binding->all_gather(send, gathered, (size_t) exchange->send_bytes, ncclUint8, binding->communicator, (hipStream_t) stream), "gathering the slabs");
+	ncclUniqueId unique;
+	memcpy(&unique, id->bytes, sizeof(unique));
+	if (rccl_failed(binding, binding->comm_init_rank(&binding->communicator, (int) exchange->rank_count, unique, (int) exchange->rank), "joining the communicator")) {
+		binding->communicator = NULL;
+		destroy_slab_exchange(exchange, app);
+		return 1;
+	}
+	exchange->gather = gather_with_rccl;
+	exchange->gather_context = binding;
+	return 0;
+}
+
+int create_slab_exchange_with_gather(slab_exchange_t* exchange, application_t* app, slab_gather_function_t gather, void* gather_context, slab_format_t format) {
+	if (!gather) {
+		printf("create_slab_exchange_with_gather() needs a gather function.\n");
+		memset(exchange, 0, sizeof(*exchange));
+		return 1;
+	}
+	if (create_exchange_buffers(exchange, app, format)) return 1;
+	exchange->gather = gather;
+	exchange->gather_context = gather_context;
+	return 0;
+}
+
+int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, local_slab_group_t* group, slab_format_t format) {
+	uint32_t rank_count = app->tile_schedule.rank_count > 1 ? app->tile_schedule.rank_count : 1;
+	if (!group || group->rank_count != rank_count) {
+		printf("create_local_slab_exchange() needs a group with as many ranks as the tile schedule has.\n");
+		memset(exchange, 0, sizeof(*exchange));
+		return 1;
+	}
+	int failed = create_slab_exchange_with_gather(exchange, app, gather_with_copies, group, format);
+	uint32_t rank = app->tile_schedule.rank;
+	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++b)
+		if (!group->copied[rank][b]) failed = hip_failed(hipEventCreateWithFlags(&group->copied[rank][b], hipEventDisableTiming), "creating events");
+	if (!failed) {
+		group->exchanges[rank] = exchange;
+		group->frames[rank] = 0;
+	}
+	/* every rank's buffers and events must exist before the first frame copies into them
+	   (a rank that failed still shows up; its peers find out at their first frame) */
+	local_group_rendezvous(group);
+	if (failed && exchange->stream) destroy_slab_exchange(exchange, app);
+	return failed;
+}
+
+int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered, void* stream) {
+	if (!exchange->gather) {
+		printf("all_gather_slabs() needs an exchange made by one of the create_*_slab_exchange() functions.\n");
+		return 1;
+	}
+	uint32_t set = 0;
+	for (uint32_t b = 0; b != exchange->set_count; ++b) if (exchange->gathered[b] == gathered) set = b;
+	return exchange->gather(exchange->gather_context, exchange->rank, set, send, gathered, exchange->send_bytes, stream);
 }
 
 int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, void* out_frame) {
-	if (!exchange->binding || exchange->slab_pixel_count != get_slab_pixel_count(app, 0)
+	if (!exchange->gather || exchange->slab_pixel_count != get_slab_pixel_count(app, 0)
 		|| exchange->rank != app->tile_schedule.rank || exchange->rank_count != (app->tile_schedule.rank_count > 1 ? app->tile_schedule.rank_count : 1))
 	{
 		printf("The slab exchange does not match the tile schedule or extent. Recreate it.\n");
@@ -171,23 +305,27 @@ int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, voi
 	int reused = exchange->frame_counter >= exchange->set_count;
 	++exchange->frame_counter;
 	hipStream_t exchange_stream = (hipStream_t) exchange->stream;
-	/* the stream this frame will run on: the set's previous frame must have left the buffers */
-	hipStream_t frame_stream = (hipStream_t) get_next_frame_stream(app);
-	if (reused && hip_failed(hipStreamWaitEvent(frame_stream, (hipEvent_t) exchange->assembled[b], 0), "waiting for the buffers of an earlier frame")) return 1;
-	/* (an untimed frame leaves the set's timing events alone: they keep the last timed frame) */
-	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][0], frame_stream);
+	/* The set's previous frame must have left the buffers before this frame writes them.  Which stream
+	   the frame takes - device->stream or one of the frame streams - is the pass's decision (it depends
+	   on the ray mode, the scene, the pipeline depth, and differs for the first frame of a fresh pass), so
+	   the pass itself waits for the event, on the stream it picks, before its first kernel. */
+	if (reused) app->shading_pass.wait_before_next_frame = exchange->assembled[b];
+	/* (an untimed frame leaves the set's timing events alone: they keep the last timed frame; the
+	   start mark goes to the stream the frame is expected on, which only the very first frame may miss) */
+	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][0], (hipStream_t) get_next_frame_stream(app));
 	int failed = exchange->format == slab_format_rgb8
 		? render_shading_pass_encoded(app, exchange->slab_radiance[b], exchange->send[b])
 		: render_shading_pass(app, exchange->slab_radiance[b]);
+	app->shading_pass.wait_before_next_frame = NULL;
 	if (failed) return 1;
-	/* (render_shading_pass falls back to device->stream when it cannot pipeline: ask again) */
-	hipStream_t used_stream = app->shading_pass.last_frame_in_flight ? frame_stream : (hipStream_t) app->device.stream;
+	/* ... and the stream it did pick carries the frame */
+	hipStream_t used_stream = (hipStream_t) app->shading_pass.last_frame_stream;
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][1], used_stream);
 	if (hip_failed(hipEventRecord((hipEvent_t) exchange->rendered[b], used_stream), "marking the frame")
 		|| hip_failed(hipStreamWaitEvent(exchange_stream, (hipEvent_t) exchange->rendered[b], 0), "waiting for the frame"))
 		return 1;
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][2], exchange_stream);
-	if (all_gather_slabs(exchange, exchange->send[b], exchange->gathered[b], exchange_stream)) return 1;
+	if (exchange->gather(exchange->gather_context, exchange->rank, b, exchange->send[b], exchange->gathered[b], exchange->send_bytes, exchange_stream)) return 1;
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][3], exchange_stream);
 	void* target = out_frame ? out_frame : (exchange->format == slab_format_rgba32f ? app->render_targets.radiance : app->render_targets.encoded);
 	if (vkr_assemble_slabs_on_stream(app, exchange->gathered[b], target, (int) exchange->format, exchange_stream)) return 1;

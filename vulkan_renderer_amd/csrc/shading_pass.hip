@@ -229,7 +229,11 @@ static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t in_l
 	return 0;
 }
 
-static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
+// `stream`: the stream the frame that uses these buffers is about to run on.  The counters are cleared
+// THERE: the frame streams are non-blocking, i.e. not ordered behind a hipMemset on the null stream, and
+// a frame that started before that memset landed had its queue sizes reset under its feet (found in
+// round 3: the first frame of a fresh context lost a few rays).
+static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count, hipStream_t stream) {
 	uint32_t max_codes = max_terms + light_count + 2;
 	if (w->codes && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
 	free_wavefront_buffers(w);
@@ -249,7 +253,7 @@ static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_
 		|| hipMalloc(&w->base_color, sizeof(float4) * (size_t) thread_count) != hipSuccess
 		|| hipMalloc(&w->ray_queue, (size_t) w->queue_capacity * kRayQueueCount * 32) != hipSuccess
 		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess
-		|| hipMemset(w->ray_queue_size, 0, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess)
+		|| hipMemsetAsync(w->ray_queue_size, 0, sizeof(uint32_t) * 2 * kRayCounterCount, stream) != hipSuccess)
 	{
 		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", (terms * 56.0 + (double) max_codes * thread_count) / 1048576.0);
 		free_wavefront_buffers(w);
@@ -489,6 +493,7 @@ static int create_timing_ring(shading_pass_t* pass) {
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	int32_t arithmetic_mode = pass->arithmetic_mode, inline_rays = pass->inline_rays, binary_traversal = pass->binary_traversal;
+	void* wait_before_next_frame = pass->wait_before_next_frame;
 	uint32_t timing_stride = pass->timing_stride, frames_in_flight = pass->frames_in_flight;
 	memset(pass, 0, sizeof(*pass));
 	pass->timing_stride = timing_stride;
@@ -499,6 +504,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 		return 1;
 	}
 	pass->arithmetic_mode = arithmetic_mode;
+	pass->wait_before_next_frame = wait_before_next_frame;
 	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->binary_traversal = binary_traversal ? 1 : 0;
 	pass->variant = -1;
@@ -704,7 +710,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			}
 		}
 		trace_blocks = compute_units * (frames->trace_waves ? frames->trace_waves : (max_terms >= 8u ? 8u : 4u));
-		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count)) return 1;
+		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count, stream)) return 1;
 		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
 		const wavefront_buffers* w = &frame->buffers;
 		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden; p.base_color = w->base_color;
@@ -743,6 +749,11 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		}
 		p.light_texture_descriptors = (const uint4*) app->light_textures.descriptors;
 		p.light_texels = (const float4*) app->light_textures.texels;
+	}
+	pass->last_frame_stream = stream;
+	if (pass->wait_before_next_frame) {
+		if (hip_failed(hipStreamWaitEvent(stream, (hipEvent_t) pass->wait_before_next_frame, 0), "waiting for the caller's event")) return 1;
+		pass->wait_before_next_frame = NULL;
 	}
 	if (pass->use_ray_tracing && pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 	if (upload_constants(app, stream)) return 1;
@@ -1005,13 +1016,22 @@ __global__ void __launch_bounds__(256) k_evaluate_arithmetic(uint32_t operation,
 	case 1: out[i] = square_root(x); break;
 	case 2: out[i] = rsqrt(x); break;
 	case 3: out[i] = x / y; break;
-	default: out[i] = sqrtf(x); break;
+	case 4: out[i] = sqrtf(x); break;
+	// the functions of the libm arithmetic mode (glibc_math.h with this file's divide / square_root)
+	case 5: out[i] = gm_atanf(x); break;
+	case 6: out[i] = gm_acosf(x); break;
+	case 7: out[i] = gm_sinf(x); break;
+	case 8: out[i] = gm_cosf(x); break;
+	case 9: out[i] = gm_log2f(x); break;
+	case 10: out[i] = gm_powf(x, y); break;
+	case 11: out[i] = gm_atan2f(x, y); break;
+	default: out[i] = divide(1.0f, square_root(x)); break;
 	}
 }
 
 extern "C" int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count) {
-	if (!device || !a || !out || operation > 4 || ((operation == 0 || operation == 3) && !b)) {
-		printf("evaluate_device_arithmetic() needs a device, operands and an operation in 0 ... 4.\n");
+	if (!device || !a || !out || operation > 12 || ((operation == 0 || operation == 3 || operation == 10 || operation == 11) && !b)) {
+		printf("evaluate_device_arithmetic() needs a device, operands and an operation in 0 ... 12.\n");
 		return 1;
 	}
 	if (!count) return 0;

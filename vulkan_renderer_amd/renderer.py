@@ -344,6 +344,14 @@ class Renderer(HostScene):
             self.exchange = None
             raise RuntimeError("create_slab_exchange failed")
 
+    def create_local_exchange(self, group, slab_format="rgba32f"):
+        """Joins a group made by capi.load().create_local_slab_group(rank_count): ranks of this process that
+        exchange their slabs with device-to-device copies (call from the rank's own thread)"""
+        self.exchange = capi.SlabExchange()
+        if self.lib.create_local_slab_exchange(C.byref(self.exchange), C.byref(self.app), group, capi.SLAB_FORMAT[slab_format]):
+            self.exchange = None
+            raise RuntimeError("create_local_slab_exchange failed")
+
     def destroy_exchange(self):
         if self.exchange is not None:
             self.lib.destroy_slab_exchange(C.byref(self.exchange), C.byref(self.app))
