@@ -219,9 +219,16 @@ typedef struct shading_pass_s {
 		frame a target which earlier work on another stream still reads (the slab exchange): only the
 		pass knows which stream the frame will take. */
 	void* wait_before_next_frame;
-	/*! hipStream_t the most recent render_shading_pass() queued its kernels on (device->stream or
-		one of the frame streams) */
+	/*! hipStream_t the most recent render_shading_pass() queued its (last) kernels on
+		(device->stream or one of the frame streams) */
 	void* last_frame_stream;
+	/*! Frames with wavefront shadow rays are rendered in `band_count` launches over consecutive parts of
+		the frame ("bands"), each shaded, traced and resolved with wavefront buffers sized for the band;
+		bands overlap on the frame streams like frames do.  0 (default): as few bands as keep all sets of
+		buffers in flight within the budget (24 GiB, environment VKR_WAVEFRONT_BUDGET_MIB) - one for
+		1920x1080 frames, eight for BASELINE config 4.  Set before create_shading_pass like
+		arithmetic_mode.  last_band_count: what the most recent frame used. */
+	uint32_t band_count, last_band_count;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */

@@ -14,6 +14,15 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def kernel_mode(kernel_name):
+    """Arithmetic mode of a shading kernel from its namespace (libm_math / exact_math / fast_math)"""
+    for mode in ("libm", "exact", "fast"):
+        if mode + "_math" in kernel_name:
+            return mode
+    return None
 
 
 def counters(directory):
@@ -38,6 +47,12 @@ def kernel_stats(directory):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    # the mode the collection ran in (profiles/collect.sh <tag> <mode>); entries of
+    # profiles/pmc_traffic.json are keyed by configuration and mode and carry the hash of the kernel
+    # sources they were measured with (bench.py refuses stale ones)
+    run_mode = sys.argv[2] if len(sys.argv) > 2 else "libm"
+    import bench
+    csrc_hash = bench.kernel_source_hash()
     base = os.path.join(ROOT, "gpurun_out", tag)
     lines = ["# rocprofv3 summary %s" % tag, "",
              "Collected by `profiles/collect.sh %s` on an MI355X (gfx950), summarised by `profiles/summarize.py`." % tag, ""]
@@ -85,8 +100,10 @@ def main():
                 simds = 1024.0
                 lines += ["", "Derived (SQ_* count quad-cycles; GRBM_GUI_ACTIVE is summed over 8 XCDs):", "",
                           "- kernel length ~ %.0f cycles; mean resident waves per SIMD = %.2f" % (cycles, 4 * c["SQ_WAVE_CYCLES"] / (simds * cycles)),
-                          "- VALU busy = %.1f %% of SIMD cycles; lane utilisation of VALU instructions = %.1f %%" % (
-                              100 * 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (simds * cycles), 100 * c.get("SQ_THREAD_CYCLES_VALU", 0) / max(64 * c.get("SQ_ACTIVE_INST_VALU", 1), 1)),
+                          # (a "VALU busy" share of SIMD cycles used to be printed here from SQ_ACTIVE_INST_VALU; its unit on gfx950 is not
+                          # the quad-cycle the formula assumed - it came out above 100 % -, so the issue floor below, from instruction
+                          # counts and measured issue costs, is the only VALU figure that is reported)
+                          "- lane utilisation of VALU instructions = %.1f %%" % (100 * c.get("SQ_THREAD_CYCLES_VALU", 0) / max(64 * c.get("SQ_ACTIVE_INST_VALU", 1), 1)),
                           "- wave time: %.1f %% issuing, %.1f %% waiting on memory (s_waitcnt), %.1f %% issue stalls" % (
                               100 * c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"])]
             if "SQ_INSTS_VALU" in c:
@@ -112,18 +129,26 @@ def main():
                 else:
                     floor_us = 4 * c.get("SQ_ACTIVE_INST_VALU", total) / 1024.0 / 2400.0
                     lines.append("- VALU issue floor at 4 clocks per instruction: %.1f us" % floor_us)
-                if ("shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel) and "fast_math" not in kernel:
-                    valu_floor = traffic.setdefault("config%d_exact_valu_floor_us" % cfg, {})
+                if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel:
+                    valu_floor = traffic.setdefault("config%d_%s_valu_floor_us" % (cfg, kernel_mode(kernel) or run_mode), {})
                     valu_floor[kernel.split("::")[-1].split("<")[0]] = round(floor_us, 2)
+                if "shade_pixels" in kernel and "SQ_INSTS_VALU_FMA_F32" in c:
+                    flop = 64.0 * (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 2.0 * c["SQ_INSTS_VALU_FMA_F32"])
+                    lines.append("- FP32 arithmetic: %.4g FLOP per dispatch (ADD + MUL + 2 FMA wave instructions x 64 lanes)%s" % (
+                        flop, (" = %.1f TFLOP/s over the %.1f us alone = %.1f %% of the 157.3 TFLOP/s FP32 vector peak" % (flop / alone / 1e6, alone, 100 * flop / alone / 1e6 / 157.3)) if alone else ""))
+                    traffic.setdefault("config%d_%s" % (cfg, kernel_mode(kernel) or run_mode), {})["fp32_flop_per_launch"] = flop
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
                 lines += ["- HBM traffic per dispatch: FETCH_SIZE %.1f MiB (x2 correction: %.1f MiB) + WRITE_SIZE %.1f MiB = %.1f MB raw" % (
                     c["FETCH_SIZE"] / 1024, 2 * c["FETCH_SIZE"] / 1024, c["WRITE_SIZE"] / 1024, raw / 1e6)]
                 if "TCC_HIT_sum" in c:
                     lines.append("- L2 hit rate %.1f %%" % (100 * c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)))
-                if "shade_pixels" in kernel and "fast_math" not in kernel:
+                if "shade_pixels" in kernel:
                     w, h = (1920, 1080)
-                    traffic["config%d_exact" % cfg] = {"width": w, "height": h, "hbm_bytes_per_launch": int(raw), "source": "profiles/%s_summary.md" % tag}
+                    entry = traffic.setdefault("config%d_%s" % (cfg, kernel_mode(kernel) or run_mode), {})
+                    # (FETCH_SIZE with the guide's x2 correction for wide coalesced reads on gfx950)
+                    entry.update({"width": w, "height": h, "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "hbm_bytes_per_launch_uncorrected": int(raw),
+                                  "source": "profiles/%s_summary.md" % tag, "csrc_hash": csrc_hash})
             lines.append("")
     open(os.path.join(ROOT, "profiles", "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(traffic_path, "w"), indent=1)

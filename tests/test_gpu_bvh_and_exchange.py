@@ -135,6 +135,36 @@ def test_bands_of_full_size_config_4_are_bit_exact(big_dataset):
     assert not np.isnan(image).any()
 
 
+@pytest.mark.parametrize("frames_in_flight", [1, 2, 3])
+@pytest.mark.parametrize("band_count", [2, 3, 7])
+def test_a_frame_rendered_in_bands_equals_the_frame_rendered_at_once(dataset, band_count, frames_in_flight):
+    """Bands: the frame as several launches over consecutive blocks, each with wavefront buffers sized
+    for the band, overlapping on the frame streams (how BASELINE config 4 keeps its buffers at a few
+    GB).  Same frame, same ray count, also when frames follow each other without synchronisation."""
+    whole, expected = render_config(dataset, 3, 512, 288)
+    rays = whole.last_ray_count()
+    whole.close()
+    r = renderer.Renderer(frames_in_flight=frames_in_flight, band_count=band_count)
+    renderer.setup_config(r, 3, dataset, width=512, height=288, acceleration_structure="sah_device")
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    for _ in range(4):
+        r.render()
+    image = r.read_radiance()
+    assert r.app.shading_pass.last_band_count == band_count
+    assert np.array_equal(image.view(np.uint32), expected.view(np.uint32))
+    assert r.last_ray_count() == rays
+    # the light display's colour goes through a stream that is only allocated when it is needed
+    r.app.render_settings.show_polygonal_lights = 1
+    r.render()
+    with_lights = r.read_radiance()
+    r.close()
+    whole, _ = render_config(dataset, 3, 512, 288, show_polygonal_lights=True)
+    assert np.array_equal(with_lights.view(np.uint32), whole.read_radiance().view(np.uint32))
+    whole.close()
+
+
 def test_error_display_frame_reports_no_rays_and_bad_settings_are_caught_at_render_time(dataset):
     r = renderer.Renderer()
     renderer.setup_config(r, 3, dataset, width=128, height=72, acceleration_structure=True)

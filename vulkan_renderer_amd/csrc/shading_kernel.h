@@ -75,10 +75,19 @@ struct shade_params {
 	// kRayQueueCount independent queues, each with its own counter (one counter for the
 	// whole chip saturates at ~88 atomics / us).  Each XCD owns 64 of them: they are filled
 	// by the shading workgroups and drained by the tracing workgroups of that XCD only.
-	float4* ray_queue;
+	// A queued ray is 20 bytes in two parallel arrays, [queue][slot]: (direction, t_max) and a
+	// record word = thread | code cursor << ray_thread_bits (ray_record()); its origin is the
+	// shading position of the pixel, stored once per thread (ray_origins) - a pixel queues up to
+	// 2 L S rays from the same point (config 3: 14 on average).
+	float4* ray_directions;
+	uint32_t* ray_records;
+	float4* ray_origins;
 	uint32_t* ray_queue_size;
-	uint32_t ray_queue_capacity;
+	uint32_t ray_queue_capacity, ray_thread_bits;
 	uint32_t thread_count, max_terms, max_codes;
+	// first 16x16 pixel block of this launch in the rank's schedule (a frame may be rendered as
+	// several launches, "bands", each with wavefront buffers of its own size)
+	uint32_t first_block, block_count;
 	// slots a wave reserves in its queue per atomic (0: exactly as many as it needs, one atomic per
 	// push; used when a lane queues only a ray or two).  Unused slots are left as null rays.
 	uint32_t ray_block;
@@ -107,13 +116,22 @@ constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic 
 enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2, kRaysDeferredBlocks = 3 };
 constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == kRaysDeferredBlocks; }
 // codes of the per-thread term stream written in deferred mode
-enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5 };
+// (kCodePendingHiddenNaN: the value of the blocked term is not stored because it can only be NaN - every
+// estimator but the plain optimal MIS heuristic computes it as 0 x something, i.e. +-0 or NaN, and a NaN
+// in any channel sends the whole pixel to the shader's NaN guard, shading_pass.frag.glsl:861-864)
+enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5, kCodePendingHiddenNaN = 6 };
 // Byte index of code `cursor` of thread `tid`: four consecutive codes of a thread share one 32-bit
 // word ([cursor / 4][thread] words), so that the resolve kernel fetches four codes per load and can
 // request their terms together instead of walking a chain of dependent one-byte loads
 VKR_DEV size_t code_slot(uint32_t thread_count, uint32_t cursor, uint32_t tid) {
 	return (((size_t) (cursor >> 2) * thread_count + tid) << 2) | (cursor & 3u);
 }
+// The record word of a queued ray: which thread's term (thread_bits low bits) and which code of
+// that thread's stream the tracing kernel flips when the ray reaches the light.  The host checks
+// that both fit (thread_count <= 2^thread_bits, max_codes <= 2^(32 - thread_bits)).
+VKR_DEV uint32_t ray_record(uint32_t thread_bits, uint32_t tid, uint32_t cursor) { return tid | (cursor << thread_bits); }
+VKR_DEV uint32_t ray_record_thread(uint32_t thread_bits, uint32_t record) { return record & ((1u << thread_bits) - 1u); }
+VKR_DEV uint32_t ray_record_cursor(uint32_t thread_bits, uint32_t record) { return record >> thread_bits; }
 
 // Reads of the constant buffer (frame constants and light records; written by the host before the
 // launch, never by a kernel) go through the constant address space: the compiler may then use scalar
@@ -699,7 +717,7 @@ VKR_DEV volatile uint32_t* ray_block_state() {
 // out from LDS, one atomic per block.  (A kernel variant, not a run-time switch: the block
 // bookkeeping costs 7 VGPRs, which is a wave of occupancy for config 2's kernel.)
 template <bool BLOCKS>
-VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 origin, f3 dir, float t_max, uint32_t code_index) {
+VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 dir, float t_max, uint32_t record) {
 	uint64_t mask = __ballot(1);
 	uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 	uint32_t count = (uint32_t) __popcll(mask);
@@ -726,8 +744,8 @@ VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 origin, f3 dir, 
 		}
 	}
 	size_t slot = (size_t) queue * p.ray_queue_capacity + slot_in_queue;
-	p.ray_queue[2 * slot] = make_float4(origin.x, origin.y, origin.z, t_max);
-	p.ray_queue[2 * slot + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(code_index));
+	p.ray_directions[slot] = make_float4(dir.x, dir.y, dir.z, t_max);
+	p.ray_records[slot] = record;
 }
 
 // At the end of a shading wave: slots of its last block that no ray took become null rays (the
@@ -740,8 +758,8 @@ VKR_DEV void close_ray_block(const shade_params& p, uint32_t queue) {
 	uint32_t base = __builtin_amdgcn_readfirstlane(state[0]), left = __builtin_amdgcn_readfirstlane(state[1]), rays = __builtin_amdgcn_readfirstlane(state[2]);
 	for (uint32_t i = rank; i < left; i += lanes) {
 		size_t slot = (size_t) queue * p.ray_queue_capacity + base + i;
-		p.ray_queue[2 * slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-		p.ray_queue[2 * slot + 1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNullRay));
+		p.ray_directions[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+		p.ray_records[slot] = kNullRay;
 	}
 	if (rank == 0 && rays) atomicAdd(p.ray_queue_size + kRayCountOffset + (queue >> 6) * kCursorStride, rays);
 }
@@ -773,14 +791,15 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
 			size_t code_index = code_slot(p.thread_count, ctx.code_cursor, ctx.tid);
 			size_t term_index = ((size_t) ctx.term_cursor * p.thread_count + ctx.tid) * 3;
-			p.codes[code_index] = (uint8_t) (is_final ? kCodeFinal : (hidden_matters ? kCodePendingWithHidden : kCodePending));
+			// (terms_hidden exists for the one estimator whose blocked terms have values, the optimal heuristic)
+			p.codes[code_index] = (uint8_t) (is_final ? kCodeFinal : (hidden_matters ? (p.terms_hidden ? kCodePendingWithHidden : kCodePendingHiddenNaN) : kCodePending));
 			p.terms_visible[term_index] = visible_term.x; p.terms_visible[term_index + 1] = visible_term.y; p.terms_visible[term_index + 2] = visible_term.z;
-			if (needs_ray && hidden_matters) {
+			if (needs_ray && hidden_matters && p.terms_hidden) {
 				p.terms_hidden[term_index] = hidden_term.x; p.terms_hidden[term_index + 1] = hidden_term.y; p.terms_hidden[term_index + 2] = hidden_term.z;
 			}
 			if (needs_ray) {
 				float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
-				push_ray<RAYS == kRaysDeferredBlocks>(p, ctx.queue, sd.position, dir, max_t, (uint32_t) code_index);
+				push_ray<RAYS == kRaysDeferredBlocks>(p, ctx.queue, dir, max_t, ray_record(p.ray_thread_bits, ctx.tid, ctx.code_cursor));
 			}
 			++ctx.code_cursor;
 			++ctx.term_cursor;
@@ -1335,11 +1354,12 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// on XCD b % 8; the four patches of a block are the workgroups b, b + 8, b + 16, b + 24 of a
 	// group of 32, so they share that XCD's L2.
 	const uint32_t b = blockIdx.x;
-	const uint32_t block = ((b >> 5) << 3) | (b & 7u);
+	const uint32_t local_block = ((b >> 5) << 3) | (b & 7u);
+	const uint32_t block = p.first_block + local_block;
 	const uint32_t thread = (((b >> 3) & 3u) << 6) | threadIdx.x;
 	uint32_t px, py;
 	size_t out_index;
-	bool inside = locate_pixel(p, block, thread, px, py, out_index);
+	bool inside = local_block < p.block_count && locate_pixel(p, block, thread, px, py, out_index);
 	// ray queue of this wave: one of the 64 queues of its XCD, so a queue counter's cache line is
 	// only ever touched from one L2
 	uint32_t queue = (b & 7u) * 64u + ((b >> 3) & 63u);
@@ -1349,7 +1369,8 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// its size that a third wave cannot fit and drop the register limit that goes with three - at V = 7 ten
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
-	pixel_context ctx = {p, 0, block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
+	// (the wavefront buffers are indexed by the thread's number within this launch)
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		volatile uint32_t* state = ray_block_state();
@@ -1371,6 +1392,8 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 			sd = get_shading_data(p, primitive, ray, (size_t) py * p.width + px);
 			end_xyz = sd.position;
 			end_w = 1.0f;
+			// every shadow ray of this pixel starts here
+			if constexpr (is_deferred(RAYS)) p.ray_origins[ctx.tid] = make_float4(sd.position.x, sd.position.y, sd.position.z, 0.0f);
 		}
 		if (p.show_polygonal_lights) {
 			f3 camera = load_f3(c, 144);
@@ -1395,7 +1418,8 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 		if constexpr (is_deferred(RAYS)) {
 			// hand over to trace_shadow_rays / resolve_shadow_terms: the colour so far
 			// (light display) and the terminated term stream
-			p.base_color[ctx.tid] = make_float4(color.x, color.y, color.z, 0.0f);
+			// (without the light display the colour so far is +0, and the resolve kernel knows)
+			if (p.show_polygonal_lights) p.base_color[ctx.tid] = make_float4(color.x, color.y, color.z, 0.0f);
 			p.codes[code_slot(p.thread_count, ctx.code_cursor, ctx.tid)] = (uint8_t) kCodeEnd;
 		}
 		else

@@ -121,9 +121,15 @@ struct wavefront_buffers {
 	float* terms_visible;
 	float* terms_hidden;
 	float4* base_color;
-	float4* ray_queue;
+	float4* ray_directions;
+	uint32_t* ray_records;
+	float4* ray_origins;
 	uint32_t* ray_queue_size;  // kRayCounterCount live counters (queue sizes, per-XCD work cursors), then last frame's copy
-	uint32_t thread_count, max_terms, max_codes, queue_capacity;
+	uint32_t thread_count, max_terms, max_codes, queue_capacity, thread_bits;
+	// the streams that only some settings need are allocated when they first do: values of blocked
+	// terms (only the plain optimal MIS heuristic has non-zero ones), colour before the sampled terms
+	// (only the light display has one)
+	bool has_hidden_terms, has_base_color;
 	// stack entries beyond the LDS part of trace_shadow_rays_wide, [entry][thread of the trace grid];
 	// allocated only for trees that can need them
 	uint32_t* spill;
@@ -132,7 +138,7 @@ struct wavefront_buffers {
 
 static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->codes); (void) hipFree(w->terms_visible); (void) hipFree(w->terms_hidden);
-	(void) hipFree(w->base_color); (void) hipFree(w->ray_queue); (void) hipFree(w->ray_queue_size);
+	(void) hipFree(w->base_color); (void) hipFree(w->ray_directions); (void) hipFree(w->ray_records); (void) hipFree(w->ray_origins); (void) hipFree(w->ray_queue_size);
 	(void) hipFree(w->spill);
 	memset(w, 0, sizeof(*w));
 }
@@ -167,7 +173,10 @@ struct frame_pipeline {
 	// queues eight rays or more, four otherwise - measured at config 2, whose 0.9 M rays are a batch or
 	// two per wave: 0.129 -> 0.121 ms per frame)
 	// VKR_TRACE_SINGLE_WAVES: 0 / 1 overrides the choice of the tracing kernel's workgroup size (2: automatic)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves;
+	// VKR_WAVEFRONT_BUDGET_MIB: most device memory that all sets of wavefront buffers in flight may take
+	// (default 24576: a frame whose worst case needs more is rendered in bands); VKR_BAND_COUNT forces
+	// the number of bands per frame (0: automatic)
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -208,6 +217,8 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
 	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
+	frames->wavefront_budget_mib = environment_knob("VKR_WAVEFRONT_BUDGET_MIB", 24576u, 64u, 262144u);
+	frames->band_count = environment_knob("VKR_BAND_COUNT", 0u, 0u, 4096u);
 	return frames;
 }
 
@@ -229,43 +240,69 @@ static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t in_l
 	return 0;
 }
 
+// Bytes per term slot of the streams every frame needs (visible value 12, code 1) and per ray slot (20)
+static uint32_t queue_capacity_for(uint32_t thread_count, uint32_t max_terms) {
+	// a queue sees every 512th wave (8 XCDs x 64 queues, waves dealt round-robin), every
+	// lane of which may emit max_terms rays
+	return ((thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * (64u * max_terms + ray_block_size(max_terms));
+}
+
+// bytes that ensure_wavefront() allocates for a launch of thread_count threads
+static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count, bool hidden_terms, bool base_color) {
+	double terms = (double) max_terms * thread_count;
+	return terms * (hidden_terms ? 24.0 : 12.0) + (double) ((max_terms + light_count + 2 + 3) & ~3u) * thread_count + (base_color ? 16.0 : 0.0) * thread_count
+		+ 16.0 * thread_count + (double) queue_capacity_for(thread_count, max_terms) * kRayQueueCount * 20.0;
+}
+
 // `stream`: the stream the frame that uses these buffers is about to run on.  The counters are cleared
 // THERE: the frame streams are non-blocking, i.e. not ordered behind a hipMemset on the null stream, and
 // a frame that started before that memset landed had its queue sizes reset under its feet (found in
 // round 3: the first frame of a fresh context lost a few rays).
-static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count, hipStream_t stream) {
+static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_t max_terms, uint32_t light_count, bool hidden_terms, bool base_color, hipStream_t stream) {
 	uint32_t max_codes = max_terms + light_count + 2;
-	if (w->codes && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) return 0;
+	size_t terms = (size_t) max_terms * thread_count;
+	if (w->codes && w->thread_count == thread_count && w->max_terms == max_terms && w->max_codes == max_codes) {
+		// (frames in flight may still use the other streams of this context: allocating does not disturb them)
+		if (hidden_terms && !w->has_hidden_terms) {
+			if (hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess) { printf("Failed to allocate %.1f MiB for the values of blocked terms.\n", terms * 12.0 / 1048576.0); return 1; }
+			w->has_hidden_terms = true;
+		}
+		if (base_color && !w->has_base_color) {
+			if (hipMalloc(&w->base_color, sizeof(float4) * (size_t) thread_count) != hipSuccess) { printf("Failed to allocate the colours of the light display.\n"); return 1; }
+			w->has_base_color = true;
+		}
+		return 0;
+	}
 	free_wavefront_buffers(w);
 	w->thread_count = thread_count; w->max_terms = max_terms; w->max_codes = max_codes;
-	size_t terms = (size_t) max_terms * thread_count;
-	if (terms >= 0xFFFFFFFFull || (size_t) (max_codes + 3u) * thread_count >= 0xFFFFFFFFull) {
-		printf("The wavefront ray queue would need more than 2^32 entries (%u threads x %u terms); render in tiles or use inline rays.\n", thread_count, max_terms);
+	// the record word of a ray: thread and code cursor (shading_kernel.h ray_record)
+	uint32_t thread_bits = 1;
+	while (thread_bits < 32 && (1ull << thread_bits) < thread_count) ++thread_bits;
+	if (terms >= 0xFFFFFFFFull || (size_t) (max_codes + 3u) * thread_count >= 0xFFFFFFFFull || thread_bits >= 32 || ((uint64_t) max_codes << thread_bits) > 0xFFFFFFFFull) {
+		printf("The wavefront ray queue would need more than 2^32 entries (%u threads x %u terms); render in more bands or use inline rays.\n", thread_count, max_terms);
 		return 1;
 	}
-	// a queue sees every 512th wave (8 XCDs x 64 queues, waves dealt round-robin), every
-	// lane of which may emit max_terms rays
-	w->queue_capacity = ((thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * (64u * max_terms + ray_block_size(max_terms));
+	w->thread_bits = thread_bits;
+	w->queue_capacity = queue_capacity_for(thread_count, max_terms);
+	size_t ray_slots = (size_t) w->queue_capacity * kRayQueueCount;
 	// (codes are stored four to a word per thread: code_slot() in shading_kernel.h)
 	if (hipMalloc(&w->codes, (size_t) ((max_codes + 3u) & ~3u) * thread_count) != hipSuccess
 		|| hipMalloc(&w->terms_visible, terms * 12) != hipSuccess
-		|| hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess
-		|| hipMalloc(&w->base_color, sizeof(float4) * (size_t) thread_count) != hipSuccess
-		|| hipMalloc(&w->ray_queue, (size_t) w->queue_capacity * kRayQueueCount * 32) != hipSuccess
+		|| (hidden_terms && hipMalloc(&w->terms_hidden, terms * 12) != hipSuccess)
+		|| (base_color && hipMalloc(&w->base_color, sizeof(float4) * (size_t) thread_count) != hipSuccess)
+		|| hipMalloc(&w->ray_directions, ray_slots * 16) != hipSuccess
+		|| hipMalloc(&w->ray_records, ray_slots * 4) != hipSuccess
+		|| hipMalloc(&w->ray_origins, sizeof(float4) * (size_t) thread_count) != hipSuccess
 		|| hipMalloc(&w->ray_queue_size, sizeof(uint32_t) * 2 * kRayCounterCount) != hipSuccess
 		|| hipMemsetAsync(w->ray_queue_size, 0, sizeof(uint32_t) * 2 * kRayCounterCount, stream) != hipSuccess)
 	{
-		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", (terms * 56.0 + (double) max_codes * thread_count) / 1048576.0);
+		printf("Failed to allocate %.1f MiB for the wavefront ray queue and term streams.\n", wavefront_bytes(thread_count, max_terms, light_count, hidden_terms, base_color) / 1048576.0);
 		free_wavefront_buffers(w);
 		return 1;
 	}
+	w->has_hidden_terms = hidden_terms;
+	w->has_base_color = base_color;
 	return 0;
-}
-
-// bytes that ensure_wavefront() would allocate
-static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count) {
-	double queue_capacity = ((double) (thread_count / 64 + kRayQueueCount - 1) / kRayQueueCount + 1) * (64.0 * max_terms + ray_block_size(max_terms));
-	return (double) max_terms * thread_count * 24.0 + (double) (max_terms + light_count + 2) * thread_count + 16.0 * thread_count + queue_capacity * kRayQueueCount * 32.0;
 }
 
 extern "C" void mark_inputs_changed(application_t* app) {
@@ -493,6 +530,7 @@ static int create_timing_ring(shading_pass_t* pass) {
 
 extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	int32_t arithmetic_mode = pass->arithmetic_mode, inline_rays = pass->inline_rays, binary_traversal = pass->binary_traversal;
+	uint32_t band_count = pass->band_count;
 	void* wait_before_next_frame = pass->wait_before_next_frame;
 	uint32_t timing_stride = pass->timing_stride, frames_in_flight = pass->frames_in_flight;
 	memset(pass, 0, sizeof(*pass));
@@ -505,6 +543,7 @@ extern "C" int create_shading_pass(shading_pass_t* pass, application_t* app) {
 	}
 	pass->arithmetic_mode = arithmetic_mode;
 	pass->wait_before_next_frame = wait_before_next_frame;
+	pass->band_count = band_count;
 	pass->inline_rays = inline_rays ? 1 : 0;
 	pass->binary_traversal = binary_traversal ? 1 : 0;
 	pass->variant = -1;
@@ -654,34 +693,59 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		return 1;
 	}
 	if (pass->use_ray_tracing) {
-		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, sizeof(unsigned long long)), "allocating the ray counter")) return 1;
+		// (eight counters, one per frame in turn: see the band loop)
+		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, 8 * sizeof(unsigned long long)), "allocating the ray counters")) return 1;
 		p.ray_counter = (unsigned long long*) pass->ray_counter;
 	}
-	// Frames with wavefront rays may run n at a time: frame k on frame stream k mod n with
-	// its own buffers, so that the (latency-bound) tracing of one frame overlaps the
+	// Launches with wavefront rays may run n at a time: launch k on frame stream k mod n with
+	// its own buffers, so that the (latency-bound) tracing of one launch overlaps the
 	// (VALU-bound) shading of the next ones.  Everything else runs on device->stream, behind
-	// any frame that is still in flight.
-	frame_context* frame = NULL;
+	// any launch that is still in flight.
+	// A frame is one launch - or several, "bands" of consecutive 16x16 blocks of the rank's schedule,
+	// when the wavefront buffers of the whole frame (sized for the worst case: every sample of every
+	// light on every pixel queues a ray) would be larger than the budget: a band is shaded, traced and
+	// resolved like a small frame, with buffers sized for the band, and the bands of one frame - and of
+	// the next frames - overlap on the frame streams exactly like whole frames do.
 	bool pipelined = false;
 	// the tracing kernels are persistent: 8 waves per SIMD on every CU, each lane strides over the queues
 	// (8 by default; the count is a knob of the frame pipeline)
 	const uint32_t compute_units = (uint32_t) (app->device.compute_unit_count > 0 ? app->device.compute_unit_count : 256);
 	uint32_t trace_blocks = compute_units * 8u;
 	const bool use_wide_tree = app->scene.acceleration_structure.wide_nodes && !pass->binary_traversal;
-	if (ray_mode == kRaysDeferred) {
-		uint32_t max_rays_per_lane = 2u * p.light_count * p.sample_count;
-		if ((int) app->render_settings.sampling_strategies >= (int) sampling_strategies_diffuse_specular_separately && ray_block_size(max_rays_per_lane))
-			ray_mode = kRaysDeferredBlocks;
-	}
+	const uint32_t max_terms = 2u * p.light_count * p.sample_count;
+	if (ray_mode == kRaysDeferred && (int) app->render_settings.sampling_strategies >= (int) sampling_strategies_diffuse_specular_separately && ray_block_size(max_terms))
+		ray_mode = kRaysDeferredBlocks;
+	// values of blocked terms exist for the plain optimal heuristic only (its estimate is not proportional
+	// to the integrand); a colour before the sampled terms only with the light display
+	const bool hidden_terms = app->render_settings.mis_heuristic == mis_heuristic_optimal && (int) app->render_settings.sampling_strategies == (int) sampling_strategies_diffuse_specular_mis;
+	const bool base_color = p.show_polygonal_lights != 0;
+	uint32_t band_count = 1, blocks_per_band = grid_blocks, depth = 1;
+	frame_pipeline* frames = NULL;
 	if (is_deferred(ray_mode)) {
-		frame_pipeline* frames = ensure_frames(pass);
+		frames = ensure_frames(pass);
 		if (!frames) return 1;
-		uint32_t thread_count = grid_blocks * 256u, max_terms = 2u * p.light_count * p.sample_count;
-		// the sets of buffers must fit comfortably into the 288 GB of HBM next to everything else
 		// (a textured scene has one per-pixel material buffer: one frame at a time)
-		uint32_t depth = pass->frames_in_flight < VKR_MAX_FRAMES_IN_FLIGHT ? pass->frames_in_flight : VKR_MAX_FRAMES_IN_FLIGHT;
-		while (depth >= 2 && (!device->frame_streams[depth - 1] || depth * wavefront_bytes(thread_count, max_terms, p.light_count) >= 192.0e9)) --depth;
+		depth = pass->frames_in_flight < VKR_MAX_FRAMES_IN_FLIGHT ? pass->frames_in_flight : VKR_MAX_FRAMES_IN_FLIGHT;
+		while (depth >= 2 && !device->frame_streams[depth - 1]) --depth;
+		if (depth < 1) depth = 1;
 		pipelined = depth >= 2 && !app->scene.materials.textured;
+		if (!pipelined) depth = 1;
+		// Bands: as few as keep all sets of buffers in flight within the budget, each at least
+		// kMinBandBlocks blocks (a launch has to fill the GPU several times over), whole groups of 8 blocks
+		// (shade_grid_size).  pass->band_count / VKR_BAND_COUNT force a number.
+		const double budget = (double) frames->wavefront_budget_mib * 1048576.0;
+		const uint32_t kMinBandBlocks = 4096;
+		uint32_t wanted = pass->band_count ? pass->band_count : frames->band_count;
+		if (!wanted) {
+			wanted = 1;
+			while (depth * wavefront_bytes(((grid_blocks + wanted - 1) / wanted) * 256u, max_terms, p.light_count, hidden_terms, base_color) > budget
+				&& (grid_blocks + wanted) / (wanted + 1) >= kMinBandBlocks)
+				++wanted;
+		}
+		blocks_per_band = (((grid_blocks + wanted - 1) / wanted) + 7u) & ~7u;
+		if (blocks_per_band == 0) blocks_per_band = 8;
+		band_count = (grid_blocks + blocks_per_band - 1) / blocks_per_band;
+		if (band_count == 0) band_count = 1;
 		if (!pipelined && finish_frames(app)) return 1;
 		if (pipelined && frames->depth != depth) {
 			// another pipeline depth: contexts and streams pair up differently, start afresh
@@ -690,39 +754,25 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			frames->depth = depth;
 			frames->next = 0;
 		}
-		uint32_t index = 0;
-		if (pipelined) {
-			index = frames->next;
-			frames->next = (index + 1) % depth;
-		}
-		frame = &frames->contexts[index];
-		frames->last = index;
-		if (pipelined) {
-			stream = (hipStream_t) device->frame_streams[index];
-			// Inputs that were produced on device->stream (visibility pass, uploads): both frame
+		if (pipelined && pass->inputs_changed) {
+			// Inputs that were produced on device->stream (visibility pass, uploads): all frame
 			// streams wait for them once.  Frames do not wait for anything else on
 			// device->stream - if they did, a consumer of frame k there would hold back frame k + 1.
-			if (pass->inputs_changed) {
-				if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")) return 1;
-				for (uint32_t i = 0; i != depth; ++i)
-					if (hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[i], frames->inputs_ready, 0), "waiting for the inputs")) return 1;
-				pass->inputs_changed = 0;
-			}
+			if (hip_failed(hipEventRecord(frames->inputs_ready, (hipStream_t) device->stream), "marking the inputs")) return 1;
+			for (uint32_t i = 0; i != depth; ++i)
+				if (hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[i], frames->inputs_ready, 0), "waiting for the inputs")) return 1;
+			pass->inputs_changed = 0;
 		}
 		trace_blocks = compute_units * (frames->trace_waves ? frames->trace_waves : (max_terms >= 8u ? 8u : 4u));
-		if (ensure_wavefront(&frame->buffers, thread_count, max_terms, p.light_count, stream)) return 1;
-		if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
-		const wavefront_buffers* w = &frame->buffers;
-		p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden; p.base_color = w->base_color;
-		p.ray_queue = w->ray_queue; p.ray_queue_size = w->ray_queue_size;
-		p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
-		p.ray_queue_capacity = w->queue_capacity;
+		// (queues of XCD x are only served by workgroups b with b % 8 == x)
+		trace_blocks = (trace_blocks + 7u) & ~7u;
 		p.ray_block = ray_mode == kRaysDeferredBlocks ? ray_block_size(max_terms) : 0u;
 		p.refill_threshold = frames->refill_threshold;
 	}
 	else if (finish_frames(app)) return 1;
 	pass->last_frame_traced_rays = ray_mode != kRaysNone;
-	pass->last_frame_in_flight = pipelined ? ((frame_pipeline*) pass->wavefront)->depth : 0u;
+	pass->last_frame_in_flight = pipelined ? depth : 0u;
+	pass->last_band_count = band_count;
 	// textured scene: sample the material textures of every pixel first (same stream)
 	bool textured = app->scene.materials.textured && app->scene.materials.texture_descriptors;
 	if (textured) {
@@ -750,85 +800,111 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		p.light_texture_descriptors = (const uint4*) app->light_textures.descriptors;
 		p.light_texels = (const float4*) app->light_textures.texels;
 	}
-	pass->last_frame_stream = stream;
-	if (pass->wait_before_next_frame) {
-		if (hip_failed(hipStreamWaitEvent(stream, (hipEvent_t) pass->wait_before_next_frame, 0), "waiting for the caller's event")) return 1;
-		pass->wait_before_next_frame = NULL;
-	}
-	if (pass->use_ray_tracing && pass->inline_rays && hip_failed(hipMemsetAsync(pass->ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
-	if (upload_constants(app, stream)) return 1;
-	p.constants = (const uint8_t*) pass->constants_device;
-	if (textured) {
-		if (g_resolve_launchers[pass->arithmetic_mode](&p, (float*) pass->pixel_materials, stream)) {
-			printf("Launching the material resolve kernel failed.\n");
-			return 1;
-		}
-		p.pixel_materials = (const float*) pass->pixel_materials;
-	}
 	int strategy = (int) app->render_settings.sampling_strategies;
 	int technique = technique_index(&app->render_settings);
 	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping || technique == kTechniquePsaArvo;
 	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
-	// every timing_stride-th frame is bracketed by a pair of events (an event record costs
-	// about 5 us of idle time on the stream, a tenth of a config-2 frame for the pair)
+	// every timing_stride-th frame is bracketed by events: start, end of the (last band's) shading
+	// kernel, end of the frame (an event record costs about 5 us of idle time on the stream, a tenth
+	// of a config-2 frame for the pair)
 	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
 	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
 	bool timed = pass->timing_stride <= 1 || pass->frame_counter % pass->timing_stride == 0;
+	// rays of this frame: one of eight counters, taken in turn, so that the bands of this frame never
+	// meet those of a frame that is still in flight (at most four launches are)
+	if (p.ray_counter) p.ray_counter += pass->frame_counter % 8u;
 	++pass->frame_counter;
-	if (timed) (void) hipEventRecord(ring[3 * slot], stream);
-	int status = error_mode != kErrorNone
-		? g_error_launchers[pass->arithmetic_mode](strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, grid_blocks, stream)
-		: g_launchers[pass->arithmetic_mode + (p.light_texture_descriptors ? 3 : 0)][strategy](technique, capacity, ray_mode, &p, grid_blocks, stream);
-	if (timed) (void) hipEventRecord(ring[3 * slot + 1], stream);
-	if (status == 0 && is_deferred(ray_mode)) {
-		if (use_wide_tree) {
-			const frame_pipeline* knobs = (const frame_pipeline*) pass->wavefront;
-			const uint4* wide_nodes = (const uint4*) app->scene.acceleration_structure.wide_nodes;
-			// single-wave workgroups where a lane queues many rays and the shading kernel runs three waves
-			// per SIMD (wavefront_kernels.h has the measurements)
-			bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 7;
-			if (knobs->trace_single_waves != 2u) single_waves = knobs->trace_single_waves != 0u;
-			if (single_waves)
-				trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
-					p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);
-			else
-				trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity,
-					p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, knobs->leaf_batch, knobs->wide_stack_lds);
-		}
-		else
-			trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, p.ray_queue, p.ray_queue_size, p.ray_queue_capacity, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
-		if (pipelined) {
-			// both frames in flight may write the same target: keep the frame order there
-			// (the frame before this one ran in the context before this one)
-			frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
-			// (whether device->stream has already been made to wait for that frame - finish_frames() -
-			// says nothing about this stream)
-			frame_context* previous = &frames->contexts[(frames->last + frames->depth - 1u) % frames->depth];
-			if (previous != frame && previous->recorded) (void) hipStreamWaitEvent(stream, previous->done, 0);
-			// ... and behind whatever still reads the target on device->stream (output encoding)
-			if (frame->readers_seen != frames->readers_generation) {
-				(void) hipStreamWaitEvent(stream, frames->readers_done, 0);
-				frame->readers_seen = frames->readers_generation;
+	hipEvent_t caller_event = (hipEvent_t) pass->wait_before_next_frame;
+	pass->wait_before_next_frame = NULL;
+	int status = 0;
+	frame_context* frame = NULL;
+	for (uint32_t band = 0; band != band_count && status == 0; ++band) {
+		p.first_block = band * blocks_per_band;
+		p.block_count = grid_blocks - p.first_block < blocks_per_band ? grid_blocks - p.first_block : blocks_per_band;
+		frame = NULL;
+		if (frames) {
+			uint32_t index = 0;
+			if (pipelined) {
+				index = frames->next;
+				frames->next = (index + 1) % depth;
+				stream = (hipStream_t) device->frame_streams[index];
 			}
+			frame = &frames->contexts[index];
+			frames->last = index;
+			if (ensure_wavefront(&frame->buffers, blocks_per_band * 256u, max_terms, p.light_count, hidden_terms, base_color, stream)) return 1;
+			if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
+			const wavefront_buffers* w = &frame->buffers;
+			p.codes = w->codes; p.terms_visible = w->terms_visible; p.terms_hidden = w->terms_hidden; p.base_color = w->base_color;
+			p.ray_directions = w->ray_directions; p.ray_records = w->ray_records; p.ray_origins = w->ray_origins; p.ray_queue_size = w->ray_queue_size;
+			p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
+			p.ray_queue_capacity = w->queue_capacity; p.ray_thread_bits = w->thread_bits;
 		}
-		resolve_shadow_terms_and_reset<<<grid_blocks, 256, 0, stream>>>(p);
-		status = hipGetLastError() != hipSuccess;
-	}
-	if (status == 0 && out_rgb8) {
-		// slab layout: every thread of the grid owns a slot; full-frame layout: the pixels
-		uint64_t pixels = p.slab_layout ? (uint64_t) grid_blocks * 256u : (uint64_t) p.width * p.height;
-		if (pixels % 4 != 0 || ensure_srgb_code_thresholds(device, stream)) {
-			printf("The frame cannot be encoded as packed RGB8 (its pixel count has to be a multiple of four).\n");
-			status = 1;
+		pass->last_frame_stream = stream;
+		// (a target that earlier work of the caller still reads: every stream that writes it waits)
+		if (caller_event && hip_failed(hipStreamWaitEvent(stream, caller_event, 0), "waiting for the caller's event")) return 1;
+		if (band == 0 && p.ray_counter && hip_failed(hipMemsetAsync(p.ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
+		if (upload_constants(app, stream)) return 1;
+		p.constants = (const uint8_t*) pass->constants_device;
+		if (textured && band == 0) {
+			if (g_resolve_launchers[pass->arithmetic_mode](&p, (float*) pass->pixel_materials, stream)) {
+				printf("Launching the material resolve kernel failed.\n");
+				return 1;
+			}
+			p.pixel_materials = (const float*) pass->pixel_materials;
 		}
-		else {
-			k_encode_output_rgb8<<<(uint32_t) ((pixels / 4 + 255) / 256), 256, 0, stream>>>((const float4*) p.out_radiance, (uint32_t*) out_rgb8, pixels / 4, app->screenshot.frame_bits, 0);
+		if (timed && band == 0) (void) hipEventRecord(ring[3 * slot], stream);
+		status = error_mode != kErrorNone
+			? g_error_launchers[pass->arithmetic_mode](strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, p.block_count, stream)
+			: g_launchers[pass->arithmetic_mode + (p.light_texture_descriptors ? 3 : 0)][strategy](technique, capacity, ray_mode, &p, p.block_count, stream);
+		if (timed && band + 1 == band_count) (void) hipEventRecord(ring[3 * slot + 1], stream);
+		if (status == 0 && is_deferred(ray_mode)) {
+			ray_stream rays = {p.ray_directions, p.ray_records, p.ray_origins, p.ray_queue_size, p.ray_queue_capacity, p.ray_thread_bits, p.thread_count};
+			if (use_wide_tree) {
+				const uint4* wide_nodes = (const uint4*) app->scene.acceleration_structure.wide_nodes;
+				// single-wave workgroups where a lane queues many rays and the shading kernel runs three waves
+				// per SIMD (wavefront_kernels.h has the measurements)
+				bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 7;
+				if (frames->trace_single_waves != 2u) single_waves = frames->trace_single_waves != 0u;
+				if (single_waves)
+					trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
+				else
+					trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
+			}
+			else
+				trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, rays, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
+			if (pipelined) {
+				// launches in flight may write the same target: keep their order there
+				// (the launch before this one ran in the context before this one)
+				// (whether device->stream has already been made to wait for that launch - finish_frames() -
+				// says nothing about this stream)
+				frame_context* previous = &frames->contexts[(frames->last + frames->depth - 1u) % frames->depth];
+				if (previous != frame && previous->recorded) (void) hipStreamWaitEvent(stream, previous->done, 0);
+				// ... and behind whatever still reads the target on device->stream (output encoding)
+				if (frame->readers_seen != frames->readers_generation) {
+					(void) hipStreamWaitEvent(stream, frames->readers_done, 0);
+					frame->readers_seen = frames->readers_generation;
+				}
+			}
+			resolve_shadow_terms_and_reset<<<p.block_count, 256, 0, stream>>>(p);
 			status = hipGetLastError() != hipSuccess;
 		}
-	}
-	if (status == 0 && pipelined) {
-		(void) hipEventRecord(frame->done, stream);
-		frame->pending = frame->recorded = true;
+		if (status == 0 && out_rgb8 && band + 1 == band_count) {
+			// (the resolves of the bands are chained, so the last band's stream has seen them all)
+			// slab layout: every thread of the grid owns a slot; full-frame layout: the pixels
+			uint64_t pixels = p.slab_layout ? (uint64_t) grid_blocks * 256u : (uint64_t) p.width * p.height;
+			if (pixels % 4 != 0 || ensure_srgb_code_thresholds(device, stream)) {
+				printf("The frame cannot be encoded as packed RGB8 (its pixel count has to be a multiple of four).\n");
+				status = 1;
+			}
+			else {
+				k_encode_output_rgb8<<<(uint32_t) ((pixels / 4 + 255) / 256), 256, 0, stream>>>((const float4*) p.out_radiance, (uint32_t*) out_rgb8, pixels / 4, app->screenshot.frame_bits, 0);
+				status = hipGetLastError() != hipSuccess;
+			}
+		}
+		if (status == 0 && pipelined) {
+			(void) hipEventRecord(frame->done, stream);
+			frame->pending = frame->recorded = true;
+		}
 	}
 	if (timed) {
 		(void) hipEventRecord(ring[3 * slot + 2], stream);
@@ -903,17 +979,17 @@ extern "C" float get_last_dispatch_milliseconds(application_t* app) {
 
 // Diagnostics: replays the rays that the last frame queued and counts the work of the
 // traversal (profiles/ cites these numbers; not part of the frame).
-__global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, const float4* ray_queue, const uint32_t* ray_queue_size, uint32_t ray_queue_capacity, unsigned long long* out) {
+__global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, ray_stream stream, unsigned long long* out) {
 	uint32_t queue = blockIdx.y;
-	uint32_t size = ray_queue_size[queue];
+	uint32_t size = stream.sizes[queue];
 	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ((size + 63u) & ~63u); i += gridDim.x * 256u) {
 		uint32_t my_visits = 0;
-		const float4* r = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + i);
-		if (i < size && __float_as_uint(r[1].w) != kNullRay) {
-			float4 a = r[0], b = r[1];
+		size_t slot = (size_t) queue * stream.capacity + i;
+		if (i < size && stream.records[slot] != kNullRay) {
+			float4 a = stream.origins[ray_record_thread(stream.thread_bits, stream.records[slot])], b = stream.directions[slot];
 			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
-			float t_max = a.w;
+			float t_max = b.w;
 			grid_ray ray = make_grid_ray(bvh, o, d);
 			uint32_t node = 0;
 			bool blocked = false;
@@ -947,17 +1023,17 @@ __global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, cons
 // The same for the four-wide tree: "visits" are fetched nodes (dependent loads), out[5] the longest
 // ray's, wave steps the longest ray of each group of 64; out[6] counts tested boxes, out[7] the
 // deepest stack a ray reached
-__global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh, const uint4* wide_nodes, const float4* ray_queue, const uint32_t* ray_queue_size, uint32_t ray_queue_capacity, unsigned long long* out) {
+__global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh, const uint4* wide_nodes, ray_stream stream, unsigned long long* out) {
 	uint32_t queue = blockIdx.y;
-	uint32_t size = ray_queue_size[queue];
+	uint32_t size = stream.sizes[queue];
 	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0, boxes = 0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ((size + 63u) & ~63u); i += gridDim.x * 256u) {
 		uint32_t my_visits = 0;
-		const float4* r = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + i);
-		if (i < size && __float_as_uint(r[1].w) != kNullRay) {
-			float4 a = r[0], b = r[1];
+		size_t slot = (size_t) queue * stream.capacity + i;
+		if (i < size && stream.records[slot] != kNullRay) {
+			float4 a = stream.origins[ray_record_thread(stream.thread_bits, stream.records[slot])], b = stream.directions[slot];
 			f3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z);
-			float t_max = a.w;
+			float t_max = b.w;
 			wide_ray ray = make_wide_ray(make_grid_ray(bvh, o, d));
 			uint32_t stack[kWideStackMax];
 			uint32_t depth = 0, deepest = 0, item = 0;
@@ -1053,7 +1129,7 @@ extern "C" int evaluate_device_arithmetic(const device_t* device, uint32_t opera
 extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]) {
 	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
-	if (!w || !w->ray_queue || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays) {
+	if (!w || !w->ray_directions || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays) {
 		printf("get_traversal_statistics() needs a frame rendered with wavefront shadow rays.\n");
 		return 1;
 	}
@@ -1067,7 +1143,7 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
 	const acceleration_structure_t* structure = &app->scene.acceleration_structure;
-	if (!w || !w->ray_queue || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays || (wide_tree && !structure->wide_nodes)) {
+	if (!w || !w->ray_directions || !app->shading_pass.use_ray_tracing || app->shading_pass.inline_rays || (wide_tree && !structure->wide_nodes)) {
 		printf("get_traversal_statistics_of_tree() needs a frame rendered with wavefront shadow rays (and the tree it is asked about).\n");
 		return 1;
 	}
@@ -1077,8 +1153,10 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 	(void) finish_frames(app);
 	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, stream);
 	bvh_view bvh = make_bvh_view(structure);
-	if (wide_tree) k_traversal_statistics_wide<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, (const uint4*) structure->wide_nodes, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
-	else k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, w->ray_queue, w->ray_queue_size + kRayCounterCount, w->queue_capacity, counters);
+	// (the queues of the most recent launch - the last band of the last frame - with the sizes the resolve kernel kept)
+	ray_stream rays = {w->ray_directions, w->ray_records, w->ray_origins, w->ray_queue_size + kRayCounterCount, w->queue_capacity, w->thread_bits, w->thread_count};
+	if (wide_tree) k_traversal_statistics_wide<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, (const uint4*) structure->wide_nodes, rays, counters);
+	else k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, rays, counters);
 	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 8, &app->device);
 	(void) hipFree(counters);
 	return failed;
@@ -1086,21 +1164,12 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 
 extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	unsigned long long rays = 0;
-	if (!app->shading_pass.ray_counter || !app->shading_pass.use_ray_tracing || !app->shading_pass.last_frame_traced_rays) return 0;
-	if (!app->shading_pass.inline_rays) {
-		const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
-		const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
-		// (the queue sizes include the null rays of partly used blocks: the shading waves count)
-		// (with block-wise reservation the queue sizes include the null rays of partly used
-		// blocks; the shading waves count their rays then, otherwise those counters stay 0)
-		uint32_t counters[kRayCounterCount];
-		if (!w || !w->ray_queue_size || finish_frames((application_t*) app) || vkr_copy_to_host(counters, w->ray_queue_size + kRayCounterCount, sizeof(counters), &app->device)) return 0;
-		for (uint32_t x = 0; x != 8; ++x) rays += counters[kRayCountOffset + x * kCursorStride];
-		if (rays == 0)
-			for (uint32_t q = 0; q != kRayQueueCount; ++q) rays += counters[q];
-		return rays;
-	}
-	if (vkr_copy_to_host(&rays, app->shading_pass.ray_counter, sizeof(rays), &app->device)) return 0;
+	const shading_pass_t* pass = &app->shading_pass;
+	if (!pass->ray_counter || !pass->use_ray_tracing || !pass->last_frame_traced_rays || !pass->frame_counter) return 0;
+	// (the kernels of the frame - the shading kernel with inline rays, else the resolve kernel of every
+	// band - added their rays to the frame's counter)
+	if (finish_frames((application_t*) app)) return 0;
+	if (vkr_copy_to_host(&rays, (const unsigned long long*) pass->ray_counter + (pass->frame_counter - 1u) % 8u, sizeof(rays), &app->device)) return 0;
 	return rays;
 }
 

@@ -9,90 +9,130 @@ namespace vkr {
 
 // ---- wavefront: trace and resolve (instantiated once, in shading_pass.hip) -------------------
 
-// Persistent waves trace the queued shadow rays.  Few registers, no LDS, no scratch:
-// 8 waves per SIMD hide the latency of the dependent node fetches.
-//  - Queues 64 x ... 64 x + 63 are served only by workgroups that run on XCD x
-//    (workgroup b is placed on XCD b % 8; used for cache affinity only, never for
-//    correctness), so counters and cursors never bounce between the eight L2s.
-//  - A wave claims kRayChunk rays with one atomic on its XCD's cursor and locates
-//    the chunk with a wave-wide prefix sum over the 64 queue sizes of that XCD.
-//  - Lanes whose ray has finished are refilled from the chunk while the others keep
-//    walking (shadow rays differ a lot in length), so lanes stay busy.
-// A ray that reaches the light flips its term's code to kCodeVisible.
-__global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t refill_threshold) {
+// Persistent tracing waves per SIMD that the wide kernel is compiled for (register budget 512 / n)
+#ifndef VKR_WIDE_TRACE_WAVES
+#define VKR_WIDE_TRACE_WAVES 8
+#endif
+constexpr uint32_t kWideTraceWaves = VKR_WIDE_TRACE_WAVES;
+
+// What the tracing kernels read: the queues that the shading kernel filled (shade_params has the
+// same pointers, writable)
+struct ray_stream {
+	const float4* directions;   // [queue][slot]: direction, t_max
+	const uint32_t* records;    // [queue][slot]: thread | code cursor << thread_bits, or kNullRay
+	const float4* origins;      // [thread]: where all rays of that pixel start
+	const uint32_t* sizes;      // slots used per queue
+	uint32_t capacity, thread_bits, thread_count;
+};
+
+// Wave-uniform bookkeeping of the persistent tracing waves: which chunk of which queue the wave
+// works on.  Queues 64 x ... 64 x + 63 are served only by workgroups that run on XCD x (workgroup b
+// is placed on XCD b % 8; used for cache affinity only, never for correctness), so counters and
+// cursors never bounce between the eight L2s.  A wave claims a chunk of rays with one atomic on its
+// XCD's cursor and locates it with a wave-wide prefix sum over the 64 queue sizes of that XCD.
+// (Tried in round 3 and dropped: waves of an XCD that has run dry helping the next XCD.  The scan had
+// to be redone per claim - its registers are needed in the walk - and the kernel got slower,
+// 610 -> 659 us alone at config 3: the XCDs finish within a few percent of each other anyway.)
+struct chunk_cursor {
+	uint32_t xcd, my_size, my_chunks, exclusive, inclusive, total_chunks, chunk_size;
+	size_t chunk_first;  // slot (over all queues) of the first ray of the claimed chunk
+	uint32_t chunk_count, chunk_next;
+	bool chunks_left;
+};
+
+VKR_DEV chunk_cursor make_chunk_cursor(const ray_stream& rays, uint32_t waves_per_workgroup) {
+	chunk_cursor c;
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t xcd = blockIdx.x & 7u;
-	// exclusive prefix sum of the chunk counts of this XCD's 64 queues, one queue per lane
-	const uint32_t my_queue = xcd * 64u + lane;
-	const uint32_t my_size = ray_queue_size[my_queue];
+	// (the host launches multiples of eight workgroups: fewer would leave the queues of an XCD unserved)
+	c.xcd = blockIdx.x & 7u;
+	c.my_size = rays.sizes[c.xcd * 64u + lane];
 	// chunk size: large enough to keep the atomics rare, small enough that every resident
 	// wave of this XCD gets about two chunks (few rays: config 2 queues 0.9 M, config 3 29 M)
-	uint32_t xcd_rays = my_size;
+	uint32_t xcd_rays = c.my_size;
 #pragma unroll
 	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
-	const uint32_t xcd_waves = (gridDim.x / 8u) * 4u;
-	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
-	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
-	uint32_t inclusive = my_chunks;
+	const uint32_t xcd_waves = max(1u, (gridDim.x / 8u) * waves_per_workgroup);
+	c.chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
+	c.my_chunks = (c.my_size + c.chunk_size - 1u) / c.chunk_size;
+	c.inclusive = c.my_chunks;
 #pragma unroll
 	for (int offset = 1; offset < 64; offset <<= 1) {
-		uint32_t other = __shfl_up(inclusive, offset);
-		if (lane >= (uint32_t) offset) inclusive += other;
+		uint32_t other = __shfl_up(c.inclusive, offset);
+		if (lane >= (uint32_t) offset) c.inclusive += other;
 	}
-	const uint32_t exclusive = inclusive - my_chunks;
-	const uint32_t total_chunks = __shfl(inclusive, 63);
+	c.exclusive = c.inclusive - c.my_chunks;
+	c.total_chunks = __shfl(c.inclusive, 63);
+	c.chunk_first = 0;
+	c.chunk_count = c.chunk_next = 0;
+	c.chunks_left = true;
+	return c;
+}
+
+// Claims the next chunk of this XCD for the wave; false when the queues are exhausted
+VKR_DEV bool claim_chunk(chunk_cursor& c, const ray_stream& rays, uint32_t* work_cursors) {
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t chunk = 0;
+	if (lane == 0) chunk = atomicAdd(work_cursors + c.xcd * kCursorStride, 1u);
+	chunk = __builtin_amdgcn_readfirstlane(chunk);
+	if (chunk >= c.total_chunks) { c.chunks_left = false; return false; }
+	uint64_t owner = __ballot(c.my_chunks != 0 && c.exclusive <= chunk && chunk < c.inclusive);
+	int owner_lane = __ffsll((unsigned long long) owner) - 1;
+	uint32_t queue = c.xcd * 64u + (uint32_t) owner_lane;
+	uint32_t first = (chunk - __shfl(c.exclusive, owner_lane)) * c.chunk_size;
+	uint32_t size = __shfl(c.my_size, owner_lane);
+	c.chunk_first = (size_t) queue * rays.capacity + first;
+	c.chunk_count = min(c.chunk_size, size - first);
+	c.chunk_next = 0;
+	return true;
+}
+
+// Persistent waves trace the queued shadow rays on the binary tree.  Few registers, no LDS, no scratch:
+// 8 waves per SIMD hide the latency of the dependent node fetches.  Lanes whose ray has finished are
+// refilled from the chunk while the others keep walking (shadow rays differ a lot in length), so lanes
+// stay busy.  A ray that reaches the light flips its term's code to kCodeVisible.
+__global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t refill_threshold) {
+	chunk_cursor cursor = make_chunk_cursor(rays, 4u);
 	const uint32_t end = bvh.node_count;
-	// wave-uniform description of the claimed chunk
-	const float4* chunk_rays = ray_queue;
-	uint32_t chunk_count = 0, chunk_next = 0;
-	bool chunks_left = true;
 	// per-lane ray; a lane without a ray has the cursor kIdle (the walk and the ballots test the
 	// cursor itself: a separate flag costs two more instructions per step)
 	constexpr uint32_t kIdle = 0xFFFFFFFFu;
 	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
 	grid_ray ray = {o, o};
 	float t_max = 0.0f;
-	uint32_t node = kIdle, code_index = 0;
+	uint32_t node = kIdle;
+	size_t code_index = 0;
 	while (true) {
 		// ---- hand new rays to idle lanes ------------------------------------------------
 		uint64_t idle = __ballot(node == kIdle);
-		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
-			if (chunk_next >= chunk_count) {
-				uint32_t chunk = 0;
-				if (lane == 0) chunk = atomicAdd(work_cursors + xcd * kCursorStride, 1u);
-				chunk = __builtin_amdgcn_readfirstlane(chunk);
-				if (chunk >= total_chunks) { chunks_left = false; break; }
-				uint64_t owner = __ballot(my_chunks != 0 && exclusive <= chunk && chunk < inclusive);
-				int owner_lane = __ffsll((unsigned long long) owner) - 1;
-				uint32_t queue = xcd * 64u + (uint32_t) owner_lane;
-				uint32_t first = (chunk - __shfl(exclusive, owner_lane)) * chunk_size;
-				uint32_t size = __shfl(my_size, owner_lane);
-				chunk_rays = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + first);
-				chunk_count = min(chunk_size, size - first);
-				chunk_next = 0;
-			}
+		while (idle != 0 && (cursor.chunk_next < cursor.chunk_count || cursor.chunks_left)) {
+			if (cursor.chunk_next >= cursor.chunk_count && !claim_chunk(cursor, rays, work_cursors)) break;
 			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-			uint32_t index = chunk_next + rank;
-			if (node == kIdle && index < chunk_count) {
-				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
-				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
-				code_index = __float_as_uint(b.w);
-				ray = make_grid_ray(bvh, o, d);
-				node = 0;
-				if (!(t_max >= 1.0e-3f)) {
-					// empty interval: nothing can block the ray (same rule as any_hit); or a
-					// slot that the shading wave reserved and did not need
-					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
-					node = kIdle;
+			uint32_t index = cursor.chunk_next + rank;
+			if (node == kIdle && index < cursor.chunk_count) {
+				float4 a = rays.directions[cursor.chunk_first + index];
+				uint32_t record = rays.records[cursor.chunk_first + index];
+				// (a slot that the shading wave reserved and did not need holds kNullRay)
+				if (record != kNullRay) {
+					uint32_t tid = ray_record_thread(rays.thread_bits, record);
+					float4 b = rays.origins[tid];
+					o = mk3(b.x, b.y, b.z); d = mk3(a.x, a.y, a.z); t_max = a.w;
+					code_index = code_slot(rays.thread_count, ray_record_cursor(rays.thread_bits, record), tid);
+					ray = make_grid_ray(bvh, o, d);
+					node = 0;
+					if (!(t_max >= 1.0e-3f)) {
+						// empty interval: nothing can block the ray (same rule as any_hit)
+						codes[code_index] = (uint8_t) kCodeVisible;
+						node = kIdle;
+					}
 				}
 			}
-			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
+			cursor.chunk_next += (uint32_t) __popcll((unsigned long long) idle);
 			idle = __ballot(node == kIdle);
 		}
 		uint64_t busy = __ballot(node != kIdle);
 		if (busy == 0) break;
 		// ---- walk until too many lanes have run dry (then refill) -------------------------
-		bool may_refill = chunk_next < chunk_count || chunks_left;
+		bool may_refill = cursor.chunk_next < cursor.chunk_count || cursor.chunks_left;
 		do {
 			if (node != kIdle) {
 				uint4 n = bvh.nodes[node];
@@ -123,41 +163,30 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, const flo
 // build's worst case acceleration_structure_t.wide_stack_need).  A lane whose next item is a
 // triangle waits until `leaf_batch` lanes of the wave have one (or no lane has a node left), so
 // that the triangle test runs with many lanes: the two kinds of work do not share every step.
+// Rays are taken 64 at a time, one per lane: the 20 bytes of a ray are two coalesced wave loads,
+// and the loads of the NEXT batch are issued before the walk of the current one begins, so that the
+// cold read of the ray stream (nothing else in this kernel misses the L2 as often) hides behind the
+// walk instead of standing between two batches; only the origin - a read of the pixel's position
+// that several consecutive batches share - is fetched when a batch starts.  (What that bought: 629 ->
+// 610 us alone at config 3, together with the 20-byte records.  The kernel is bound by the issue of
+// its box tests and by the dependent node fetches, not by this read: profiles/r03_trace.md.)
 // THREADS: 256, or 64 - one wave per workgroup, which then leaves on its own when it finds no more
 // chunks and fits into whatever a SIMD has free.  Measured (profiles/): with the three-wave shading
 // kernels and many rays (config 3) single waves overlap the neighbouring frame's shading better
 // (-2.6 %, config 4 -0.9 %); with few rays (config 2) or two-wave shading kernels launching four
 // times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
 template <uint32_t THREADS>
-__global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, const float4* __restrict__ ray_queue, const uint32_t* __restrict__ ray_queue_size, uint32_t ray_queue_capacity, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
+__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
 	__shared__ uint32_t stack[kWideStackLds * THREADS];
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t xcd = blockIdx.x & 7u;
-	const uint32_t my_queue = xcd * 64u + lane;
-	const uint32_t my_size = ray_queue_size[my_queue];
-	uint32_t xcd_rays = my_size;
-#pragma unroll
-	for (int offset = 32; offset > 0; offset >>= 1) xcd_rays += __shfl_xor(xcd_rays, offset);
-	const uint32_t xcd_waves = (gridDim.x / 8u) * (THREADS / 64u);
-	const uint32_t chunk_size = min(kRayChunk, max(64u, ((xcd_rays / (2u * xcd_waves) + 63u) / 64u) * 64u));
-	const uint32_t my_chunks = (my_size + chunk_size - 1u) / chunk_size;
-	uint32_t inclusive = my_chunks;
-#pragma unroll
-	for (int offset = 1; offset < 64; offset <<= 1) {
-		uint32_t other = __shfl_up(inclusive, offset);
-		if (lane >= (uint32_t) offset) inclusive += other;
-	}
-	const uint32_t exclusive = inclusive - my_chunks;
-	const uint32_t total_chunks = __shfl(inclusive, 63);
-	const float4* chunk_rays = ray_queue;
-	uint32_t chunk_count = 0, chunk_next = 0;
-	bool chunks_left = true;
+	chunk_cursor cursor = make_chunk_cursor(rays, THREADS / 64u);
 	// `item`: what the lane looks at next - a wide node (index), a triangle (kLeafBit | slot) or
 	// nothing (kIdle: the lane has no ray)
 	constexpr uint32_t kIdle = 0xFFFFFFFFu;
 	f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
 	wide_ray ray = {o, o, 0u, 0u, 0u};
 	float t_max = 0.0f;
+	// (byte index of the term's code: below 2^32, the host checks)
 	uint32_t item = kIdle, code_index = 0;
 	// The stack pointer is the lane's LDS address itself (entries are THREADS x 4 bytes apart), so
 	// that a push is a store and a conditional add; entries beyond the LDS part only exist as a
@@ -172,42 +201,47 @@ __global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bv
 #define VKR_STACK_AT(address) (*(lds_u32*) (uintptr_t) (address))
 	uint32_t* my_spill = spill + (size_t) blockIdx.x * THREADS + threadIdx.x;
 	const size_t spill_stride = (size_t) gridDim.x * THREADS;
-	while (true) {
-		// ---- hand new rays to idle lanes (as in trace_shadow_rays) --------------------------
-		uint64_t idle = __ballot(item == kIdle);
-		while (idle != 0 && (chunk_next < chunk_count || chunks_left)) {
-			if (chunk_next >= chunk_count) {
-				uint32_t chunk = 0;
-				if (lane == 0) chunk = atomicAdd(work_cursors + xcd * kCursorStride, 1u);
-				chunk = __builtin_amdgcn_readfirstlane(chunk);
-				if (chunk >= total_chunks) { chunks_left = false; break; }
-				uint64_t owner = __ballot(my_chunks != 0 && exclusive <= chunk && chunk < inclusive);
-				int owner_lane = __ffsll((unsigned long long) owner) - 1;
-				uint32_t queue = xcd * 64u + (uint32_t) owner_lane;
-				uint32_t first = (chunk - __shfl(exclusive, owner_lane)) * chunk_size;
-				uint32_t size = __shfl(my_size, owner_lane);
-				chunk_rays = ray_queue + 2 * ((size_t) queue * ray_queue_capacity + first);
-				chunk_count = min(chunk_size, size - first);
-				chunk_next = 0;
-			}
-			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-			uint32_t index = chunk_next + rank;
-			if (item == kIdle && index < chunk_count) {
-				float4 a = chunk_rays[2 * (size_t) index], b = chunk_rays[2 * (size_t) index + 1];
-				o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z); t_max = a.w;
-				code_index = __float_as_uint(b.w);
+	// the batch after the current one, already on its way: this lane's direction and record word
+	float4 next_direction = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+	uint32_t next_record = kNullRay;
+	// Takes the next (up to) 64 rays of the chunk - claiming a new chunk if this one is used up - and
+	// issues this lane's loads.  false: no work left for this wave.
+	auto fetch_batch = [&]() -> bool {
+		if (cursor.chunk_next >= cursor.chunk_count && (!cursor.chunks_left || !claim_chunk(cursor, rays, work_cursors))) return false;
+		uint32_t index = cursor.chunk_next + lane;
+		next_record = kNullRay;
+		if (index < cursor.chunk_count) {
+			next_direction = rays.directions[cursor.chunk_first + index];
+			next_record = rays.records[cursor.chunk_first + index];
+		}
+		cursor.chunk_next += 64u;
+		return true;
+	};
+	bool batch_pending = fetch_batch();
+	while (batch_pending) {
+		// ---- the prefetched batch becomes the current one ---------------------------------------
+		{
+			float4 a = next_direction;
+			uint32_t record = next_record;
+			uint32_t tid = ray_record_thread(rays.thread_bits, record);
+			float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			// (a slot that the shading wave reserved and did not need holds kNullRay)
+			if (record != kNullRay) b = rays.origins[tid];
+			// ... and the one after it is requested before the walk starts
+			batch_pending = fetch_batch();
+			if (record != kNullRay) {
+				o = mk3(b.x, b.y, b.z); d = mk3(a.x, a.y, a.z); t_max = a.w;
+				code_index = (uint32_t) code_slot(rays.thread_count, ray_record_cursor(rays.thread_bits, record), tid);
 				ray = make_wide_ray(make_grid_ray(bvh, o, d));
 				item = 0;
 				top = my_stack;
 				if (!(t_max >= 1.0e-3f)) {
-					if (code_index != kNullRay) codes[code_index] = (uint8_t) kCodeVisible;
+					// empty interval: nothing can block the ray (same rule as any_hit)
+					codes[code_index] = (uint8_t) kCodeVisible;
 					item = kIdle;
 				}
 			}
-			chunk_next += (uint32_t) __popcll((unsigned long long) idle);
-			idle = __ballot(item == kIdle);
 		}
-		if (__ballot(item != kIdle) == 0) break;
 		// ---- walk until every lane has run dry -----------------------------------------------
 		while (true) {
 			bool at_node = item != kIdle && !(item & kLeafBit);
@@ -216,7 +250,7 @@ __global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bv
 			if ((node_lanes | leaf_lanes) == 0) break;
 			bool pop = false;
 			if (at_node) {
-				const uint4* n = (const uint4*) ((const uint8_t*) wide_nodes + (item << 6));
+				const uint4* n = (const uint4*) ((const uint8_t*) wide_nodes + ((size_t) item << 6));
 				uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
 				bool h0 = wide_ray_box(qx.x, qy.x, qz.x, ray, 1.0e-3f, t_max);
 				bool h1 = wide_ray_box(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
@@ -235,7 +269,8 @@ __global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bv
 					const uint32_t links[4] = {link.w, link.z, link.y, link.x};
 #pragma unroll
 					for (int c = 0; c != 4; ++c) {
-						if (!hits[c]) continue;
+						// (an absent child cannot be hit - unless a NaN slab let it through: never push its link, which is kIdle)
+						if (!hits[c] || links[c] == kWideEmpty) continue;
 						if (top < lds_end) VKR_STACK_AT(top) = links[c];
 						else my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride] = links[c];
 						top += kEntry;
@@ -274,10 +309,14 @@ __global__ void __launch_bounds__(THREADS, 8) trace_shadow_rays_wide(bvh_view bv
 VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 	uint32_t px, py;
 	size_t out_index;
-	if (!locate_pixel(p, blockIdx.x, threadIdx.x, px, py, out_index)) return;
+	if (!locate_pixel(p, p.first_block + blockIdx.x, threadIdx.x, px, py, out_index)) return;
 	uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-	float4 base = p.base_color[tid];
-	f3 color = mk3(base.x, base.y, base.z);
+	// (the colour before the sampled terms is the light display's, +0 without it)
+	f3 color = mk3(0.0f, 0.0f, 0.0f);
+	if (p.show_polygonal_lights) {
+		float4 base = p.base_color[tid];
+		color = mk3(base.x, base.y, base.z);
+	}
 	f3 sum = mk3(0.0f, 0.0f, 0.0f);
 	float rcp_samples = 1.0f / (float) p.sample_count;
 	uint32_t term = 0;
@@ -304,6 +343,8 @@ VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 				value[j] = mk3(p.terms_visible[index], p.terms_visible[index + 1], p.terms_visible[index + 2]);
 			else if (is_term && code[j] == kCodePendingWithHidden)
 				value[j] = mk3(p.terms_hidden[index], p.terms_hidden[index + 1], p.terms_hidden[index + 2]);
+			else if (is_term && code[j] == kCodePendingHiddenNaN)
+				value[j] = mk3(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
 		}
 #pragma unroll
 		for (int j = 0; j != 4; ++j) {
@@ -321,14 +362,27 @@ VKR_DEV void resolve_shadow_terms_body(const shade_params& p) {
 
 // Leaves the ray queues empty for the next frame (saves two fill launches per frame) and
 // keeps a copy of the counters for get_last_ray_count() / get_traversal_statistics().
+// The rays of the launch are added to the frame's counter (get_last_ray_count()): what the shading
+// waves counted (block-wise reservation, where the queue sizes include the null rays of partly used
+// blocks), else the queue sizes.
 __global__ void __launch_bounds__(256) resolve_shadow_terms_and_reset(const shade_params p) {
 	resolve_shadow_terms_body(p);
 	if (blockIdx.x == 0) {
+		__shared__ uint32_t counted, queued;
+		if (threadIdx.x == 0) { counted = 0; queued = 0; }
+		__syncthreads();
 		uint32_t* counters = const_cast<uint32_t*>(p.ray_queue_size);
+		uint32_t my_queued = 0;
 		for (uint32_t i = threadIdx.x; i < kRayCounterCount; i += 256u) {
-			counters[kRayCounterCount + i] = counters[i];
+			uint32_t value = counters[i];
+			if (i < kRayQueueCount) my_queued += value;
+			else if (i >= kRayCountOffset && (i - kRayCountOffset) % kCursorStride == 0 && value) atomicAdd(&counted, value);
+			counters[kRayCounterCount + i] = value;
 			counters[i] = 0;
 		}
+		if (my_queued) atomicAdd(&queued, my_queued);
+		__syncthreads();
+		if (threadIdx.x == 0 && p.ray_counter) atomicAdd(p.ray_counter, (unsigned long long) (counted ? counted : queued));
 	}
 }
 

@@ -231,7 +231,7 @@ class HostScene:
 class Renderer(HostScene):
     """The shading pass on one MI355X."""
 
-    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1, binary_traversal=False, arithmetic=None):
+    def __init__(self, hip_device=0, stream=None, fast_math=False, inline_rays=False, timing_stride=1, frames_in_flight=1, binary_traversal=False, arithmetic=None, band_count=0):
         super().__init__()
         self.binary_traversal = binary_traversal
         self.exchange = None
@@ -244,6 +244,8 @@ class Renderer(HostScene):
         # math mode 0 bit for bit), "fast", "exact" (polynomial; equals the oracle's math mode 1)
         self.arithmetic = arithmetic if arithmetic is not None else ("fast" if fast_math else "libm")
         self.fast_math = self.arithmetic == "fast"
+        # launches per frame with wavefront rays (0: automatic, include/vkr_shading_pass.h band_count)
+        self.band_count = band_count
         self.inline_rays = inline_rays
 
     def create_targets(self):
@@ -256,6 +258,7 @@ class Renderer(HostScene):
         if self.app.shading_pass.constants_device:
             self.lib.destroy_shading_pass(C.byref(self.app.shading_pass), self._dev())
         self.app.shading_pass.arithmetic_mode = ARITHMETIC_MODES[self.arithmetic]
+        self.app.shading_pass.band_count = int(self.band_count)
         self.app.shading_pass.inline_rays = int(self.inline_rays)
         self.app.shading_pass.timing_stride = int(self.timing_stride)
         self.app.shading_pass.frames_in_flight = int(self.frames_in_flight)
