@@ -75,7 +75,8 @@ static inline float vkr_rsqrtf(float x) {
 	t = y * y;
 	return fmaf(y, fmaf(-hx, t, 0.5f), y);
 }
-static inline float rsqrt_f(float x) { return g_oracle_math_mode ? vkr_rsqrtf(x) : 1.0f / sqrtf(x); }
+/* (until round 3 math mode 1 used vkr_rsqrtf; it is kept for tests of the function itself) */
+static inline float rsqrt_f(float x) { return 1.0f / sqrtf(x); }
 static inline v3 normalize3(v3 a) { return scale3(a, rsqrt_f(dot3(a, a))); }
 static inline v2 normalize2(v2 a) { return scale2(a, rsqrt_f(dot2(a, a))); }
 static inline float clamp_f(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -225,15 +226,16 @@ static inline float vkr_atan2f(float y, float x) {
 	return a;
 }
 
-static inline float o_log2(float x) { return g_oracle_math_mode ? vkr_log2f(x) : log2f(x); }
-static inline float o_atan2(float y, float x) { return g_oracle_math_mode ? vkr_atan2f(y, x) : atan2f(y, x); }
-static inline float o_pow_third(float x) { return g_oracle_math_mode ? vkr_cbrt_positive(x) : powf(x, 1.0f / 3.0f); }
+/* Math mode 1 ("deterministic", mirrored bit for bit by the kernels' "exact" arithmetic mode) is
+ * math mode 0 with ONE function replaced, the arctangent: polynomial with explicit FMAs, one
+ * division per arctangent of a ratio.  Everything else - inversesqrt as 1 / sqrt, acos, sin, cos,
+ * log2, pow, atan2 - is the C library in both modes.  (Until round 3 mode 1 replaced all of them;
+ * the Newton inversesqrt turned out to be what moved pixels into and out of the shader's NaN guard.) */
+static inline float o_log2(float x) { return log2f(x); }
+static inline float o_atan2(float y, float x) { return atan2f(y, x); }
+static inline float o_pow_third(float x) { return powf(x, 1.0f / 3.0f); }
 static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : atanf(t); }
-/* acos on [-1, 1] from the [0, 1] form (mode 1) */
-static inline float o_acos(float x) {
-	if (!g_oracle_math_mode) return acosf(x);
-	return (x < 0.0f) ? (O_PI - vkr_acosf_unit(-x)) : vkr_acosf_unit(x);
-}
+static inline float o_acos(float x) { return acosf(x); }
 /* atan(n / d) + (n / d < 0 ? pi : 0), i.e. positive_atan(n / d) of polygon_sampling.glsl:104-111.
  * Mode 0 evaluates exactly that with libm.  Mode 1 is the fused form shared with the GPU: the
  * range reduction divides the smaller by the larger magnitude directly, ONE division instead of
@@ -253,10 +255,7 @@ static inline float o_positive_atan_ratio(float n, float d) {
 	int negative = differs && (big || z > 0.0f);
 	return (differs ? -r : r) + (negative ? O_PI : 0.0f);
 }
-static inline float o_acos_unit(float x) { return g_oracle_math_mode ? vkr_acosf_unit(x) : acosf(x); }
-static inline void o_sincos(float x, float* s, float* c) {
-	if (g_oracle_math_mode) vkr_sincosf(x, s, c);
-	else { *s = sinf(x); *c = cosf(x); }
-}
+static inline float o_acos_unit(float x) { return acosf(x); }
+static inline void o_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 
 #endif

@@ -30,12 +30,13 @@ def compare(gpu, cpu):
 
 
 def main():
+    modes = os.environ.get("VKR_MODES", "libm,exact,fast").split(",")
     configs = [int(c) if c != "target" else c for c in sys.argv[1:]] or [2, 3]
     with tempfile.TemporaryDirectory() as tmp:
         dataset = synthetic.write_dataset(tmp, grid=256, box_count=64, seed=1234, ltc_resolution=64, fresnel_count=51)
         for config in configs:
             oracle_frames = {}
-            for mode in ("libm", "exact", "fast"):
+            for mode in modes:
                 r = renderer.Renderer(arithmetic=mode, frames_in_flight=3, timing_stride=1)
                 renderer.setup_config(r, config, dataset)
                 r.create_targets()
@@ -52,7 +53,7 @@ def main():
                 period = (time.perf_counter() - t0) / steps * 1e3
                 image = r.read_radiance()
                 visibility = r.read_visibility()
-                out = {"config": config, "mode": mode, "ms_per_frame": round(period, 4), "rays": r.last_ray_count()}
+                out = {"config": config, "mode": mode, "library": os.path.basename(os.environ.get("VKR_SHADING_LIBRARY", "libvkr_shading.so")), "ms_per_frame": round(period, 4), "rays": r.last_ray_count()}
                 r.frames_in_flight = 1
                 r.create_pass()
                 for _ in range(12):

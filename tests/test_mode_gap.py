@@ -2,8 +2,8 @@
 
 Math mode 0 (libm) equals the reference's shader source compiled as C++ bit for bit
 (tests/test_reference_live.py, tests/test_oracle_golden.py) and is what the kernels' default "libm"
-mode reproduces bit for bit (tests/test_gpu_full_size.py).  Math mode 1 (polynomial transcendentals)
-is what the kernels' cheaper "exact" mode reproduces bit for bit.  This test states how far the two
+mode reproduces bit for bit (tests/test_gpu_full_size.py).  Math mode 1 (mode 0 with a polynomial
+arctangent) is what the kernels' cheaper "exact" mode reproduces bit for bit.  This test states how far the two
 are apart on the full 1920x1080 frames: the tolerance of BASELINE.json (RMSE <= 1e-4 on
 exposure-scaled linear radiance) holds over all pixels that do not sit on a discontinuity of the
 shader, and every pixel that does is one of the classified kinds of tests/helpers.py (the shader's NaN
@@ -16,7 +16,9 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "tools"))
 
 RMSE_TOLERANCE = 1.0e-4
-# most pixels on a discontinuity that a 1920x1080 frame may have (config 3: 20 guard pixels of 2 073 600)
+# most pixels on a discontinuity that a 1920x1080 frame may have.  (With the arctangent as the only
+# difference between the modes config 3 has none; when mode 1 also had a Newton inversesqrt - rounds 1
+# and 2 - 20 of 2 073 600 pixels entered or left the shader's NaN guard.)
 MAX_OUTLIERS = 48
 
 

@@ -156,7 +156,8 @@ def test_solid_angle_of_octant_and_sampling_inside():
 
 
 def test_deterministic_math_is_accurate():
-    """The polynomial atan / acos / sincos shared with the GPU against float64 libm."""
+    """The functions of math mode 1 - the polynomial arctangent shared with the kernels' "exact" mode, the C
+    library for the rest - against float64."""
     L = oracle.lib()
     oracle.set_math_mode(1)
     try:
@@ -178,12 +179,12 @@ def test_deterministic_math_is_accurate():
             L.oracle_sincos(float(x), C.byref(s), C.byref(c))
             worst = max(worst, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
         assert worst < 2.5e-7
-        # inversesqrt: integer seed + Newton, at most 0.85 ulp over the whole positive range
+        # inversesqrt: 1 / sqrt, two correctly rounded operations (until round 3: integer seed + Newton, 0.85 ulp)
         xs = np.concatenate([rng.uniform(1e-3, 4.0, 20000), np.exp(rng.uniform(-80, 80, 20000))]).astype(np.float32)
         got = np.array([L.oracle_rsqrt(float(x)) for x in xs], np.float32).astype(np.float64)
         ref = 1.0 / np.sqrt(xs.astype(np.float64))
         ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
-        assert np.max(np.abs(got - ref) / ulp) <= 0.9
+        assert np.max(np.abs(got - ref) / ulp) <= 1.5
         # log2 of the range the error display feeds it (1 .. 1e5)
         xs = np.exp(rng.uniform(0.0, np.log(1.0e5), 20000)).astype(np.float32)
         got = np.array([L.oracle_log2(float(x)) for x in xs], np.float64)
@@ -295,9 +296,9 @@ def test_estimators_converge_to_the_same_image(dataset):
 
 
 def test_deterministic_math_mode_renders_the_same_frames_as_libm():
-    """Math mode 1 (polynomial atan/acos/sincos/log2, Newton inversesqrt: what the GPU mirrors
-    bit for bit) against math mode 0 (libm / IEEE: what is pinned against the reference):
-    the same frames to well within the stated tolerance."""
+    """Math mode 1 (math mode 0 with a polynomial arctangent: what the kernels' "exact" mode mirrors
+    bit for bit) against math mode 0 (libm / IEEE: what is pinned against the reference and what the
+    kernels' default mode mirrors bit for bit): the same frames to well within the stated tolerance."""
     from vulkan_renderer_amd import renderer, synthetic
     import golden_cases
     with tempfile.TemporaryDirectory() as d:

@@ -6,13 +6,17 @@
 //      glibc 2.35 evaluates them (glibc_math.h) - operation for operation what the CPU oracle does
 //      in its math mode 0, the mode that is pinned bit for bit against the reference's shader
 //      source compiled as C++.  Frames equal that oracle's in every bit.
-//   0  "exact": the same IEEE operations with cheaper transcendentals: polynomial
-//      atan / acos / sincos / log2 / exp2 with explicit FMAs, one division per arctangent of a
-//      ratio, a seed + Newton inversesqrt.  Every operation is correctly rounded, so the result
-//      is reproducible on any IEEE machine (oracle math mode 1 mirrors it), but a few pixels per
-//      frame land on the other side of a discontinuity (NaN guard, shadow edge) than in mode 2.
-//   1  "fast": v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and -ffp-contract=fast; the
-//      algorithms of mode 0.
+//   0  "exact": mode 2 with ONE function replaced: the arctangent - a fifth of the libm kernel's
+//      time (two divisions, five argument ranges, a degree-11 polynomial without FMAs) - is a
+//      polynomial with explicit FMAs behind a single division of the smaller by the larger magnitude.
+//      Every operation is still correctly rounded, so the result is reproducible on any IEEE machine
+//      (oracle math mode 1 mirrors it bit for bit).  Measured against mode 2 at BASELINE config 3:
+//      RMSE 2.3e-7, no pixel beyond 5e-4, the same NaN-guard pixels (profiles/r03j).  (Until
+//      round 3 this mode also had a Newton inversesqrt and polynomial acos / sincos / log2: the
+//      0.85-ulp inversesqrt is what moved samples across sliver sectors into or out of the shader's
+//      NaN guard - 20 pixels of a config-3 frame - for 5 % of the time.)
+//   1  "fast": v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp), -ffp-contract=fast, polynomial
+//      transcendentals.
 // The reference leaves these precisions to the GLSL driver
 // (src/shaders/polygon_sampling.glsl:79-82).
 #pragma once
@@ -23,7 +27,14 @@
 #define VKR_MATH_MODE 0
 #endif
 #define VKR_FAST_MATH (VKR_MATH_MODE == 1)
-#define VKR_LIBM_MATH (VKR_MATH_MODE == 2)
+// glibc's functions in both IEEE modes ...
+#define VKR_LIBM_MATH (VKR_MATH_MODE != 1)
+// ... except those named here, which keep their polynomial forms - bit 0: arctangent (that is what
+// mode 0 is), bit 1: inversesqrt, bit 2: acos / sincos (profiling aids, profiles/tools/ab_build.sh:
+// pricing the functions one by one is how mode 0 got its definition)
+#ifndef VKR_LIBM_EXCEPT
+#define VKR_LIBM_EXCEPT (VKR_MATH_MODE == 0 ? 1 : 0)
+#endif
 
 #define VKR_DEV __device__ __forceinline__
 
@@ -133,7 +144,7 @@ VKR_DEV float square_root(float x) {
 VKR_DEV float rsqrt(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_rsqf(x);
-#elif VKR_LIBM_MATH
+#elif VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 2)
 	// two correctly rounded operations, as the oracle's math mode 0 (and the reference shader
 	// compiled as C++) evaluates inversesqrt
 	return divide(1.0f, square_root(x));
@@ -151,6 +162,43 @@ VKR_DEV float rsqrt(float x) {
 	// would differ from the oracle's 1 / sqrt; sums of squares are zero or far above 1e-38.)
 	bool ordinary = x >= 1.17549435e-38f && x < __builtin_inff();
 	return ordinary ? y : __builtin_amdgcn_rsqf(x);
+#endif
+}
+
+// Hybrid arithmetic (VKR_FAST_SHADING, measured once in round 3: profiles/r03_hybrid.md): everything that
+// decides WHERE a sample goes - G-buffer decode, LTC matrices, clipping, polygon preparation, sector
+// search, the sampled direction, the ray - stays in the translation unit's IEEE arithmetic, so rays and
+// NaN-guard pixels are those of the exact frame; only the VALUE of a sample (BRDF, densities, MIS
+// weights) uses the approximate reciprocal / root instructions.
+#ifndef VKR_FAST_SHADING
+#define VKR_FAST_SHADING 0
+#endif
+VKR_DEV float value_divide(float a, float b) {
+#if VKR_FAST_SHADING
+	return a * __builtin_amdgcn_rcpf(b);
+#else
+	return divide(a, b);
+#endif
+}
+VKR_DEV float value_rcp(float x) {
+#if VKR_FAST_SHADING
+	return __builtin_amdgcn_rcpf(x);
+#else
+	return rcp(x);
+#endif
+}
+VKR_DEV float value_square_root(float x) {
+#if VKR_FAST_SHADING
+	return __builtin_amdgcn_sqrtf(x);
+#else
+	return square_root(x);
+#endif
+}
+VKR_DEV float value_rsqrt(float x) {
+#if VKR_FAST_SHADING
+	return __builtin_amdgcn_rsqf(x);
+#else
+	return rsqrt(x);
 #endif
 }
 
@@ -207,7 +255,7 @@ VKR_DEV float atan_unit(float z) {
 }
 
 VKR_DEV float arctan(float t) {
-#if VKR_LIBM_MATH
+#if VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 1)
 	return gm_atanf(t);
 #endif
 	float a = fabsf(t);
@@ -223,7 +271,7 @@ VKR_DEV float arctan(float t) {
 // instead of forming the quotient and then its reciprocal.  Operation by operation the mode-1
 // o_positive_atan_ratio of oracle/oracle_math.h (which documents the special cases).
 VKR_DEV float arctan_ratio_positive(float n, float d) {
-#if VKR_LIBM_MATH
+#if VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 1)
 	// as the shader words it: the quotient, its arctangent, pi for a negative quotient
 	// (the quotient of an angle next to pi / 2 is as large as floats get)
 	float tangent = divide_full_range(n, d);
@@ -251,7 +299,7 @@ VKR_DEV float asin_tail(float z, float s) {
 
 // acos for arguments already clamped to [0, 1]
 VKR_DEV float arccos_unit(float x) {
-#if VKR_LIBM_MATH
+#if VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 4)
 	return gm_acosf(x);
 #endif
 	if (x <= 0.5f) {
@@ -333,7 +381,7 @@ VKR_DEV float arctan2(float y, float x) {
 }
 
 VKR_DEV void sincos_poly(float x, float& out_sin, float& out_cos) {
-#if VKR_LIBM_MATH
+#if VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 4)
 	gm_sincosf(x, &out_sin, &out_cos);
 	return;
 #endif

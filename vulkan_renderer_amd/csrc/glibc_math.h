@@ -68,11 +68,15 @@ GM_FN float gm_fabsf(float x) { return gm_float(gm_bits(x) & 0x7FFFFFFFu); }
 
 /* ---- atanf (s_atanf.c) --------------------------------------------------------------------- */
 
-/* Written without branches on the five argument ranges of the source (|x| < 7/16, < 11/16, < 19/16,
- * < 39/16, the rest): every range is "hi - ((t P(t^2) - lo) - t)" of a quotient t = n / d, the first
- * one with n / d = |x| / 1 (exact) and hi = lo = 0, which yields the source's x - x P(x^2) in every
- * bit; the sign of x is applied at the end (all operations are odd-symmetric under round to
- * nearest).  Lanes of a wave then never diverge here. */
+/* Written without branches on the five argument ranges of the source.  The three middle ranges
+ * (7/16 <= |x| < 11/16, < 19/16, < 39/16) reduce with t = (|x| - c) / (1 + c |x|), c = 1/2, 1, 3/2 - the
+ * source's (2|x| - 1) / (2 + |x|) is that quotient with numerator and denominator doubled, which
+ * changes no rounding - and the first range (|x| < 7/16, no reduction) is the same expression with
+ * c = 0: t = |x| / 1.  Only the last range, t = -1 / |x|, is selected separately.  Every range ends in
+ * hi - ((t P(t^2) - lo) - t) with hi + lo = atan(c) (0 for the first range, where the expression equals
+ * the source's x - x P(x^2) in every bit); the sign of x is applied at the end (all operations are
+ * odd-symmetric under round to nearest).  The source's shortcut for |x| < 2^-29 (return x) needs no
+ * case: there t P(t^2) is below half an ulp of t.  Lanes of a wave never diverge here. */
 GM_FN float gm_atanf(float x) {
 	const float at0 = 3.3333334327e-01f, at1 = -2.0000000298e-01f, at2 = 1.4285714924e-01f, at3 = -1.1111110449e-01f,
 		at4 = 9.0908870101e-02f, at5 = -7.6918758452e-02f, at6 = 6.6610731184e-02f, at7 = -5.8335702866e-02f,
@@ -80,21 +84,26 @@ GM_FN float gm_atanf(float x) {
 	uint32_t hx = gm_bits(x), ix = hx & 0x7FFFFFFFu;
 	float ax = gm_float(ix);
 	int r1 = ix >= 0x3EE00000u, r2 = ix >= 0x3F300000u, r3 = ix >= 0x3F980000u, r4 = ix >= 0x401C0000u;
-	float n = r4 ? -1.0f : (r3 ? (ax - 1.5f) : (r2 ? (ax - 1.0f) : (r1 ? (2.0f * ax - 1.0f) : ax)));
-	float d = r4 ? ax : (r3 ? (1.0f + 1.5f * ax) : (r2 ? (ax + 1.0f) : (r1 ? (2.0f + ax) : 1.0f)));
-	float hi = r4 ? 1.5707962513e+00f : (r3 ? 9.8279368877e-01f : (r2 ? 7.8539812565e-01f : (r1 ? 4.6364760399e-01f : 0.0f)));
-	float lo = r4 ? 7.5497894159e-08f : (r3 ? 3.4473217170e-08f : (r2 ? 3.7748947079e-08f : (r1 ? 5.0121582440e-09f : 0.0f)));
+	float c = r1 ? 0.5f : 0.0f;
+	c = r2 ? 1.0f : c;
+	c = r3 ? 1.5f : c;
+	float n = ax - c;
+	float d = 1.0f + c * ax;
+	n = r4 ? -1.0f : n;
+	d = r4 ? ax : d;
+	float hi = r1 ? 4.6364760399e-01f : 0.0f, lo = r1 ? 5.0121582440e-09f : 0.0f;
+	hi = r2 ? 7.8539812565e-01f : hi; lo = r2 ? 3.7748947079e-08f : lo;
+	hi = r3 ? 9.8279368877e-01f : hi; lo = r3 ? 3.4473217170e-08f : lo;
+	hi = r4 ? 1.5707962513e+00f : hi; lo = r4 ? 7.5497894159e-08f : lo;
 	float t = GM_DIVF(n, d);
 	float z = t * t;
 	float w = z * z;
 	float s1 = z * (at0 + w * (at2 + w * (at4 + w * (at6 + w * (at8 + w * at10)))));
 	float s2 = w * (at1 + w * (at3 + w * (at5 + w * (at7 + w * at9))));
 	float r = hi - ((t * (s1 + s2) - lo) - t);
-	/* |x| < 2^-29: x itself; |x| >= 2^25: atanhi[3] + atanlo[3]; NaN: NaN */
-	r = (ix < 0x31000000u) ? ax : r;
-	r = (ix >= 0x4C000000u) ? (1.5707962513e+00f + 7.5497894159e-08f) : r;
-	r = gm_float(gm_bits(r) | (hx & 0x80000000u));
-	return (ix > 0x7F800000u) ? (x + x) : r;
+	/* 2^25 <= |x| <= inf: atanhi[3] + atanlo[3] (a NaN passes through the arithmetic above) */
+	r = (ix - 0x4C000000u <= 0x7F800000u - 0x4C000000u) ? (1.5707962513e+00f + 7.5497894159e-08f) : r;
+	return gm_float(gm_bits(r) | (hx & 0x80000000u));
 }
 
 /* ---- acosf (e_acosf.c; the wrapper only adds errno) ------------------------------------------ */

@@ -9,7 +9,7 @@
 #if VKR_FAST_MATH
 #define VKR_ERROR_LAUNCH_NAME vkr_launch_error_display_fast
 #define VKR_RESOLVE_LAUNCH_NAME vkr_launch_resolve_materials_fast
-#elif VKR_LIBM_MATH
+#elif VKR_MATH_MODE == 2
 #define VKR_ERROR_LAUNCH_NAME vkr_launch_error_display_libm
 #define VKR_RESOLVE_LAUNCH_NAME vkr_launch_resolve_materials_libm
 #else

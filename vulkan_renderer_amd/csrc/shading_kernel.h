@@ -479,7 +479,7 @@ VKR_DEV ltc_coefficients get_ltc_coefficients(const shade_params& p, float fresn
 VKR_DEV float evaluate_ltc_density(const ltc_coefficients& l, f3 dir_shading, float rcp_psa) {
 	f3 dc = shading_to_cosine(l, dir_shading);
 	float len_sq = dot(dc, dc);
-	float density = divide(gmax(0.0f, dc.z) * l.determinant, len_sq * len_sq);
+	float density = value_divide(gmax(0.0f, dc.z) * l.determinant, len_sq * len_sq);
 	return density * rcp_psa;
 }
 
@@ -493,7 +493,8 @@ VKR_DEV float schlick(float f0, float f90, float cos_theta) {
 
 template <bool DIFFUSE, bool SPECULAR>
 VKR_DEV f3 evaluate_brdf(const shading_data& d, f3 incoming) {
-	f3 half_vector = normalize(incoming + d.outgoing);
+	f3 half_sum = incoming + d.outgoing;
+	f3 half_vector = half_sum * value_rsqrt(dot(half_sum, half_sum));
 	float lambert_incoming = dot(d.normal, incoming);
 	float outgoing_dot_half = dot(d.outgoing, half_vector);
 	f3 brdf = mk3(0.0f, 0.0f, 0.0f);
@@ -506,10 +507,10 @@ VKR_DEV f3 evaluate_brdf(const shading_data& d, f3 incoming) {
 		float normal_dot_half = dot(d.normal, half_vector);
 		float a2 = d.roughness * d.roughness;
 		float ggx = fmaf(fmaf(normal_dot_half, a2, -normal_dot_half), normal_dot_half, 1.0f);
-		ggx = divide(a2, ggx * ggx);
-		float masking = lambert_incoming * square_root(fmaf(fmaf(-d.lambert_outgoing, a2, d.lambert_outgoing), d.lambert_outgoing, a2));
-		float shadowing = d.lambert_outgoing * square_root(fmaf(fmaf(-lambert_incoming, a2, lambert_incoming), lambert_incoming, a2));
-		float smith = divide(0.5f, masking + shadowing);
+		ggx = value_divide(a2, ggx * ggx);
+		float masking = lambert_incoming * value_square_root(fmaf(fmaf(-d.lambert_outgoing, a2, d.lambert_outgoing), d.lambert_outgoing, a2));
+		float shadowing = d.lambert_outgoing * value_square_root(fmaf(fmaf(-lambert_incoming, a2, lambert_incoming), lambert_incoming, a2));
+		float smith = value_divide(0.5f, masking + shadowing);
 		float ct = gclamp(outgoing_dot_half, 0.0f, 1.0f);
 		float gs = ggx * smith;
 		brdf = brdf + mk3(gs * schlick(d.fresnel_0.x, 1.0f, ct), gs * schlick(d.fresnel_0.y, 1.0f, ct), gs * schlick(d.fresnel_0.z, 1.0f, ct));
@@ -809,21 +810,21 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 }
 
 VKR_DEV float mis_weight_over_density(int heuristic, float sampled, float other) {
-	if (heuristic == kMisBalance) return rcp(sampled + other);
-	if (heuristic == kMisPower) return divide(sampled, sampled * sampled + other * other);
+	if (heuristic == kMisBalance) return value_rcp(sampled + other);
+	if (heuristic == kMisPower) return value_divide(sampled, sampled * sampled + other * other);
 	return 0.0f;
 }
 
 VKR_DEV float mis_estimate_channel(int heuristic, float in, float s, float sd, float o, float od, float ve) {
 	if (heuristic == kMisWeighted) {
 		float weighted_sum = s * sd + o * od;
-		return divide(s * in, weighted_sum);
+		return value_divide(s * in, weighted_sum);
 	}
 	if (heuristic == kMisOptimalClamped || heuristic == kMisOptimal) {
-		float balance = rcp(sd + od);
+		float balance = value_rcp(sd + od);
 		float weighted_sum = s * sd + o * od;
 		if (heuristic == kMisOptimalClamped) {
-			float weighted = divide(s, weighted_sum);
+			float weighted = value_divide(s, weighted_sum);
 			float mixed = fmaf(-ve, balance, balance);
 			mixed = fmaf(ve, weighted, mixed);
 			return mixed * in;
@@ -1320,7 +1321,7 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 // stubs would be merged by the linker (one mode would silently run for both).
 #if VKR_FAST_MATH
 #define VKR_MODE_NAMESPACE fast_math
-#elif VKR_LIBM_MATH
+#elif VKR_MATH_MODE == 2
 #define VKR_MODE_NAMESPACE libm_math
 #else
 #define VKR_MODE_NAMESPACE exact_math

@@ -20,7 +20,7 @@
 #define VKR_MODE kLightTextures
 #if VKR_FAST_MATH
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_fast_, VKR_STRATEGY, , )
-#elif VKR_LIBM_MATH
+#elif VKR_MATH_MODE == 2
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_libm_, VKR_STRATEGY, , )
 #else
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_textured_exact_, VKR_STRATEGY, , )
@@ -29,7 +29,7 @@
 #define VKR_MODE kErrorNone
 #if VKR_FAST_MATH
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_fast_, VKR_STRATEGY, , )
-#elif VKR_LIBM_MATH
+#elif VKR_MATH_MODE == 2
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_libm_, VKR_STRATEGY, , )
 #else
 #define VKR_LAUNCH_NAME VKR_CAT(vkr_launch_shade_exact_, VKR_STRATEGY, , )
