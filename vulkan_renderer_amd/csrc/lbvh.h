@@ -143,7 +143,10 @@ VKR_DEV bool any_hit(const bvh_view& bvh, f3 o, f3 d, float t_min, float t_max) 
 // acceleration_structure_t.wide_stack_need - spill to global memory.  Any-hit queries are
 // order-independent, so the result (a boolean) is the same as with any other tree.
 constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;
-constexpr uint32_t kWideStackLds = 16;   // stack entries per lane that live in LDS
+#ifndef VKR_WIDE_STACK_LDS
+#define VKR_WIDE_STACK_LDS 16
+#endif
+constexpr uint32_t kWideStackLds = VKR_WIDE_STACK_LDS;   // stack entries per lane that live in LDS
 constexpr uint32_t kWideStackMax = 128;  // deepest stack the kernels are prepared for (else: binary walk)
 // Grid coordinates are 15-bit (0 ... kGridMax): a plane q then sits in bits 8 ... 22 of the float
 // 2^15 + q, i.e. one v_perm_b32 turns a packed pair (lo | hi << 16) into that float - and the byte

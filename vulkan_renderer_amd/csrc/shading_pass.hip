@@ -148,6 +148,11 @@ static void free_wavefront_buffers(wavefront_buffers* w) {
 // device->stream.
 struct frame_context {
 	wavefront_buffers buffers;
+	// VKR_TRACE_STREAM_PRIORITY=high (experiment of round 3, profiles/r03_trace.md): the tracing and the
+	// resolve kernel of a launch run on a stream of their own with the highest priority, behind an event
+	// that marks the end of the shading kernel
+	hipStream_t trace_stream;
+	hipEvent_t shaded;
 	hipEvent_t done;  // recorded behind the last kernel of the frame
 	bool recorded;    // `done` has been recorded: the next frame's resolve is ordered behind it
 	bool pending;     // device->stream has not been made to wait for `done` yet
@@ -191,6 +196,8 @@ static void destroy_wavefront(shading_pass_t* pass) {
 	if (!frames) return;
 	for (frame_context& c : frames->contexts) {
 		if (c.done) { (void) hipEventSynchronize(c.done); (void) hipEventDestroy(c.done); }
+		if (c.trace_stream) { (void) hipStreamSynchronize(c.trace_stream); (void) hipStreamDestroy(c.trace_stream); }
+		if (c.shaded) (void) hipEventDestroy(c.shaded);
 		free_wavefront_buffers(&c.buffers);
 	}
 	if (frames->inputs_ready) (void) hipEventDestroy(frames->inputs_ready);
@@ -219,6 +226,17 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
 	frames->wavefront_budget_mib = environment_knob("VKR_WAVEFRONT_BUDGET_MIB", 24576u, 64u, 262144u);
 	frames->band_count = environment_knob("VKR_BAND_COUNT", 0u, 0u, 4096u);
+	const char* priority = getenv("VKR_TRACE_STREAM_PRIORITY");
+	if (priority && strcmp(priority, "high") == 0) {
+		int least = 0, greatest = 0;
+		(void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+		for (frame_context& c : frames->contexts)
+			if (hipStreamCreateWithPriority(&c.trace_stream, hipStreamNonBlocking, greatest) != hipSuccess || hipEventCreateWithFlags(&c.shaded, kSyncEventFlags) != hipSuccess) {
+				printf("Failed to create the high-priority tracing streams.\n");
+				destroy_wavefront(pass);
+				return NULL;
+			}
+	}
 	return frames;
 }
 
@@ -831,6 +849,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			}
 			frame = &frames->contexts[index];
 			frames->last = index;
+			// (with a tracing stream the previous launch of this context did not end on this stream)
+			if (pipelined && frame->trace_stream && frame->recorded) (void) hipStreamWaitEvent(stream, frame->done, 0);
 			if (ensure_wavefront(&frame->buffers, blocks_per_band * 256u, max_terms, p.light_count, hidden_terms, base_color, stream)) return 1;
 			if (use_wide_tree && ensure_spill(&frame->buffers, app->scene.acceleration_structure.wide_stack_need, frames->wide_stack_lds, trace_blocks * 256u)) return 1;
 			const wavefront_buffers* w = &frame->buffers;
@@ -858,6 +878,14 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			: g_launchers[pass->arithmetic_mode + (p.light_texture_descriptors ? 3 : 0)][strategy](technique, capacity, ray_mode, &p, p.block_count, stream);
 		if (timed && band + 1 == band_count) (void) hipEventRecord(ring[3 * slot + 1], stream);
 		if (status == 0 && is_deferred(ray_mode)) {
+			if (pipelined && frame->trace_stream) {
+				// the rest of the launch moves to the high-priority stream; the next launch that reuses this context's
+				// frame stream is ordered behind `done` below (which is then recorded on the tracing stream)
+				(void) hipEventRecord(frame->shaded, stream);
+				(void) hipStreamWaitEvent(frame->trace_stream, frame->shaded, 0);
+				stream = frame->trace_stream;
+				pass->last_frame_stream = stream;
+			}
 			ray_stream rays = {p.ray_directions, p.ray_records, p.ray_origins, p.ray_queue_size, p.ray_queue_capacity, p.ray_thread_bits, p.thread_count};
 			if (use_wide_tree) {
 				const uint4* wide_nodes = (const uint4*) app->scene.acceleration_structure.wide_nodes;
@@ -866,9 +894,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 7;
 				if (frames->trace_single_waves != 2u) single_waves = frames->trace_single_waves != 0u;
 				if (single_waves)
-					trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
+					trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
 				else
-					trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
+					trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
 			}
 			else
 				trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, rays, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);

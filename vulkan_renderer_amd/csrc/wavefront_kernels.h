@@ -15,6 +15,14 @@ namespace vkr {
 #endif
 constexpr uint32_t kWideTraceWaves = VKR_WIDE_TRACE_WAVES;
 
+// Experiment of round 3 (north_star: "LDS-staged BVH node packets"; profiles/r03_trace.md has the
+// measurement): the first VKR_LDS_TOP_NODES nodes of the four-wide tree - its top levels, breadth
+// first: 1 + 4 + 16 = 21 nodes are three levels - are copied into LDS by every workgroup and fetched
+// from there (flat loads: the address decides between LDS and global memory).  0: off (the default).
+#ifndef VKR_LDS_TOP_NODES
+#define VKR_LDS_TOP_NODES 0
+#endif
+
 // What the tracing kernels read: the queues that the shading kernel filled (shade_params has the
 // same pointers, writable)
 struct ray_stream {
@@ -176,8 +184,16 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, ray_strea
 // (-2.6 %, config 4 -0.9 %); with few rays (config 2) or two-wave shading kernels launching four
 // times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
 template <uint32_t THREADS>
-__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
+__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, uint32_t wide_node_count, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
 	__shared__ uint32_t stack[kWideStackLds * THREADS];
+#if VKR_LDS_TOP_NODES
+	__shared__ uint4 top_nodes[VKR_LDS_TOP_NODES * 4];
+	const uint32_t top_count = min((uint32_t) VKR_LDS_TOP_NODES, wide_node_count);
+	for (uint32_t i = threadIdx.x; i < top_count * 4u; i += THREADS) top_nodes[i] = wide_nodes[i];
+	__syncthreads();
+#else
+	(void) wide_node_count;
+#endif
 	const uint32_t lane = threadIdx.x & 63u;
 	chunk_cursor cursor = make_chunk_cursor(rays, THREADS / 64u);
 	// `item`: what the lane looks at next - a wide node (index), a triangle (kLeafBit | slot) or
@@ -251,6 +267,9 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 			bool pop = false;
 			if (at_node) {
 				const uint4* n = (const uint4*) ((const uint8_t*) wide_nodes + ((size_t) item << 6));
+#if VKR_LDS_TOP_NODES
+				if (item < top_count) n = top_nodes + 4u * item;
+#endif
 				uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
 				bool h0 = wide_ray_box(qx.x, qy.x, qz.x, ray, 1.0e-3f, t_max);
 				bool h1 = wide_ray_box(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
