@@ -125,16 +125,23 @@ VKR_DEV float rcp(float x) {
 // instructions, 5 of which rescale denormal inputs; arguments here are sums of products
 // of O(1) quantities (exactly 0 or far above 1e-38), so this is the same selection
 // between s - 1 ulp, s and s + 1 ulp around the 1-ulp hardware result, without the rescaling.
-VKR_DEV float square_root(float x) {
-#if VKR_FAST_MATH
-	return __builtin_amdgcn_sqrtf(x);
-#else
+// The selection between the hardware result and its two neighbours.  For +-0 and +inf the
+// "neighbours" are NaN bit patterns (or, above +0, the smallest denormal, whose residual is 0), every
+// comparison with their residuals is false and the hardware result - the argument itself - stays.
+VKR_DEV float square_root_unguarded(float x) {
 	float s = __builtin_amdgcn_sqrtf(x);
 	float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
 	float residual_below = fmaf(-below, s, x), residual_above = fmaf(-above, s, x);
 	s = (residual_below <= 0.0f) ? below : s;
 	s = (residual_above > 0.0f) ? above : s;
-	// +-0 and +inf map to themselves (the neighbours above are meaningless for them)
+	return s;
+}
+VKR_DEV float square_root(float x) {
+#if VKR_FAST_MATH
+	return __builtin_amdgcn_sqrtf(x);
+#else
+	float s = square_root_unguarded(x);
+	// +-0 and +inf map to themselves (spelled out; square_root_unguarded explains why it would hold anyway)
 	return (x == 0.0f || x == __builtin_inff()) ? x : s;
 #endif
 }
@@ -147,7 +154,7 @@ VKR_DEV float rsqrt(float x) {
 #elif VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 2)
 	// two correctly rounded operations, as the oracle's math mode 0 (and the reference shader
 	// compiled as C++) evaluates inversesqrt
-	return divide(1.0f, square_root(x));
+	return divide(1.0f, square_root_unguarded(x));
 #else
 	float hx = 0.5f * x;
 	float y = __uint_as_float(0x5F3759DFu - (__float_as_uint(x) >> 1));

@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(256) k_evaluate_arithmetic(uint32_t operation,
 	case 9: out[i] = gm_log2f(x); break;
 	case 10: out[i] = gm_powf(x, y); break;
 	case 11: out[i] = gm_atan2f(x, y); break;
-	default: out[i] = divide(1.0f, square_root(x)); break;
+	default: out[i] = rsqrt(x); break;  // (this unit is compiled in an IEEE mode: 1 / sqrt)
 	}
 }
 
