@@ -393,6 +393,12 @@ VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_t
 	12 inversesqrt as 1 / sqrt.  a, b (may be NULL for unary operations) and out are host arrays of
 	`count` floats.  0 on success. */
 VKR_API int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count);
+/*! Two one-argument operations of evaluate_device_arithmetic (1 square_root, 4 the compiler's sqrtf, 5 atanf,
+	12 inversesqrt as divide(1, square_root), plus 16: the compiler's 1 / sqrtf) evaluated on the device
+	for the `count` (<= 2^32) consecutive bit patterns from `first_bits` on - e.g. every float - and
+	compared bit for bit (NaNs equal each other).  out[0]: arguments with different results, out[1]: the
+	smallest such bit pattern (all ones if none).  How a cheaper chain is admitted into the IEEE modes. */
+VKR_API int compare_device_arithmetic(const device_t* device, uint32_t operation_a, uint32_t operation_b, uint32_t first_bits, uint64_t count, uint64_t out_mismatches_and_first[2]);
 
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,
 	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,

@@ -102,3 +102,18 @@ def test_square_root_is_correctly_rounded(device):
     specials = np.array([0.0, -0.0, np.inf, np.nan, -1.0, 1.0, 4.0], np.float32)
     with np.errstate(all="ignore"):
         assert same_bits(evaluate(device, 1, specials), np.sqrt(specials)).all()
+
+
+def test_square_root_and_inverse_square_root_are_the_ieee_results_for_every_float_of_the_working_range(device):
+    """Not a sample: every float with an exponent in [-100, 100) - 1.7 billion bit patterns - goes through the
+    kernels' square_root() and inversesqrt (divide(1, square_root)) and through the compiler's correctly
+    rounded sqrtf / 1 / sqrtf on the device (compare_device_arithmetic of the C-ABI); plus zeros, infinity,
+    NaN and negative numbers."""
+    out = (C.c_uint64 * 2)()
+    first, last = (127 - 100) << 23, (127 + 100) << 23
+    for mine, theirs in ((1, 4), (12, 16)):
+        assert device.lib.compare_device_arithmetic(C.byref(device.app.device), mine, theirs, first, last - first, out) == 0
+        assert out[0] == 0, (mine, theirs, int(out[0]), hex(int(out[1])))
+        for special in (0x00000000, 0x80000000, 0x7F800000, 0x7FC00000, 0xBF800000, 0xFF800000):
+            assert device.lib.compare_device_arithmetic(C.byref(device.app.device), mine, theirs, special, 1, out) == 0
+            assert out[0] == 0, (mine, theirs, hex(special))

@@ -136,6 +136,9 @@ VKR_DEV float square_root_unguarded(float x) {
 	s = (residual_above > 0.0f) ? above : s;
 	return s;
 }
+// (Round 3 tried Markstein's coupled iterations - sqrt and 1 / sqrt from one v_rsq_f32 estimate, 38 instead of
+// 65 clocks per inversesqrt: the last FMA does not always land on the correctly rounded value (a config-3 frame
+// differed from the oracle's, RMSE 1.5e-3) and the kernel got 1 % faster; profiles/r03k/markstein_roots.jsonl.)
 VKR_DEV float square_root(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_sqrtf(x);

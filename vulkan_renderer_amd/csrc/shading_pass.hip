@@ -1129,8 +1129,50 @@ __global__ void __launch_bounds__(256) k_evaluate_arithmetic(uint32_t operation,
 	case 9: out[i] = gm_log2f(x); break;
 	case 10: out[i] = gm_powf(x, y); break;
 	case 11: out[i] = gm_atan2f(x, y); break;
-	default: out[i] = rsqrt(x); break;  // (this unit is compiled in an IEEE mode: 1 / sqrt)
+	case 12: out[i] = divide(1.0f, square_root_unguarded(x)); break;
+	default: out[i] = rsqrt(x); break;  // (what the kernels of this unit's arithmetic mode use)
 	}
+}
+
+// compare_device_arithmetic(): two one-argument operations of k_evaluate_arithmetic over a range of bit
+// patterns, without moving the arguments through the host
+__device__ __forceinline__ float evaluate_unary(uint32_t operation, float x) {
+	switch (operation) {
+	case 1: return square_root(x);
+	case 4: return sqrtf(x);
+	case 5: return gm_atanf(x);
+	case 12: return divide(1.0f, square_root_unguarded(x));
+	case 16: return 1.0f / sqrtf(x);
+	default: return rsqrt(x);
+	}
+}
+__global__ void __launch_bounds__(256) k_compare_arithmetic(uint32_t operation_a, uint32_t operation_b, uint32_t first_bits, uint64_t count, unsigned long long* out) {
+	unsigned long long mismatches = 0;
+	for (uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t) gridDim.x * 256u) {
+		uint32_t bits = first_bits + (uint32_t) i;
+		float x = __uint_as_float(bits), a = evaluate_unary(operation_a, x), b = evaluate_unary(operation_b, x);
+		bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+		if (!same) { ++mismatches; atomicMin(out + 1, (unsigned long long) bits); }
+	}
+	if (mismatches) atomicAdd(out, mismatches);
+}
+
+extern "C" int compare_device_arithmetic(const device_t* device, uint32_t operation_a, uint32_t operation_b, uint32_t first_bits, uint64_t count, uint64_t out_mismatches_and_first[2]) {
+	if (!device || !out_mismatches_and_first || count > (1ull << 32)) {
+		printf("compare_device_arithmetic() needs a device, an output and at most 2^32 arguments.\n");
+		return 1;
+	}
+	unsigned long long* counters = NULL;
+	if (hip_failed(hipMalloc(&counters, 2 * sizeof(unsigned long long)), "allocating counters")) return 1;
+	hipStream_t stream = (hipStream_t) device->stream;
+	unsigned long long initial[2] = {0ull, ~0ull};
+	int failed = hip_failed(hipMemcpyAsync(counters, initial, sizeof(initial), hipMemcpyHostToDevice, stream), "clearing counters");
+	if (!failed) {
+		k_compare_arithmetic<<<8192, 256, 0, stream>>>(operation_a, operation_b, first_bits, count, counters);
+		failed = vkr_copy_to_host(out_mismatches_and_first, counters, 2 * sizeof(unsigned long long), device);
+	}
+	(void) hipFree(counters);
+	return failed;
 }
 
 extern "C" int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count) {
