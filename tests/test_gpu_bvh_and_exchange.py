@@ -262,8 +262,8 @@ def test_slab_exchange_with_one_rank_reproduces_the_frame(dataset, slab_format):
 
 
 @pytest.mark.parametrize("slab_format", ["rgba32f", "rgb8"])
-@pytest.mark.parametrize("rank_count, tile_size, frames_in_flight", [(2, 32, 3), (2, 16, 2), (4, 64, 3), (3, 32, 1)])
-def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_count, tile_size, frames_in_flight, slab_format):
+@pytest.mark.parametrize("rank_count, tile_size, frames_in_flight, band_count", [(2, 32, 3, 0), (2, 16, 2, 2), (4, 64, 3, 0), (3, 32, 1, 0)])
+def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_count, tile_size, frames_in_flight, band_count, slab_format):
     """render_and_exchange_frame() with rank_count > 1 on ONE device: every rank is an application_t of its
     own, driven by its own thread; the collective is the local one (device-to-device copies with a
     host-side rendezvous, create_local_slab_exchange) where RCCL would refuse two ranks on one
@@ -289,7 +289,8 @@ def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_coun
 
     def run_rank(rank):
         try:
-            r = renderer.Renderer(frames_in_flight=frames_in_flight)
+            # (band_count 2: every rank renders its slab as two launches on two streams; the exchange waits for the last)
+            r = renderer.Renderer(frames_in_flight=frames_in_flight, band_count=band_count)
             renderer.setup_config(r, 3, dataset, width=width, height=height, acceleration_structure="sah_device")
             r.set_tiles(tile_size, rank, rank_count, slab_layout=True)
             r.create_targets()
