@@ -362,7 +362,7 @@ def run_workload(job, config, primary):
     pass_ms = float(np.mean(period_ms if (pipelined and period_ms) else launch_ms)) if launch_ms else float("nan")
     # the reference's protocol (src/frame_timer.c:24,47-72, main.c:1958-1959): the median of at least 100 frame
     # times; here of the periods between the ends of consecutive timed frames inside the timed region
-    median_ms = job.max_over_ranks(float(np.median(period_ms))) if (period_ms and steps >= 100 and len(period_ms) >= 12) else None
+    median_ms = job.max_over_ranks(float(np.median(period_ms))) if (period_ms and steps >= 100 and len(period_ms) >= 8) else None
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
