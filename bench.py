@@ -57,13 +57,12 @@ def kernel_source_hash():
     import hashlib
     base = os.path.join(ROOT, "vulkan_renderer_amd", "csrc")
     h = hashlib.sha256()
-    for directory, _, files in sorted(os.walk(base)):
-        if os.path.basename(directory) in ("build", "ab", "__pycache__"):
-            continue
-        for name in sorted(files):
-            if name.endswith((".h", ".hip", ".inc", ".c")) or name == "Makefile":
-                h.update(name.encode())
-                h.update(open(os.path.join(directory, name), "rb").read())
+    # (the device code: headers, .hip units, the generated clipping table and the flags they are built with;
+    # the C host code under host/ does not change what a kernel executes)
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".h", ".hip", ".inc")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(base, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -149,6 +149,11 @@ static int gather_with_copies(void* context, uint32_t rank, uint32_t set, const 
 	int reused = group->frames[rank] >= group->exchanges[rank]->set_count;
 	for (uint32_t q = 0; q != group->rank_count && !failed; ++q) {
 		const slab_exchange_t* peer = group->exchanges[q];
+		if (!peer || !peer->gathered[set]) {
+			printf("Rank %u of the local slab group has no exchange (its create_local_slab_exchange failed).\n", q);
+			failed = 1;
+			break;
+		}
 		if (reused && q != rank) failed = hip_failed(hipStreamWaitEvent(s, (hipEvent_t) peer->assembled[set], 0), "waiting for a peer's scatter");
 		if (!failed) failed = hip_failed(hipMemcpyAsync((uint8_t*) peer->gathered[set] + (size_t) rank * send_bytes, send, (size_t) send_bytes, hipMemcpyDeviceToDevice, s), "copying a slab to a peer");
 	}
