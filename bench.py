@@ -57,12 +57,12 @@ def kernel_source_hash():
     import hashlib
     base = os.path.join(ROOT, "vulkan_renderer_amd", "csrc")
     h = hashlib.sha256()
-    # (the device code: headers, .hip units, the generated clipping table and the flags they are built with;
-    # the C host code under host/ does not change what a kernel executes)
-    for name in sorted(os.listdir(base)):
-        if name.endswith((".h", ".hip", ".inc")) or name == "Makefile":
-            h.update(name.encode())
-            h.update(open(os.path.join(base, name), "rb").read())
+    # (what the shading, tracing and resolve kernels are compiled from, and the flags; host code - host/*.c,
+    # shading_pass.hip around the kernels it instantiates - and the BVH builder do not change what they execute)
+    for name in ("shading_kernel.h", "polygon_sampling.h", "related_work.h", "device_math.h", "glibc_math.h", "lbvh.h", "clip_cases.inc",
+                 "wavefront_kernels.h", "shading_variants.hip", "Makefile"):
+        h.update(name.encode())
+        h.update(open(os.path.join(base, name), "rb").read())
     return h.hexdigest()[:16]
 
 
