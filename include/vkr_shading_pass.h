@@ -394,7 +394,8 @@ VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_t
 	`count` floats.  0 on success. */
 VKR_API int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count);
 /*! Two one-argument operations of evaluate_device_arithmetic (1 square_root, 4 the compiler's sqrtf, 5 atanf,
-	12 inversesqrt as divide(1, square_root), plus 16: the compiler's 1 / sqrtf) evaluated on the device
+	12 inversesqrt as divide(1, square_root), plus 16: the compiler's 1 / sqrtf, 17: atanf with its argument
+	range from the LDS table, as the libm kernels evaluate it) evaluated on the device
 	for the `count` (<= 2^32) consecutive bit patterns from `first_bits` on - e.g. every float - and
 	compared bit for bit (NaNs equal each other).  out[0]: arguments with different results, out[1]: the
 	smallest such bit pattern (all ones if none).  How a cheaper chain is admitted into the IEEE modes. */

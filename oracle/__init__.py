@@ -118,7 +118,7 @@ def set_math_mode(mode):
 
 
 # operation codes of oracle_libm.c == evaluate_device_arithmetic (include/vkr_shading_pass.h)
-LIBM_OPERATIONS = {"atan": 5, "acos": 6, "sin": 7, "cos": 8, "log2": 9, "pow": 10, "atan2": 11, "inverse_sqrt": 12}
+LIBM_OPERATIONS = {"atan": 5, "acos": 6, "sin": 7, "cos": 8, "log2": 9, "pow": 10, "atan2": 11, "inverse_sqrt": 12, "atan_rows": 13}
 
 
 def libm_evaluate(operation, a, b=None, port=False):

@@ -9,11 +9,23 @@
 #include <stddef.h>
 
 /* operation codes shared with evaluate_device_arithmetic (include/vkr_shading_pass.h) */
-enum { op_atan = 5, op_acos = 6, op_sin = 7, op_cos = 8, op_log2 = 9, op_pow = 10, op_atan2 = 11, op_inverse_sqrt = 12 };
+enum { op_atan = 5, op_acos = 6, op_sin = 7, op_cos = 8, op_log2 = 9, op_pow = 10, op_atan2 = 11, op_inverse_sqrt = 12,
+	/* the arctangent with its argument range looked up in a table (what the kernels run, with the table in LDS) */
+	op_atan_rows = 13 };
+
+static gm_atan_row_t g_atan_rows[GM_ATAN_ROW_COUNT];
+static int g_atan_rows_filled = 0;
+static const gm_atan_row_t* atan_rows(void) {
+	if (!g_atan_rows_filled) {
+		for (uint32_t i = 0; i != GM_ATAN_ROW_COUNT; ++i) g_atan_rows[i] = gm_atan_row(i);
+		g_atan_rows_filled = 1;
+	}
+	return g_atan_rows;
+}
 
 static float by_libm(int op, float a, float b) {
 	switch (op) {
-	case op_atan: return atanf(a);
+	case op_atan: case op_atan_rows: return atanf(a);
 	case op_acos: return acosf(a);
 	case op_sin: return sinf(a);
 	case op_cos: return cosf(a);
@@ -27,6 +39,7 @@ static float by_libm(int op, float a, float b) {
 static float by_port(int op, float a, float b) {
 	switch (op) {
 	case op_atan: return gm_atanf(a);
+	case op_atan_rows: return gm_atanf_rows(a, g_atan_rows);
 	case op_acos: return gm_acosf(a);
 	case op_sin: return gm_sinf(a);
 	case op_cos: return gm_cosf(a);
@@ -39,6 +52,7 @@ static float by_port(int op, float a, float b) {
 
 /* out[i] = f(a[i], b[i]) (b may be NULL for one-argument functions) */
 void oracle_libm_evaluate(int op, int use_port, const float* a, const float* b, float* out, size_t count) {
+	(void) atan_rows();
 #pragma omp parallel for schedule(static)
 	for (ptrdiff_t i = 0; i < (ptrdiff_t) count; ++i)
 		out[i] = use_port ? by_port(op, a[i], b ? b[i] : 0.0f) : by_libm(op, a[i], b ? b[i] : 0.0f);
@@ -48,6 +62,7 @@ void oracle_libm_evaluate(int op, int use_port, const float* a, const float* b, 
  * (NaNs compare equal); *first_mismatch receives the bit pattern of one of them */
 size_t oracle_libm_count_mismatches(int op, uint32_t first_bits, uint32_t stride, size_t count, float second_argument, uint32_t* first_mismatch) {
 	size_t mismatches = 0;
+	(void) atan_rows();
 #pragma omp parallel for schedule(static) reduction(+ : mismatches)
 	for (ptrdiff_t i = 0; i < (ptrdiff_t) count; ++i) {
 		uint32_t bits = first_bits + (uint32_t) i * stride;

@@ -108,6 +108,8 @@ static uint64_t check_binary(const char* name, binary_t ours, binary_t theirs, u
 	return mismatches;
 }
 
+static gm_atan_row_t g_rows[GM_ATAN_ROW_COUNT];
+static float ours_atan_rows(float x) { return gm_atanf_rows(x, g_rows); }
 static float ours_sin_of_sincos(float x) { float s, c; gm_sincosf(x, &s, &c); return s; }
 static float ours_cos_of_sincos(float x) { float s, c; gm_sincosf(x, &s, &c); return c; }
 static float ours_pow_third(float x) { return gm_powf(x, 1.0f / 3.0f); }
@@ -122,7 +124,9 @@ int main(int argc, char** argv) {
 	uint64_t pairs = (argc > 2 ? strtoull(argv[2], NULL, 10) : 2000ull) * 1000000ull;
 	if (stride == 0 || 65536u % stride != 0) stride = 1;
 	uint64_t bad = 0;
+	for (uint32_t i = 0; i != GM_ATAN_ROW_COUNT; ++i) g_rows[i] = gm_atan_row(i);
 	bad += check_unary("atanf", gm_atanf, atanf, stride);
+	bad += check_unary("atanf.t", ours_atan_rows, atanf, stride);
 	bad += check_unary("acosf", gm_acosf, acosf, stride);
 	bad += check_unary("sinf", gm_sinf, sinf, stride);
 	bad += check_unary("cosf", gm_cosf, cosf, stride);

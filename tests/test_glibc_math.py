@@ -17,7 +17,7 @@ import oracle
 UNARY = ["atan", "acos", "sin", "cos", "log2", "inverse_sqrt"]
 
 
-@pytest.mark.parametrize("operation", UNARY + ["pow"])
+@pytest.mark.parametrize("operation", UNARY + ["pow", "atan_rows"])
 def test_restatement_equals_the_c_library_on_the_cpu(operation):
     second = {"pow": 1.0 / 3.0}.get(operation, 0.0)
     # every 64th bit pattern of the whole range ...
@@ -102,3 +102,12 @@ def test_two_argument_device_functions_equal_the_c_library_of_the_host(operation
         special = ~np.isfinite(a) | ~np.isfinite(b) | (a == 0) | (b == 0)
         same = same | ~(window | special)
     assert same.all(), (operation, int((~same).sum()), a[~same][:4], b[~same][:4], gpu[~same][:4], cpu[~same][:4])
+
+
+@pytest.mark.gpu
+def test_the_arctangent_with_its_range_table_in_lds_equals_the_plain_one_for_every_float(device):
+    """What the libm kernels run (gm_atanf_rows, table in LDS) against gm_atanf - which the test above compares
+    with the host's C library - over all 2^32 bit patterns, on the device (compare_device_arithmetic)."""
+    out = (C.c_uint64 * 2)()
+    assert device.lib.compare_device_arithmetic(C.byref(device.app.device), 17, 5, 0, 1 << 32, out) == 0
+    assert out[0] == 0, (int(out[0]), hex(int(out[1])))

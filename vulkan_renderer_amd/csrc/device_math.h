@@ -248,6 +248,29 @@ VKR_DEV f3 mul_transposed(const m43& m, f3 d) { return mk3(dot(m.c[0], d), dot(m
 
 namespace vkr {
 
+// VKR_ATAN_TABLE (on wherever glibc's arctangent is used, i.e. in the libm mode): its argument range is looked up in
+// an LDS table of 81 rows (1.3 KB per workgroup, fill_atan_rows() at the start of the kernel) instead of found with
+// four compares and sixteen selects per call: gm_atanf_rows in glibc_math.h, equal to atanf for all 2^32 arguments
+// like gm_atanf.  4.5 % fewer instructions in the config-3 kernel: 1.676 -> 1.610 ms per frame; the V = 7 kernel of
+// config 4 loses one of its ten waves per CU to the table and still gains 3 % (profiles/r03k/atan_table.jsonl).
+#ifndef VKR_ATAN_TABLE
+#define VKR_ATAN_TABLE (VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 1))
+#endif
+#if VKR_ATAN_TABLE
+VKR_DEV gm_atan_row_t* atan_rows() {
+	__shared__ gm_atan_row_t rows[GM_ATAN_ROW_COUNT];
+	return rows;
+}
+VKR_DEV void fill_atan_rows() {
+	for (uint32_t i = threadIdx.x; i < GM_ATAN_ROW_COUNT; i += blockDim.x) atan_rows()[i] = gm_atan_row(i);
+	__syncthreads();
+}
+VKR_DEV float libm_arctangent(float t) { return gm_atanf_rows(t, atan_rows()); }
+#else
+VKR_DEV void fill_atan_rows() {}
+VKR_DEV float libm_arctangent(float t) { return gm_atanf(t); }
+#endif
+
 // ---- polynomial transcendentals (coefficients: oracle/tools/fit_math.py) -------
 
 VKR_DEV float atan_unit(float z) {
@@ -266,7 +289,7 @@ VKR_DEV float atan_unit(float z) {
 
 VKR_DEV float arctan(float t) {
 #if VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 1)
-	return gm_atanf(t);
+	return libm_arctangent(t);
 #endif
 	float a = fabsf(t);
 	bool big = a > 1.0f;
@@ -285,7 +308,7 @@ VKR_DEV float arctan_ratio_positive(float n, float d) {
 	// as the shader words it: the quotient, its arctangent, pi for a negative quotient
 	// (the quotient of an angle next to pi / 2 is as large as floats get)
 	float tangent = divide_full_range(n, d);
-	return gm_atanf(tangent) + ((tangent < 0.0f) ? kPi : 0.0f);
+	return libm_arctangent(tangent) + ((tangent < 0.0f) ? kPi : 0.0f);
 #endif
 	float a = fabsf(n), b = fabsf(d);
 	bool big = a > b;

@@ -106,6 +106,48 @@ GM_FN float gm_atanf(float x) {
 	return gm_float(gm_bits(r) | (hx & 0x80000000u));
 }
 
+/* The same function with the argument range looked up instead of compared: `rows` holds, for every
+ * value of the top bits of |x| that the five ranges can be told apart by (their bounds 7/16, 11/16,
+ * 19/16, 39/16 are multiples of 2^18 as bit patterns), the four numbers of the range:
+ * (c, s, atanhi, atanlo) with t = (s |x| - c) / (c |x| + s): s = 1 for the first four ranges (c = 0, 1/2, 1,
+ * 3/2), and c = 1, s = 0 for the last one, t = -1 / |x|.  One 16-byte read replaces four compares and
+ * sixteen selects; on the GPU the table lives in LDS (device_math.h).  gm_fill_atan_rows() makes it. */
+#define GM_ATAN_ROW_COUNT 81
+typedef struct __attribute__((aligned(16))) gm_atan_row_s { float c, s, hi, lo; } gm_atan_row_t;
+GM_FN gm_atan_row_t gm_atan_row(uint32_t index) {
+	gm_atan_row_t r;
+	if (index < 1u) { r.c = 0.0f; r.s = 1.0f; r.hi = 0.0f; r.lo = 0.0f; }
+	else if (index < 21u) { r.c = 0.5f; r.s = 1.0f; r.hi = 4.6364760399e-01f; r.lo = 5.0121582440e-09f; }
+	else if (index < 47u) { r.c = 1.0f; r.s = 1.0f; r.hi = 7.8539812565e-01f; r.lo = 3.7748947079e-08f; }
+	else if (index < 80u) { r.c = 1.5f; r.s = 1.0f; r.hi = 9.8279368877e-01f; r.lo = 3.4473217170e-08f; }
+	else { r.c = 1.0f; r.s = 0.0f; r.hi = 1.5707962513e+00f; r.lo = 7.5497894159e-08f; }
+	return r;
+}
+GM_FN float gm_atanf_rows(float x, const gm_atan_row_t* rows) {
+	const float at0 = 3.3333334327e-01f, at1 = -2.0000000298e-01f, at2 = 1.4285714924e-01f, at3 = -1.1111110449e-01f,
+		at4 = 9.0908870101e-02f, at5 = -7.6918758452e-02f, at6 = 6.6610731184e-02f, at7 = -5.8335702866e-02f,
+		at8 = 4.9768779427e-02f, at9 = -3.6531571299e-02f, at10 = 1.6285819933e-02f;
+	uint32_t hx = gm_bits(x), ix = hx & 0x7FFFFFFFu;
+	float ax = gm_float(ix);
+	int32_t index = (int32_t) (ix >> 18) - 0xFB7;
+	index = index < 0 ? 0 : (index > 80 ? 80 : index);
+	gm_atan_row_t row = rows[index];
+#if defined(__HIPCC__)
+	float n = __builtin_fmaf(row.s, ax, -row.c);
+#else
+	float n = fmaf(row.s, ax, -row.c);
+#endif
+	float d = row.c * ax + row.s;
+	float t = GM_DIVF(n, d);
+	float z = t * t;
+	float w = z * z;
+	float s1 = z * (at0 + w * (at2 + w * (at4 + w * (at6 + w * (at8 + w * at10)))));
+	float s2 = w * (at1 + w * (at3 + w * (at5 + w * (at7 + w * at9))));
+	float r = row.hi - ((t * (s1 + s2) - row.lo) - t);
+	r = (ix - 0x4C000000u <= 0x7F800000u - 0x4C000000u) ? (1.5707962513e+00f + 7.5497894159e-08f) : r;
+	return gm_float(gm_bits(r) | (hx & 0x80000000u));
+}
+
 /* ---- acosf (e_acosf.c; the wrapper only adds errno) ------------------------------------------ */
 
 GM_FN float gm_acosf(float x) {

@@ -1400,6 +1400,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// of waiting for its block (mean resident waves per SIMD 2.3 -> see profiles/).  Workgroup b runs
 	// on XCD b % 8; the four patches of a block are the workgroups b, b + 8, b + 16, b + 24 of a
 	// group of 32, so they share that XCD's L2.
+	fill_atan_rows();  // (nothing unless VKR_ATAN_TABLE, device_math.h)
 	const uint32_t b = blockIdx.x;
 	const uint32_t local_block = ((b >> 5) << 3) | (b & 7u);
 	const uint32_t block = p.first_block + local_block;

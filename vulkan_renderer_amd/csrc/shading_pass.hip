@@ -1136,8 +1136,9 @@ __global__ void __launch_bounds__(256) k_evaluate_arithmetic(uint32_t operation,
 
 // compare_device_arithmetic(): two one-argument operations of k_evaluate_arithmetic over a range of bit
 // patterns, without moving the arguments through the host
-__device__ __forceinline__ float evaluate_unary(uint32_t operation, float x) {
+__device__ __forceinline__ float evaluate_unary(uint32_t operation, float x, const gm_atan_row_t* atan_rows) {
 	switch (operation) {
+	case 17: return gm_atanf_rows(x, atan_rows);
 	case 1: return square_root(x);
 	case 4: return sqrtf(x);
 	case 5: return gm_atanf(x);
@@ -1147,10 +1148,14 @@ __device__ __forceinline__ float evaluate_unary(uint32_t operation, float x) {
 	}
 }
 __global__ void __launch_bounds__(256) k_compare_arithmetic(uint32_t operation_a, uint32_t operation_b, uint32_t first_bits, uint64_t count, unsigned long long* out) {
+	// (the table of the arctangent's argument ranges, in LDS as in the shading kernels)
+	__shared__ gm_atan_row_t atan_rows[GM_ATAN_ROW_COUNT];
+	for (uint32_t i = threadIdx.x; i < GM_ATAN_ROW_COUNT; i += 256u) atan_rows[i] = gm_atan_row(i);
+	__syncthreads();
 	unsigned long long mismatches = 0;
 	for (uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t) gridDim.x * 256u) {
 		uint32_t bits = first_bits + (uint32_t) i;
-		float x = __uint_as_float(bits), a = evaluate_unary(operation_a, x), b = evaluate_unary(operation_b, x);
+		float x = __uint_as_float(bits), a = evaluate_unary(operation_a, x, atan_rows), b = evaluate_unary(operation_b, x, atan_rows);
 		bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
 		if (!same) { ++mismatches; atomicMin(out + 1, (unsigned long long) bits); }
 	}
