@@ -10,6 +10,7 @@
 #include "lbvh.h"
 #include "host/vkr_internal.h"
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 #include <time.h>
 
 using namespace vkr;
@@ -238,15 +239,6 @@ __device__ __forceinline__ float unordered(uint32_t u) {
 	return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
-	for (int offset = 32; offset > 0; offset >>= 1) v = min(v, (uint32_t) __shfl_xor((int) v, offset));
-	return v;
-}
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-	for (int offset = 32; offset > 0; offset >>= 1) v = max(v, (uint32_t) __shfl_xor((int) v, offset));
-	return v;
-}
-
 __device__ __forceinline__ void reset_open_node(sah_open_node* node, uint32_t position, uint32_t first, uint32_t count) {
 	node->position = position; node->first = first; node->count = count; node->fallback_rank = 0;
 	for (int j = 0; j != 3; ++j) {
@@ -255,23 +247,14 @@ __device__ __forceinline__ void reset_open_node(sah_open_node* node, uint32_t po
 	}
 }
 
-// Grows the boxes of an open node by one triangle.  When the whole wave feeds the same node
-// (the first levels: all 131 k triangles would otherwise queue up on twelve addresses) the wave
-// reduces first and one lane does the atomics.
-__device__ __forceinline__ void grow_open_node(sah_open_node* node, bool active, f3 lo, f3 hi, bool wave_uniform) {
+// Grows the boxes of an open node by one triangle, directly in global memory
+__device__ __forceinline__ void grow_open_node(sah_open_node* node, f3 lo, f3 hi) {
 	const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
 	for (int j = 0; j != 3; ++j) {
-		uint32_t b0 = active ? ordered(l[j]) : 0xFFFFFFFFu, b1 = active ? ordered(h[j]) : 0u;
 		// centroids like sah_bvh.c: 0.5 (lo + hi)
 		uint32_t c = ordered(0.5f * (l[j] + h[j]));
-		uint32_t c0 = active ? c : 0xFFFFFFFFu, c1 = active ? c : 0u;
-		if (wave_uniform) {
-			b0 = wave_min(b0); b1 = wave_max(b1); c0 = wave_min(c0); c1 = wave_max(c1);
-			if ((threadIdx.x & 63u) != 0) continue;
-		}
-		else if (!active) continue;
-		atomicMin(&node->bounds[j], b0); atomicMax(&node->bounds[3 + j], b1);
-		atomicMin(&node->centroid_bounds[j], c0); atomicMax(&node->centroid_bounds[3 + j], c1);
+		atomicMin(&node->bounds[j], ordered(l[j])); atomicMax(&node->bounds[3 + j], ordered(h[j]));
+		atomicMin(&node->centroid_bounds[j], c); atomicMax(&node->centroid_bounds[3 + j], c);
 	}
 }
 
@@ -293,8 +276,48 @@ __device__ __forceinline__ void write_leaf(const build_params& p, uint32_t t, co
 	triangles[3 * (size_t) slot + 2] = make_float4(v[2].x, v[2].y, v[2].z, 0.0f);
 }
 
+// ---- contributions of a workgroup combined in LDS ------------------------------------------
+// Atomics of device scope are performed behind the L2s of the eight XCDs, a few billion per second
+// whatever their address; the levels of a build issue 12 (boxes of the children) and 21 (bins) of
+// them per triangle.  The 256 consecutive triangles of a workgroup mostly belong to a handful of
+// open nodes, so the workgroup combines their contributions in LDS - a 16-slot table keyed by the
+// node - and sends one atomic per field that received something; a triangle that finds the table
+// full (deep levels: few triangles per node, hence little contention) goes to global memory directly.
+// Counts add up and bounds are minima / maxima: the tree is the one of the direct atomics.
+constexpr uint32_t kSahGroupSlots = 16;
+constexpr uint32_t kSahEmptyKey = 0xFFFFFFFFu;
+__device__ __forceinline__ int group_slot(uint32_t* keys, uint32_t key) {
+	uint32_t h = (key * 2654435761u) >> 28;
+	for (uint32_t probe = 0; probe != kSahGroupSlots; ++probe) {
+		uint32_t old = atomicCAS(&keys[h], kSahEmptyKey, key);
+		if (old == kSahEmptyKey || old == key) return (int) h;
+		h = (h + 1u) & (kSahGroupSlots - 1u);
+	}
+	return -1;
+}
+// the twelve words of an open node's boxes as one array: bounds lo.xyz hi.xyz, centroid bounds lo.xyz hi.xyz
+__device__ __forceinline__ void reset_box_words(uint32_t* words) {
+	for (int j = 0; j != 12; ++j) words[j] = (j % 6) < 3 ? 0xFFFFFFFFu : 0u;
+}
+__device__ __forceinline__ void grow_box_words(uint32_t* words, f3 lo, f3 hi) {
+	const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+	for (int j = 0; j != 3; ++j) {
+		uint32_t c = ordered(0.5f * (l[j] + h[j]));
+		atomicMin(&words[j], ordered(l[j])); atomicMax(&words[3 + j], ordered(h[j]));
+		atomicMin(&words[6 + j], c); atomicMax(&words[9 + j], c);
+	}
+}
+__device__ __forceinline__ void flush_box_word(sah_open_node* node, uint32_t field, uint32_t value) {
+	uint32_t* target = field < 6 ? &node->bounds[field] : &node->centroid_bounds[field - 6];
+	if ((field % 6) < 3) atomicMin(target, value);
+	else atomicMax(target, value);
+}
+
 // level 0: every triangle is in the root
 __global__ void __launch_bounds__(256) k_sah_init(build_params p, uint32_t* triangle_node, sah_open_node* root, float4* threaded, float4* triangles) {
+	__shared__ uint32_t words[12];
+	if (threadIdx.x < 12) words[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xFFFFFFFFu : 0u;
+	__syncthreads();
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	bool active = t < p.triangle_count;
 	f3 v[3], lo = mk3(0.0f, 0.0f, 0.0f), hi = lo;
@@ -302,8 +325,10 @@ __global__ void __launch_bounds__(256) k_sah_init(build_params p, uint32_t* tria
 		triangle_bounds(p, t, v, lo, hi);
 		triangle_node[t] = p.triangle_count > 1 ? 0u : kSahDone;
 		if (p.triangle_count == 1) write_leaf(p, t, v, lo, hi, 0u, 0u, threaded, triangles);
+		grow_box_words(words, lo, hi);
 	}
-	grow_open_node(root, active, lo, hi, true);
+	__syncthreads();
+	if (threadIdx.x < 12) flush_box_word(root, threadIdx.x, words[threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256) k_sah_reset_root(sah_open_node* root, uint32_t triangle_count, uint32_t* counters) {
@@ -332,21 +357,14 @@ __device__ __forceinline__ int sah_bin_index(float c, float lo, float scale) {
 	return k < 0 ? 0 : (k >= kSahBinCount ? kSahBinCount - 1 : k);
 }
 
-__global__ void __launch_bounds__(256) k_sah_bin(build_params p, const uint32_t* triangle_node, const sah_open_node* open, sah_bin* bins) {
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= p.triangle_count) return;
-	uint32_t id = triangle_node[t];
-	if (id == kSahDone) return;
-	const sah_open_node* node = open + id;
-	f3 v[3], lo, hi;
-	triangle_bounds(p, t, v, lo, hi);
+__device__ __forceinline__ void bin_triangle(sah_bin* node_bins, const sah_open_node* node, f3 lo, f3 hi) {
 	const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
 	for (int j = 0; j != 3; ++j) {
 		float c_lo = unordered(node->centroid_bounds[j]), c_hi = unordered(node->centroid_bounds[3 + j]);
 		float scale = sah_bin_scale(c_lo, c_hi);
 		if (!(scale > 0.0f)) continue;
 		int k = sah_bin_index(0.5f * (l[j] + h[j]), c_lo, scale);
-		sah_bin* bin = bins + ((size_t) id * 3 + j) * kSahBinCount + k;
+		sah_bin* bin = node_bins + j * kSahBinCount + k;
 		atomicAdd(&bin->count, 1u);
 		for (int a = 0; a != 3; ++a) {
 			atomicMin(&bin->lo[a], ordered(l[a]));
@@ -354,11 +372,44 @@ __global__ void __launch_bounds__(256) k_sah_bin(build_params p, const uint32_t*
 		}
 	}
 }
+__device__ __forceinline__ void flush_bin(sah_bin* out, const sah_bin& in) {
+	if (!in.count) return;
+	atomicAdd(&out->count, in.count);
+	for (int a = 0; a != 3; ++a) {
+		atomicMin(&out->lo[a], in.lo[a]);
+		atomicMax(&out->hi[a], in.hi[a]);
+	}
+}
 
-// The same for the first levels, where a few open nodes hold all triangles and every atomic above
-// lands on one of a few dozen addresses (level 0: 2.8 M atomics on 48 bins, 11 ms of a 38 ms build):
-// the workgroup bins in LDS first and sends one atomic per non-empty bin and field.  The result
-// is the same: counts add up and the bounds are minima / maxima.
+// Bins of the open nodes of a level (more than kSahSharedNodes of them, see below), combined per workgroup
+__global__ void __launch_bounds__(256) k_sah_bin(build_params p, const uint32_t* triangle_node, const sah_open_node* open, sah_bin* bins) {
+	constexpr uint32_t kBinsPerNode = 3 * kSahBinCount;
+	__shared__ uint32_t keys[kSahGroupSlots];
+	__shared__ sah_bin shared_bins[kSahGroupSlots * kBinsPerNode];
+	if (threadIdx.x < kSahGroupSlots) keys[threadIdx.x] = kSahEmptyKey;
+	for (uint32_t i = threadIdx.x; i < kSahGroupSlots * kBinsPerNode; i += 256u) {
+		shared_bins[i].count = 0;
+		for (int a = 0; a != 3; ++a) { shared_bins[i].lo[a] = 0xFFFFFFFFu; shared_bins[i].hi[a] = 0u; }
+	}
+	__syncthreads();
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t id = t < p.triangle_count ? triangle_node[t] : kSahDone;
+	if (id != kSahDone) {
+		f3 v[3], lo, hi;
+		triangle_bounds(p, t, v, lo, hi);
+		int slot = group_slot(keys, id);
+		if (slot >= 0) bin_triangle(shared_bins + (uint32_t) slot * kBinsPerNode, open + id, lo, hi);
+		else bin_triangle(bins + (size_t) id * kBinsPerNode, open + id, lo, hi);
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < kSahGroupSlots * kBinsPerNode; i += 256u) {
+		uint32_t key = keys[i / kBinsPerNode];
+		if (key != kSahEmptyKey) flush_bin(bins + (size_t) key * kBinsPerNode + i % kBinsPerNode, shared_bins[i]);
+	}
+}
+
+// The first levels, where a few open nodes hold all triangles (level 0: 2.8 M atomics on 48 bins
+// were 11 ms of a 38 ms build): the table is indexed by the node itself, no triangle goes around it.
 constexpr uint32_t kSahSharedNodes = 32;  // (8 until round 3: the first level without LDS binning took 1.3 ms of a 15 ms build)
 __global__ void __launch_bounds__(256) k_sah_bin_shared(build_params p, const uint32_t* triangle_node, const sah_open_node* open, uint32_t open_count, sah_bin* bins) {
 	__shared__ sah_bin shared_bins[kSahSharedNodes * 3 * kSahBinCount];
@@ -371,32 +422,12 @@ __global__ void __launch_bounds__(256) k_sah_bin_shared(build_params p, const ui
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t id = t < p.triangle_count ? triangle_node[t] : kSahDone;
 	if (id != kSahDone) {
-		const sah_open_node* node = open + id;
 		f3 v[3], lo, hi;
 		triangle_bounds(p, t, v, lo, hi);
-		const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
-		for (int j = 0; j != 3; ++j) {
-			float c_lo = unordered(node->centroid_bounds[j]), c_hi = unordered(node->centroid_bounds[3 + j]);
-			float scale = sah_bin_scale(c_lo, c_hi);
-			if (!(scale > 0.0f)) continue;
-			int k = sah_bin_index(0.5f * (l[j] + h[j]), c_lo, scale);
-			sah_bin* bin = shared_bins + ((size_t) id * 3 + j) * kSahBinCount + k;
-			atomicAdd(&bin->count, 1u);
-			for (int a = 0; a != 3; ++a) {
-				atomicMin(&bin->lo[a], ordered(l[a]));
-				atomicMax(&bin->hi[a], ordered(h[a]));
-			}
-		}
+		bin_triangle(shared_bins + id * 3u * kSahBinCount, open + id, lo, hi);
 	}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < bin_count; i += 256u) {
-		if (!shared_bins[i].count) continue;
-		atomicAdd(&bins[i].count, shared_bins[i].count);
-		for (int a = 0; a != 3; ++a) {
-			atomicMin(&bins[i].lo[a], shared_bins[i].lo[a]);
-			atomicMax(&bins[i].hi[a], shared_bins[i].hi[a]);
-		}
-	}
+	for (uint32_t i = threadIdx.x; i < bin_count; i += 256u) flush_bin(bins + i, shared_bins[i]);
 }
 
 struct sah_box {
@@ -473,41 +504,46 @@ __global__ void __launch_bounds__(64) k_sah_split(sah_open_node* open, uint32_t 
 	}
 }
 
-// Every triangle of an open node moves to the child on its side of the split, or becomes a leaf
+// Every triangle of an open node moves to the child on its side of the split, or becomes a leaf.
+// The boxes of the children grow by the triangles they receive (combined per workgroup, see above).
 __global__ void __launch_bounds__(256) k_sah_assign(build_params p, uint32_t* triangle_node, sah_open_node* open, sah_open_node* next_open, float4* threaded, float4* triangles) {
+	__shared__ uint32_t keys[kSahGroupSlots];
+	__shared__ uint32_t words[kSahGroupSlots * 12];
+	if (threadIdx.x < kSahGroupSlots) keys[threadIdx.x] = kSahEmptyKey;
+	if (threadIdx.x < kSahGroupSlots * 12) words[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xFFFFFFFFu : 0u;
+	__syncthreads();
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t id = t < p.triangle_count ? triangle_node[t] : kSahDone;
-	bool active = id != kSahDone;
-	// (a wave whose triangles share one parent reduces the children's boxes before the atomics)
-	uint32_t first_id = __builtin_amdgcn_readfirstlane(id);
-	bool wave_uniform = __all(id == first_id) && first_id != kSahDone;
-	f3 v[3], lo = mk3(0.0f, 0.0f, 0.0f), hi = lo;
-	uint32_t side = 0, child = kSahDone;
-	if (active) {
+	if (id != kSahDone) {
 		sah_open_node* node = open + id;
+		f3 v[3], lo, hi;
 		triangle_bounds(p, t, v, lo, hi);
 		int axis = node->axis;
+		uint32_t side;
 		if (axis >= 0) {
 			float c = 0.5f * (axis == 0 ? lo.x + hi.x : (axis == 1 ? lo.y + hi.y : lo.z + hi.z));
 			side = sah_bin_index(c, node->bin_origin, node->bin_scale) > node->split_bin ? 1u : 0u;
 		}
 		else side = atomicAdd(&node->fallback_rank, 1u) >= node->left_count ? 1u : 0u;
-		child = node->child[side];
+		uint32_t child = node->child[side];
 		if (child == kSahLeafChild) {
 			uint32_t position = side ? node->position + 2u * node->left_count : node->position + 1u;
 			uint32_t slot = side ? node->first + node->left_count : node->first;
 			write_leaf(p, t, v, lo, hi, position, slot, threaded, triangles);
 			triangle_node[t] = kSahDone;
 		}
-		else triangle_node[t] = child;
+		else {
+			triangle_node[t] = child;
+			int slot = group_slot(keys, child);
+			if (slot >= 0) grow_box_words(words + 12 * slot, lo, hi);
+			else grow_open_node(next_open + child, lo, hi);
+		}
 	}
-	bool grows = active && child != kSahLeafChild;
-	if (wave_uniform) {
-		uint32_t children[2] = {open[first_id].child[0], open[first_id].child[1]};
-		for (uint32_t s = 0; s != 2; ++s)
-			if (children[s] != kSahLeafChild) grow_open_node(next_open + children[s], grows && side == s, lo, hi, true);
+	__syncthreads();
+	if (threadIdx.x < kSahGroupSlots * 12) {
+		uint32_t key = keys[threadIdx.x / 12];
+		if (key != kSahEmptyKey) flush_box_word(next_open + key, threadIdx.x % 12, words[threadIdx.x]);
 	}
-	else if (grows) grow_open_node(next_open + child, true, lo, hi, false);
 }
 
 // ---- collapse to the four-wide layout (lbvh.h) ------------------------------------------------
@@ -578,6 +614,16 @@ __global__ void __launch_bounds__(64) k_collapse_level(const uint4* binary, cons
 	out[3] = make_uint4(link[0], link[1], link[2], link[3]);
 }
 
+// The host learns how many nodes the next level has: the counters go to pinned host memory (a store
+// of the device instead of a copy command per level and direction) and the per-level one starts over.
+__global__ void __launch_bounds__(64) k_publish_counters(uint32_t* counters, uint32_t count, uint32_t* host_words) {
+	if (blockIdx.x == 0 && threadIdx.x < count) {
+		host_words[threadIdx.x] = counters[threadIdx.x];
+		if (threadIdx.x == 0) counters[0] = 0u;
+		__threadfence_system();
+	}
+}
+
 }  // namespace
 
 // Replaces structure->nodes (fp32 threaded nodes on the device) by the quantised nodes
@@ -616,19 +662,22 @@ extern "C" void vkr_destroy_acceleration_structure(acceleration_structure_t* str
 // known when the level before it has been written).  Leaves structure->wide_nodes NULL (the
 // kernels then walk the binary tree) if the tree is a single leaf or a ray could need a deeper
 // stack than the kernels provide.
-static int collapse_to_wide(acceleration_structure_t* structure, const device_t* device) {
+static int collapse_to_wide(acceleration_structure_t* structure, const device_t* device, uint32_t* host_words) {
 	uint32_t triangle_count = (structure->node_count + 1) / 2;
 	if (triangle_count < 2) return 0;
 	hipStream_t stream = (hipStream_t) device->stream;
 	wide_item* items[2] = {NULL, NULL};
 	uint32_t* counters = NULL;
+	uint8_t* arena = NULL;
 	uint4* wide = NULL;
 	int failed = 1;
 	uint32_t host_counters[3] = {0, 1, 0};
+	const size_t item_bytes = (sizeof(wide_item) * (size_t) triangle_count + 255) & ~(size_t) 255;
 	do {
-		HIP_OK_BREAK(hipMalloc(&items[0], sizeof(wide_item) * (size_t) triangle_count));
-		HIP_OK_BREAK(hipMalloc(&items[1], sizeof(wide_item) * (size_t) triangle_count));
-		HIP_OK_BREAK(hipMalloc(&counters, sizeof(uint32_t) * 3));
+		HIP_OK_BREAK(hipMalloc(&arena, 2 * item_bytes + 256));
+		items[0] = (wide_item*) arena;
+		items[1] = (wide_item*) (arena + item_bytes);
+		counters = (uint32_t*) (arena + 2 * item_bytes);
 		HIP_OK_BREAK(hipMalloc(&wide, sizeof(uint4) * 4 * (size_t) (triangle_count - 1)));
 		wide_item root = {0u, 0u, 0u};
 		HIP_OK_BREAK(hipMemcpyAsync(items[0], &root, sizeof(root), hipMemcpyHostToDevice, stream));
@@ -637,16 +686,15 @@ static int collapse_to_wide(acceleration_structure_t* structure, const device_t*
 		bool ok = true;
 		while (item_count && ok) {
 			k_collapse_level<<<(item_count + 63) / 64, 64, 0, stream>>>((const uint4*) structure->nodes, items[level & 1], item_count, items[(level + 1) & 1], counters, wide);
-			ok = hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, stream) == hipSuccess
-				&& hipStreamSynchronize(stream) == hipSuccess;
+			k_publish_counters<<<1, 64, 0, stream>>>(counters, 3u, host_words);
+			ok = hipStreamSynchronize(stream) == hipSuccess && ++level < 4096;
+			for (int i = 0; i != 3; ++i) host_counters[i] = ((volatile uint32_t*) host_words)[i];
 			item_count = host_counters[0];
-			uint32_t zero = 0;
-			ok = ok && hipMemcpyAsync(counters, &zero, sizeof(zero), hipMemcpyHostToDevice, stream) == hipSuccess && ++level < 4096;
 		}
 		if (!ok || hipGetLastError() != hipSuccess) break;
 		failed = 0;
 	} while (0);
-	(void) hipFree(items[0]); (void) hipFree(items[1]); (void) hipFree(counters);
+	(void) hipFree(arena);
 	if (failed || host_counters[2] > kWideStackMax) {
 		if (!failed) printf("The four-wide BVH would need a stack of %u entries per ray (at most %u are provided); shadow rays walk the binary tree.\n", host_counters[2], kWideStackMax);
 		(void) hipFree(wide);
@@ -659,7 +707,7 @@ static int collapse_to_wide(acceleration_structure_t* structure, const device_t*
 }
 
 // The binned SAH build by HIP kernels (see above); leaves fp32 threaded nodes in structure->nodes
-static int build_sah_on_device(acceleration_structure_t* structure, const device_t* device, const build_params& p) {
+static int build_sah_on_device(acceleration_structure_t* structure, const device_t* device, const build_params& p, uint32_t* host_words) {
 	hipStream_t stream = (hipStream_t) device->stream;
 	uint32_t n = p.triangle_count;
 	uint32_t total_nodes = 2 * n - 1;
@@ -697,11 +745,10 @@ static int build_sah_on_device(acceleration_structure_t* structure, const device
 			else k_sah_bin<<<blocks, 256, 0, stream>>>(p, triangle_node, now, bins);
 			k_sah_split<<<(open_count + 63) / 64, 64, 0, stream>>>(now, open_count, bins, next, counters, (float4*) structure->nodes, p.pad);
 			k_sah_assign<<<blocks, 256, 0, stream>>>(p, triangle_node, now, next, (float4*) structure->nodes, (float4*) structure->triangle_vertices);
-			uint32_t next_count = 0, zero = 0;
-			ok = hipMemcpyAsync(&next_count, counters, sizeof(next_count), hipMemcpyDeviceToHost, stream) == hipSuccess
-				&& hipStreamSynchronize(stream) == hipSuccess
-				&& hipMemcpyAsync(counters, &zero, sizeof(zero), hipMemcpyHostToDevice, stream) == hipSuccess
-				&& next_count <= open_capacity && ++level < 4096;
+			k_publish_counters<<<1, 64, 0, stream>>>(counters, 1u, host_words);
+			ok = hipStreamSynchronize(stream) == hipSuccess;
+			uint32_t next_count = ((volatile uint32_t*) host_words)[0];
+			ok = ok && next_count <= open_capacity && ++level < 4096;
 			open_count = next_count;
 		}
 		if (!ok || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) break;
@@ -805,13 +852,30 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	if (hipStreamSynchronize(stream) != hipSuccess) return 1;
 	struct timespec start, end;
 	clock_gettime(CLOCK_MONOTONIC, &start);
+	// VKR_BVH_BUILD_TRACE=1 prints the wall-clock time of the three phases (diagnostics)
+	const bool trace = getenv("VKR_BVH_BUILD_TRACE") != NULL;
+	struct timespec phase[3] = {start, start, start};
+	// (pinned: where the level loops of the build read their counters, k_publish_counters)
+	uint32_t* host_words = NULL;
+	if (hipHostMalloc(&host_words, 64) != hipSuccess) {
+		printf("Failed to allocate pinned host memory for the BVH build.\n");
+		return 1;
+	}
 	int failed = builder == (int) acceleration_structure_sah_host ? build_sah_on_host(structure, device, mesh, p.pad)
-		: (builder == (int) acceleration_structure_lbvh_device ? build_lbvh_on_device(structure, device, p) : build_sah_on_device(structure, device, p));
+		: (builder == (int) acceleration_structure_lbvh_device ? build_lbvh_on_device(structure, device, p) : build_sah_on_device(structure, device, p, host_words));
+	if (trace) clock_gettime(CLOCK_MONOTONIC, &phase[0]);
 	if (!failed) {
 		failed = quantize_nodes(structure, device);
 		if (failed) printf("Quantising the BVH nodes failed.\n");
 	}
-	if (!failed) failed = collapse_to_wide(structure, device);
+	if (trace) clock_gettime(CLOCK_MONOTONIC, &phase[1]);
+	if (!failed) failed = collapse_to_wide(structure, device, host_words);
+	(void) hipHostFree(host_words);
+	if (trace) {
+		clock_gettime(CLOCK_MONOTONIC, &phase[2]);
+		auto ms = [](const struct timespec& a, const struct timespec& b) { return (double) (b.tv_sec - a.tv_sec) * 1.0e3 + (double) (b.tv_nsec - a.tv_nsec) * 1.0e-6; };
+		printf("BVH build over %u triangles: tree %.3f ms, quantisation %.3f ms, four-wide collapse %.3f ms\n", n, ms(start, phase[0]), ms(phase[0], phase[1]), ms(phase[1], phase[2]));
+	}
 	if (failed) {
 		printf("Building the BVH over %u triangles failed: %s\n", n, hipGetErrorString(hipGetLastError()));
 		vkr_destroy_acceleration_structure(structure, device);
