@@ -447,42 +447,81 @@ __device__ __forceinline__ float sah_half_area(const sah_box& b) {
 	return x * y + y * z + z * x;
 }
 
-// One thread per open node: the cheapest of the 3 x 15 splits (same order of evaluation and the
-// same strict comparison as sah_bvh.c), the node itself in the output, its children as open
-// nodes of the next level.  counters[0]: open nodes of the next level.
-__global__ void __launch_bounds__(64) k_sah_split(sah_open_node* open, uint32_t open_count, const sah_bin* bins, sah_open_node* next_open, uint32_t* counters, float4* threaded, float pad) {
-	uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= open_count) return;
-	sah_open_node* node = open + id;
-	uint32_t count = node->count;
-	float best_cost = 3.402823466e+38f;
-	int best_axis = -1, best_split = 0;
-	uint32_t best_left = 0;
-	for (int j = 0; j != 3; ++j) {
-		float c_lo = unordered(node->centroid_bounds[j]), c_hi = unordered(node->centroid_bounds[3 + j]);
-		if (!(sah_bin_scale(c_lo, c_hi) > 0.0f)) continue;
-		const sah_bin* axis_bins = bins + ((size_t) id * 3 + j) * kSahBinCount;
-		float right_area[kSahBinCount];
-		uint32_t right_count[kSahBinCount];
-		sah_box sweep;
-		sah_box_reset(sweep);
-		uint32_t n = 0;
-		for (int k = kSahBinCount - 1; k > 0; --k) {
-			if (axis_bins[k].count) sah_box_merge(sweep, axis_bins[k]);
-			n += axis_bins[k].count;
-			right_area[k] = n ? sah_half_area(sweep) : 0.0f;
-			right_count[k] = n;
+// The cheapest of the 3 x 15 splits of every open node, the node itself in the output, its children
+// as open nodes of the next level.  counters[0]: open nodes of the next level.
+// A wave looks at one node at a time: lane 16 j + k holds bin k of axis j (sixteen lanes idle), the
+// boxes and counts left and right of every plane come from segmented scans - minima, maxima and
+// integer sums, so the order of the merges does not matter - the 45 costs are evaluated side by side
+// with the expression of sah_bvh.c, and a reduction over (cost, lane) picks the first of the cheapest in
+// the order axis, bin: what the strict comparison in sah_bvh.c's loops picks.  A workgroup handles 64
+// nodes, sixteen per wave, and then one lane per node writes the node and allocates its children, so
+// that the compiler can combine the wave's allocations into one atomic (one wave per node meant 130 k
+// atomics on one address at the widest level: 0.5 ms).  Measured (profiles/r03w/): 5 us for the first
+// levels (one thread per node walking 90 bins one after the other took 37 us whatever the level); the
+// deep levels stay at 40 - 57 us either way, because their 66 k open nodes have 88 MB of bins to read.
+constexpr uint32_t kSplitNodesPerGroup = 64;
+__global__ void __launch_bounds__(256) k_sah_split(sah_open_node* open, uint32_t open_count, const sah_bin* bins, sah_open_node* next_open, uint32_t* counters, float4* threaded, float pad) {
+	__shared__ uint32_t best_lanes[kSplitNodesPerGroup], best_lefts[kSplitNodesPerGroup];
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t axis = lane >> 4, k = lane & 15u;
+	for (uint32_t i = 0; i != kSplitNodesPerGroup / 4u; ++i) {
+		const uint32_t local = i * 4u + wave;
+		const uint32_t id = blockIdx.x * kSplitNodesPerGroup + local;
+		if (id >= open_count) break;
+		const sah_open_node* node = open + id;
+		bool splittable = false;
+		sah_box left, right;
+		sah_box_reset(left);
+		uint32_t left_n = 0;
+		if (axis < 3u) {
+			splittable = sah_bin_scale(unordered(node->centroid_bounds[axis]), unordered(node->centroid_bounds[3 + axis])) > 0.0f;
+			const sah_bin bin = bins[(size_t) id * (3 * kSahBinCount) + lane];
+			if (bin.count) sah_box_merge(left, bin);
+			left_n = bin.count;
 		}
-		sah_box_reset(sweep);
-		n = 0;
-		for (int k = 0; k != kSahBinCount - 1; ++k) {
-			if (axis_bins[k].count) sah_box_merge(sweep, axis_bins[k]);
-			n += axis_bins[k].count;
-			if (n == 0 || right_count[k + 1] == 0) continue;
-			float cost = sah_half_area(sweep) * (float) n + right_area[k + 1] * (float) right_count[k + 1];
-			if (cost < best_cost) { best_cost = cost; best_axis = j; best_split = k; best_left = n; }
+		right = left;
+		uint32_t right_n = left_n;
+#pragma unroll
+		for (uint32_t offset = 1; offset < (uint32_t) kSahBinCount; offset <<= 1) {
+			const bool from_below = k >= offset, from_above = k + offset < (uint32_t) kSahBinCount;
+			uint32_t n = (uint32_t) __shfl_up((int) left_n, offset, kSahBinCount);
+			left_n += from_below ? n : 0u;
+			n = (uint32_t) __shfl_down((int) right_n, offset, kSahBinCount);
+			right_n += from_above ? n : 0u;
+			for (int j = 0; j != 3; ++j) {
+				float lo = __shfl_up(left.lo[j], offset, kSahBinCount), hi = __shfl_up(left.hi[j], offset, kSahBinCount);
+				if (from_below) { left.lo[j] = fminf(left.lo[j], lo); left.hi[j] = fmaxf(left.hi[j], hi); }
+				lo = __shfl_down(right.lo[j], offset, kSahBinCount); hi = __shfl_down(right.hi[j], offset, kSahBinCount);
+				if (from_above) { right.lo[j] = fminf(right.lo[j], lo); right.hi[j] = fmaxf(right.hi[j], hi); }
+			}
 		}
+		// the plane behind bin k: bins 0 ... k on the left, k + 1 ... 15 on the right
+		const float right_area = right_n ? sah_half_area(right) : 0.0f;
+		const float next_area = __shfl_down(right_area, 1, kSahBinCount);
+		const uint32_t next_n = (uint32_t) __shfl_down((int) right_n, 1, kSahBinCount);
+		float cost = 3.402823466e+38f;
+		if (splittable && k + 1u < (uint32_t) kSahBinCount && left_n != 0u && next_n != 0u)
+			cost = sah_half_area(left) * (float) left_n + next_area * (float) next_n;
+		uint32_t best = cost < 3.402823466e+38f ? lane : 0xFFFFFFFFu;
+		if (best == 0xFFFFFFFFu) cost = 3.402823466e+38f;
+#pragma unroll
+		for (int offset = 32; offset > 0; offset >>= 1) {
+			float other_cost = __shfl_xor(cost, offset);
+			uint32_t other = (uint32_t) __shfl_xor((int) best, offset);
+			bool take = other_cost < cost || (other_cost == cost && other < best);
+			cost = take ? other_cost : cost;
+			best = take ? other : best;
+		}
+		const uint32_t best_left = (uint32_t) __shfl((int) left_n, (int) (best & 63u));
+		if (lane == 0) { best_lanes[local] = best; best_lefts[local] = best_left; }
 	}
+	__syncthreads();
+	const uint32_t id = blockIdx.x * kSplitNodesPerGroup + threadIdx.x;
+	if (threadIdx.x >= kSplitNodesPerGroup || id >= open_count) return;
+	sah_open_node* node = open + id;
+	const uint32_t best = best_lanes[threadIdx.x], best_left = best_lefts[threadIdx.x];
+	uint32_t count = node->count;
+	int best_axis = best == 0xFFFFFFFFu ? -1 : (int) (best >> 4), best_split = best == 0xFFFFFFFFu ? 0 : (int) (best & 15u);
 	// all centroids coincide: any split is as good as another (triangles are dealt by rank)
 	uint32_t left_count = best_axis < 0 ? count / 2u : best_left;
 	node->axis = best_axis;
@@ -650,6 +689,12 @@ static int quantize_nodes(acceleration_structure_t* structure, const device_t* d
 	return 0;
 }
 
+static __global__ void k_empty() {}
+extern "C" int vkr_launch_empty_kernel(void* stream) {
+	k_empty<<<1, 64, 0, (hipStream_t) stream>>>();
+	return hipGetLastError() != hipSuccess;
+}
+
 extern "C" void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, const device_t* device) {
 	(void) device;
 	if (structure->triangle_vertices) (void) hipFree(structure->triangle_vertices);
@@ -743,7 +788,7 @@ static int build_sah_on_device(acceleration_structure_t* structure, const device
 			k_sah_clear_bins<<<(bin_count + 255) / 256, 256, 0, stream>>>(bins, bin_count);
 			if (open_count <= kSahSharedNodes) k_sah_bin_shared<<<blocks, 256, 0, stream>>>(p, triangle_node, now, open_count, bins);
 			else k_sah_bin<<<blocks, 256, 0, stream>>>(p, triangle_node, now, bins);
-			k_sah_split<<<(open_count + 63) / 64, 64, 0, stream>>>(now, open_count, bins, next, counters, (float4*) structure->nodes, p.pad);
+			k_sah_split<<<(open_count + kSplitNodesPerGroup - 1u) / kSplitNodesPerGroup, 256, 0, stream>>>(now, open_count, bins, next, counters, (float4*) structure->nodes, p.pad);
 			k_sah_assign<<<blocks, 256, 0, stream>>>(p, triangle_node, now, next, (float4*) structure->nodes, (float4*) structure->triangle_vertices);
 			k_publish_counters<<<1, 64, 0, stream>>>(counters, 1u, host_words);
 			ok = hipStreamSynchronize(stream) == hipSuccess;
