@@ -400,6 +400,15 @@ VKR_API int evaluate_device_arithmetic(const device_t* device, uint32_t operatio
 	compared bit for bit (NaNs equal each other).  out[0]: arguments with different results, out[1]: the
 	smallest such bit pattern (all ones if none).  How a cheaper chain is admitted into the IEEE modes. */
 VKR_API int compare_device_arithmetic(const device_t* device, uint32_t operation_a, uint32_t operation_b, uint32_t first_bits, uint64_t count, uint64_t out_mismatches_and_first[2]);
+/*! divide(a, b) of the IEEE arithmetic modes (csrc/device_math.h: one correction behind the refined
+	v_rcp_f32 estimate) against the compiler's IEEE a / b, on the device, for `divisor_count` (<= 65535)
+	divisors with the significands first_significand + i * stride (23 bits) and the biased exponent
+	divisor_exponent, each with EVERY one of the 2^23 dividends of the biased exponent dividend_exponent.
+	out[0]: quotients that differ, out[1]: the smallest divisor_bits << 32 | dividend_bits among them (all
+	ones if none).  A slice of the search over all 2^46 pairs of significands that admitted the chain
+	(profiles/tools/division_chains.hip), kept in the test suite.  No reference counterpart (the reference
+	leaves division to the driver's compiler). */
+VKR_API int compare_device_division(const device_t* device, uint32_t first_significand, uint32_t divisor_count, uint32_t stride, uint32_t dividend_exponent, uint32_t divisor_exponent, uint64_t out_mismatches_and_first[2]);
 
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,
 	first_person_camera_t, ltc_constants_t, ltc_table_t, noise_table_t, mesh_t,

@@ -65,6 +65,24 @@ def test_division_is_the_ieee_quotient_in_the_range_the_kernels_work_in(device):
         assert same_bits(evaluate(device, 3, a, b), a / b).all()
 
 
+def test_division_with_one_correction_equals_the_ieee_quotient_for_whole_rows_of_significand_pairs(device):
+    """divide() corrects its quotient once, the compiler's a / b twice; that once is enough was found by trying all
+    2^46 pairs of significands (profiles/tools/division_chains.hip, profiles/r03w/division_chains.txt).  A slice
+    of that search stays in the suite: 4096 divisors spread over the significands (and the ones around the
+    first counterexample of the chain that does NOT work), each against every one of the 2^23 dividends, at
+    several places of the exponent window."""
+    out = (C.c_uint64 * 2)()
+    pairs = 0
+    for first, count, stride, dividend_exponent, divisor_exponent in (
+            (0x000000, 4096, 2048, 127, 127), (0x000001, 4096, 2047, 128, 127), (0x57EA09 - 64, 128, 1, 127, 127),
+            (0x7FFFFF - 255, 256, 1, 127, 127), (0x000000, 256, 1, 127, 127),
+            (0x000123, 512, 16381, 127 + 40, 127 - 30), (0x000456, 512, 16381, 127 - 60, 127 + 20), (0x000789, 512, 16381, 127 - 33, 127 - 80)):
+        assert device.lib.compare_device_division(C.byref(device.app.device), first, count, stride, dividend_exponent, divisor_exponent, out) == 0
+        assert out[0] == 0, (first, count, stride, dividend_exponent, divisor_exponent, int(out[0]), hex(int(out[1])))
+        pairs += count << 23
+    assert pairs > 8.0e10
+
+
 def test_division_keeps_the_ieee_results_for_zeros_infinities_and_nans(device):
     specials = np.array([0.0, -0.0, 1.0, -1.0, 3.5, -2.25e-3, np.inf, -np.inf, np.nan, 1.0e10, -1.0e-10], np.float32)
     a, b = [x.ravel() for x in np.meshgrid(specials, specials)]

@@ -248,6 +248,7 @@ SIGNATURES = {
     "get_slab_pixel_coordinates": (C.c_uint64, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
     "evaluate_device_arithmetic": (C.c_int, [P(Device), C.c_uint32, P(C.c_float), P(C.c_float), P(C.c_float), C.c_uint32]),
     "compare_device_arithmetic": (C.c_int, [P(Device), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, P(C.c_uint64)]),
+    "compare_device_division": (C.c_int, [P(Device), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_uint64)]),
     "get_traversal_statistics_of_tree": (C.c_int, [P(Application), C.c_uint32, P(C.c_uint64)]),
     "get_abi_struct_sizes": (C.c_uint32, [P(C.c_uint64), C.c_uint32]),
     "create_experiment_list": (None, [P(ExperimentList)]),

@@ -77,15 +77,19 @@ VKR_DEV float positive_part(float x) { return (x > 0.0f) ? x : 0.0f; }
 // arrays into scratch memory.
 VKR_DEV float opaque(float x) { asm("" : "+v"(x)); return x; }
 
-// Division.  Exact mode: the correctly rounded quotient by the chain the compiler itself expands
-// a / b to - reciprocal estimate, one Newton step on it, the quotient and two corrections of it
-// with exact (FMA) residuals, v_div_fixup_f32 for zeros, infinities and NaNs - without the two
-// v_div_scale_f32 and the v_div_fmas_f32 that rescale operands near the ends of the exponent range:
-// 30 instead of 40 clocks of VALU issue (profiles/tools/valu_rate.hip; a fifth of the shading
-// kernel's instructions are divisions).  The result is the IEEE quotient - independent of the
-// estimate - whenever v_div_scale_f32 would not have rescaled: |b| in [2^-126, 2^126), a = 0 or
-// |a| >= 2^-103, |a / b| in [2^-126, 2^96) (tests/test_gpu_arithmetic.py pins that).  The operands
-// here are radiances, densities, areas and lengths of O(1e-10 ... 1e10); like square_root below
+// Division.  IEEE modes: the correctly rounded quotient from v_rcp_f32 - the estimate refined by one
+// Newton step, the quotient, ONE correction of it with an exact (FMA) residual, v_div_fixup_f32 for
+// zeros, infinities and NaNs.  The compiler's expansion of a / b has a second correction and rescales
+// operands near the ends of the exponent range (two v_div_scale_f32, v_div_fmas_f32): 40 clocks of
+// VALU issue against 25 here (profiles/tools/valu_rate.hip; a fifth of the shading kernel's
+// instructions are divisions).  That one correction is enough on this hardware is not a theorem but
+// the result of trying every pair of significands, 2^23 x 2^23 quotients in 70 s on an MI355X
+// (profiles/tools/division_chains.hip, profiles/r03w/division_chains.txt: no mismatch against the
+// compiler's chain; the raw estimate with two corrections fails 26 621 times); powers of two scale every
+// intermediate value exactly, so the result is the IEEE quotient whenever v_div_scale_f32 would not
+// have rescaled: |b| in [2^-126, 2^126), a = 0 or |a| >= 2^-103, |a / b| in [2^-126, 2^96)
+// (tests/test_gpu_arithmetic.py pins that, and a slice of the search through compare_device_division()).
+// The operands here are radiances, densities, areas and lengths of O(1e-10 ... 1e10); like square_root below
 // this gives up the last decades of the exponent range, nothing else.
 // The IEEE quotient over the whole exponent range: the compiler's own expansion with the two
 // v_div_scale_f32 and the v_div_fmas_f32 (40 clocks).  For quotients that may leave the window of
@@ -109,7 +113,6 @@ VKR_DEV float divide(float a, float b) {
 	float r = __builtin_amdgcn_rcpf(b);
 	r = fmaf(fmaf(-b, r, 1.0f), r, r);
 	float q = a * r;
-	q = fmaf(fmaf(-b, q, a), r, q);
 	q = fmaf(fmaf(-b, q, a), r, q);
 	return __builtin_amdgcn_div_fixupf(q, b, a);
 #endif

@@ -1180,6 +1180,40 @@ extern "C" int compare_device_arithmetic(const device_t* device, uint32_t operat
 	return failed;
 }
 
+// compare_device_division(): divide() against the compiler's IEEE a / b for a block of divisor
+// significands and EVERY dividend significand (blockIdx.y = divisor, the threads of its blocks share the dividends)
+__global__ void __launch_bounds__(256) k_compare_division(uint32_t first_significand, uint32_t stride, uint32_t dividend_exponent, uint32_t divisor_exponent, unsigned long long* out) {
+	const uint32_t b_bits = (divisor_exponent << 23) | ((first_significand + blockIdx.y * stride) & 0x7FFFFFu);
+	const float b = __uint_as_float(b_bits);
+	unsigned long long mismatches = 0;
+	for (uint32_t m = blockIdx.x * 256u + threadIdx.x; m < (1u << 23); m += gridDim.x * 256u) {
+		const uint32_t a_bits = (dividend_exponent << 23) | m;
+		const float a = __uint_as_float(a_bits);
+		float mine = divide(a, b), theirs = __fdiv_rn(a, b);
+		bool same = __float_as_uint(mine) == __float_as_uint(theirs) || (mine != mine && theirs != theirs);
+		if (!same) { ++mismatches; atomicMin(out + 1, ((unsigned long long) b_bits << 32) | a_bits); }
+	}
+	if (mismatches) atomicAdd(out, mismatches);
+}
+
+extern "C" int compare_device_division(const device_t* device, uint32_t first_significand, uint32_t divisor_count, uint32_t stride, uint32_t dividend_exponent, uint32_t divisor_exponent, uint64_t out_mismatches_and_first[2]) {
+	if (!device || !out_mismatches_and_first || divisor_count == 0 || divisor_count > 65535u || dividend_exponent > 254u || divisor_exponent > 254u) {
+		printf("compare_device_division() needs a device, an output, 1 ... 65535 divisors and biased exponents below 255.\n");
+		return 1;
+	}
+	unsigned long long* counters = NULL;
+	if (hip_failed(hipMalloc(&counters, 2 * sizeof(unsigned long long)), "allocating counters")) return 1;
+	hipStream_t stream = (hipStream_t) device->stream;
+	unsigned long long initial[2] = {0ull, ~0ull};
+	int failed = hip_failed(hipMemcpyAsync(counters, initial, sizeof(initial), hipMemcpyHostToDevice, stream), "clearing counters");
+	if (!failed) {
+		k_compare_division<<<dim3(32, divisor_count), 256, 0, stream>>>(first_significand, stride, dividend_exponent, divisor_exponent, counters);
+		failed = vkr_copy_to_host(out_mismatches_and_first, counters, 2 * sizeof(unsigned long long), device);
+	}
+	(void) hipFree(counters);
+	return failed;
+}
+
 extern "C" int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count) {
 	if (!device || !a || !out || operation > 12 || ((operation == 0 || operation == 3 || operation == 10 || operation == 11) && !b)) {
 		printf("evaluate_device_arithmetic() needs a device, operands and an operation in 0 ... 12.\n");
