@@ -390,11 +390,11 @@ VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_t
 	device.  operation 0: divide(a, b), 1: square_root(a), 2: rsqrt(a) of the polynomial mode, 3: the
 	compiler's IEEE a / b, 4: the compiler's IEEE sqrtf(a); the functions of the libm mode
 	(csrc/glibc_math.h): 5 atanf, 6 acosf, 7 sinf, 8 cosf, 9 log2f, 10 powf(a, b), 11 atan2f(a, b),
-	12 inversesqrt as 1 / sqrt.  a, b (may be NULL for unary operations) and out are host arrays of
+	12 inversesqrt as 1 / sqrt (inverse_square_root_ieee).  a, b (may be NULL for unary operations) and out are host arrays of
 	`count` floats.  0 on success. */
 VKR_API int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count);
 /*! Two one-argument operations of evaluate_device_arithmetic (1 square_root, 4 the compiler's sqrtf, 5 atanf,
-	12 inversesqrt as divide(1, square_root), plus 16: the compiler's 1 / sqrtf, 17: atanf with its argument
+	12 inversesqrt as the kernels evaluate it, plus 16: the compiler's 1 / sqrtf, 17: atanf with its argument
 	range from the LDS table, as the libm kernels evaluate it) evaluated on the device
 	for the `count` (<= 2^32) consecutive bit patterns from `first_bits` on - e.g. every float - and
 	compared bit for bit (NaNs equal each other).  out[0]: arguments with different results, out[1]: the

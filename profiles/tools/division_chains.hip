@@ -18,8 +18,8 @@ constexpr int kChains = 3;
 struct findings {
 	unsigned long long mismatches[kChains];
 	unsigned first_a[kChains], first_b[kChains];
-	unsigned long long root_mismatches[2];
-	unsigned first_root[2];
+	unsigned long long root_mismatches[3];
+	unsigned first_root[3];
 	unsigned long long scale_mismatches[3];
 	unsigned first_scale[3];
 };
@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(256) k_quotients(unsigned first_divisor, findi
 	for (int c = 0; c != kChains; ++c) note(out, c, bad[c], bad_a[c], b_bits);
 }
 
-// correctly rounded square root as csrc/device_math.h square_root_unguarded() computes it (pinned against
-// sqrtf by tests/test_gpu_arithmetic.py)
+// correctly rounded square root by selection between the 1-ulp hardware result and its two neighbours
+// (csrc/device_math.h square_root_unguarded(); pinned against the compiler's sqrtf for every float of 200 binades)
 __device__ __forceinline__ float root_by_neighbours(float x) {
 	float s = __builtin_amdgcn_sqrtf(x);
 	float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
@@ -87,6 +87,12 @@ __global__ void __launch_bounds__(256) k_roots(findings* out) {
 	float s = __builtin_amdgcn_sqrtf(x);
 	float half_reciprocal = 0.5f * __builtin_amdgcn_rsqf(x);
 	float t = fmaf(fmaf(-s, s, x), half_reciprocal, s);
+	// 2: inversesqrt = 1 / sqrt by the one-correction chain with v_rsq_f32 as the reciprocal estimate, against
+	// the compiler's division of 1 by the exact root
+	float y = __builtin_amdgcn_rsqf(x);
+	float q = fmaf(fmaf(-exact, y, 1.0f), y, y);
+	q = fmaf(fmaf(-exact, q, 1.0f), q, q);
+	if (q != __fdiv_rn(1.0f, exact) && atomicAdd(&out->root_mismatches[2], 1ull) == 0ull) out->first_root[2] = x_bits;
 	if (g != exact && atomicAdd(&out->root_mismatches[0], 1ull) == 0ull) out->first_root[0] = x_bits;
 	if (t != exact && atomicAdd(&out->root_mismatches[1], 1ull) == 0ull) out->first_root[1] = x_bits;
 }
@@ -145,9 +151,9 @@ int main(int argc, char** argv) {
 		if (host.mismatches[c]) printf(" (e.g. 0x%08x / 0x%08x)", host.first_a[c], host.first_b[c]);
 		printf("\n");
 	}
-	const char* root_names[2] = {"v_rsq_f32, coupled iteration (5 FMAs, 2 products)", "v_sqrt_f32 + one correction by 0.5 v_rsq_f32"};
+	const char* root_names[3] = {"v_rsq_f32, coupled iteration (5 FMAs, 2 products)", "v_sqrt_f32 + one correction by 0.5 v_rsq_f32", "1 / sqrt: v_rsq_f32 refined once, one correction"};
 	printf("square roots: 2^24 arguments in [1, 4)\n");
-	for (int c = 0; c != 2; ++c) {
+	for (int c = 0; c != 3; ++c) {
 		printf("  %-62s %llu mismatches", root_names[c], host.root_mismatches[c]);
 		if (host.root_mismatches[c]) printf(" (e.g. 0x%08x)", host.first_root[c]);
 		printf("\n");

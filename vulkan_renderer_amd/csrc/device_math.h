@@ -139,16 +139,46 @@ VKR_DEV float square_root_unguarded(float x) {
 	s = (residual_above > 0.0f) ? above : s;
 	return s;
 }
-// (Round 3 tried Markstein's coupled iterations - sqrt and 1 / sqrt from one v_rsq_f32 estimate, 38 instead of
-// 65 clocks per inversesqrt: the last FMA does not always land on the correctly rounded value (a config-3 frame
-// differed from the oracle's, RMSE 1.5e-3) and the kernel got 1 % faster; profiles/r03k/markstein_roots.jsonl.)
+// (Round 3 tried three chains with fewer instructions, each exact for every significand - searched in
+// profiles/tools/division_chains.hip - or shown not to be: (a) the hardware root corrected once,
+// s + (x - s s) (0.5 v_rsq_f32(x)), and a v_cmp_class_f32 selection for zeros, infinity and NaN: exact,
+// 33 against 35 clocks by the price list, but 1 % SLOWER in the kernel (config 3, three runs each on one
+// box: 1.603 against 1.587 ms per frame - a second transcendental instruction per root costs more in these
+// dependent chains than its issue slot); (b) Markstein's coupled iteration from v_rsq_f32 alone: exact as
+// well, the same selection, no cheaper; (c) inversesqrt by divide()'s chain with v_rsq_f32(x) as the
+// reciprocal estimate: fails for the two significands whose root has a significand of all ones, 1 - 2^-24
+// and 1 - 2^-23 - the squared length of every vector that is normalised a second time, 637 872 pixels of a
+// config-3 frame.)
+// VKR_SQRT_VARIANT (A/B knob, profiles/r03x/): 0 the selection above; 1 the same with the special cases
+// spelled out by a second selection (until round 3); 2 the hardware root corrected once with half of
+// v_rsq_f32(x) as the reciprocal and a v_cmp_class_f32 selection for everything that is not a positive normal number
+#ifndef VKR_SQRT_VARIANT
+#define VKR_SQRT_VARIANT 0
+#endif
 VKR_DEV float square_root(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_sqrtf(x);
-#else
+#elif VKR_SQRT_VARIANT == 2
+	float estimate = __builtin_amdgcn_sqrtf(x);
+	float s = fmaf(fmaf(-estimate, estimate, x), 0.5f * __builtin_amdgcn_rsqf(x), estimate);
+	return __builtin_amdgcn_classf(x, 0x100) ? s : estimate;
+#elif VKR_SQRT_VARIANT == 1
 	float s = square_root_unguarded(x);
-	// +-0 and +inf map to themselves (spelled out; square_root_unguarded explains why it would hold anyway)
 	return (x == 0.0f || x == __builtin_inff()) ? x : s;
+#else
+	// (+-0, +inf, NaN and negative arguments come out as IEEE wants them without a selection:
+	// square_root_unguarded says why, tests/test_gpu_arithmetic.py checks it.  Until round 3 a
+	// selection spelled it out, variant 1: the same frame time, 1.586 against 1.587 ms.)
+	return square_root_unguarded(x);
+#endif
+}
+// inversesqrt as the oracle's math mode 0 (and the reference shader compiled as C++) evaluates it:
+// two correctly rounded operations, 1 / sqrt(x)
+VKR_DEV float inverse_square_root_ieee(float x) {
+#if VKR_SQRT_VARIANT == 2
+	return divide(1.0f, square_root(x));
+#else
+	return divide(1.0f, square_root_unguarded(x));
 #endif
 }
 // GLSL inversesqrt.  Exact mode: integer seed, two Newton steps and one in residual form
@@ -158,9 +188,7 @@ VKR_DEV float rsqrt(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_rsqf(x);
 #elif VKR_LIBM_MATH && !(VKR_LIBM_EXCEPT & 2)
-	// two correctly rounded operations, as the oracle's math mode 0 (and the reference shader
-	// compiled as C++) evaluates inversesqrt
-	return divide(1.0f, square_root_unguarded(x));
+	return inverse_square_root_ieee(x);
 #else
 	float hx = 0.5f * x;
 	float y = __uint_as_float(0x5F3759DFu - (__float_as_uint(x) >> 1));

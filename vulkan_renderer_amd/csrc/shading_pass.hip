@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(256) k_evaluate_arithmetic(uint32_t operation,
 	case 9: out[i] = gm_log2f(x); break;
 	case 10: out[i] = gm_powf(x, y); break;
 	case 11: out[i] = gm_atan2f(x, y); break;
-	case 12: out[i] = divide(1.0f, square_root_unguarded(x)); break;
+	case 12: out[i] = inverse_square_root_ieee(x); break;
 	default: out[i] = rsqrt(x); break;  // (what the kernels of this unit's arithmetic mode use)
 	}
 }
@@ -1142,7 +1142,7 @@ __device__ __forceinline__ float evaluate_unary(uint32_t operation, float x, con
 	case 1: return square_root(x);
 	case 4: return sqrtf(x);
 	case 5: return gm_atanf(x);
-	case 12: return divide(1.0f, square_root_unguarded(x));
+	case 12: return inverse_square_root_ieee(x);
 	case 16: return 1.0f / sqrtf(x);
 	default: return rsqrt(x);
 	}
