@@ -35,9 +35,11 @@ def encode_octahedral_normals(normals):
     return q[..., 0], q[..., 1]
 
 
-def write_vks(path, positions, normals, uvs, material_indices, material_names, sort_triangles=True):
+def write_vks(path, positions, normals, uvs, material_indices, material_names, sort_triangles=True, shuffle_seed=None):
     """positions, normals: (T, 3, 3); uvs: (T, 3, 2); material_indices: (T,).
-    Returns the dict of buffers exactly as they are stored in the file."""
+    Returns the dict of buffers exactly as they are stored in the file.  shuffle_seed: store the triangles
+    in a random order instead of along a Morton curve (neighbours in the file are then unrelated in space:
+    the worst case for everything that combines the contributions of consecutive triangles)."""
     positions = np.asarray(positions, np.float32)
     normals = np.asarray(normals, np.float32)
     uvs = np.asarray(uvs, np.float32).copy()
@@ -51,6 +53,10 @@ def write_vks(path, positions, normals, uvs, material_indices, material_names, s
         g = np.clip(((c - c.min(axis=0)) / np.maximum(np.ptp(c, axis=0), 1e-12) * 1023.0), 0, 1023).astype(np.uint64)
         code = (_morton_10(g[:, 0]) << np.uint64(2)) | (_morton_10(g[:, 1]) << np.uint64(1)) | _morton_10(g[:, 2])
         order = np.argsort(code, kind="stable")
+        positions, normals, uvs, material_indices = positions[order], normals[order], uvs[order], material_indices[order]
+        flat = positions.reshape(-1, 3).astype(np.float64)
+    if shuffle_seed is not None:
+        order = np.random.default_rng(shuffle_seed).permutation(T)
         positions, normals, uvs, material_indices = positions[order], normals[order], uvs[order], material_indices[order]
         flat = positions.reshape(-1, 3).astype(np.float64)
     # 21 bits per coordinate; the summand places samples at cell centres
@@ -457,7 +463,7 @@ CONFIG_SETTINGS = {
 }
 
 
-def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51, textured=False, texture_size=64):
+def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51, textured=False, texture_size=64, shuffle_seed=None):
     """Writes scene.vks, textures/, ltc/ below `directory` and returns the paths.  textured:
     real images (BC1 / RGBA8 / BC5 with mip chains) instead of constant material textures."""
     os.makedirs(directory, exist_ok=True)
@@ -466,7 +472,7 @@ def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=3
         write_textured_material_textures(os.path.join(directory, "textures"), names, texture_size)
     positions, normals, uvs, mats = make_scene_geometry(grid, box_count, seed, materials=len(names))
     scene_path = os.path.join(directory, "scene.vks")
-    write_vks(scene_path, positions, normals, uvs, mats, names)
+    write_vks(scene_path, positions, normals, uvs, mats, names, shuffle_seed=shuffle_seed)
     ltc_dir = os.path.join(directory, "ltc")
     write_ltc_fits(ltc_dir, ltc_resolution, fresnel_count)
     return {"scene": scene_path, "textures": os.path.join(directory, "textures"), "ltc": ltc_dir, "fresnel_count": fresnel_count,
