@@ -154,27 +154,73 @@ VKR_DEV float unorm16(uint32_t v) {
 
 // ---- noise (noise_utility.glsl:63-103) ---------------------------------------------
 
+// The texel of the NEXT fetch is requested as soon as the current one has been unpacked (VKR_NOISE_AHEAD):
+// a fetch is the one vector load of a sample, and it used to be waited for right where it was issued -
+// which, on this hardware, also means waiting for every store before it: loads and stores share the
+// vector-memory counter and complete out of order with each other, so the wait for a load with stores in
+// flight is a wait for all of them (s_waitcnt vmcnt(0): the terms and rays of the sample before, a round
+// trip to the L2).  With the request a sample ahead and the wait pinned in front of the sample's own stores
+// (settle_noise(), called by accumulate()) both the load and the earlier stores have long completed
+// when the wave asks.  Two more live registers.
+#ifndef VKR_NOISE_AHEAD
+#define VKR_NOISE_AHEAD 1
+#endif
 struct noise_accessor {
 	float n0, n1, n2, n3;
 	uint32_t available, px, py, sample_index;
+	uint32_t ahead_x, ahead_y;  // texel of fetch number sample_index, on its way or there
 };
+
+VKR_DEV uint2 fetch_noise_texel(const shade_params& p, const noise_accessor& a) {
+	const uint8_t* c = p.constants;
+	uint32_t s = a.sample_index;
+	uint32_t r0 = load_u(c, 208), r1 = load_u(c, 212), r2 = load_u(c, 216), r3 = load_u(c, 220);
+	if (s & 2) { uint32_t t0 = r0, t1 = r1; r0 = r2; r1 = r3; r2 = t0; r3 = t1; }
+	if (s & 1) { r0 = r1; r1 = r2; r2 = r3; }
+	uint32_t shift = (s & 124) >> 2;
+	uint32_t layer = (r2 + s) & load_u(c, 192);
+	uint32_t sx = (a.px + (r0 >> shift)) & load_u(c, 184);
+	uint32_t sy = (a.py + (r1 >> shift)) & load_u(c, 188);
+	return p.noise[((size_t) layer * p.noise_height + sy) * p.noise_width + sx];
+}
+
+VKR_DEV noise_accessor make_noise_accessor(const shade_params& p, uint32_t px, uint32_t py) {
+	noise_accessor a;
+	a.n0 = a.n1 = a.n2 = a.n3 = 0.0f;
+	a.available = 0; a.px = px; a.py = py; a.sample_index = 0;
+	a.ahead_x = a.ahead_y = 0u;
+#if VKR_NOISE_AHEAD
+	uint2 texel = fetch_noise_texel(p, a);
+	a.ahead_x = texel.x; a.ahead_y = texel.y;
+#endif
+	return a;
+}
+
+// The requested texel has to have arrived from here on (an empty statement that "uses" its registers)
+VKR_DEV void settle_noise(noise_accessor& a) {
+#if VKR_NOISE_AHEAD
+	asm volatile("" : "+v"(a.ahead_x), "+v"(a.ahead_y));
+#else
+	(void) a;
+#endif
+}
 
 VKR_DEV f2 next_noise_2(const shade_params& p, noise_accessor& a) {
 	if (a.available <= 1) {
-		const uint8_t* c = p.constants;
-		uint32_t s = a.sample_index;
-		uint32_t r0 = load_u(c, 208), r1 = load_u(c, 212), r2 = load_u(c, 216), r3 = load_u(c, 220);
-		if (s & 2) { uint32_t t0 = r0, t1 = r1; r0 = r2; r1 = r3; r2 = t0; r3 = t1; }
-		if (s & 1) { r0 = r1; r1 = r2; r2 = r3; }
-		uint32_t shift = (s & 124) >> 2;
-		uint32_t layer = (r2 + s) & load_u(c, 192);
-		uint32_t sx = (a.px + (r0 >> shift)) & load_u(c, 184);
-		uint32_t sy = (a.py + (r1 >> shift)) & load_u(c, 188);
-		uint2 texel = p.noise[((size_t) layer * p.noise_height + sy) * p.noise_width + sx];
+#if VKR_NOISE_AHEAD
+		uint2 texel = make_uint2(a.ahead_x, a.ahead_y);
+#else
+		uint2 texel = fetch_noise_texel(p, a);
+#endif
 		a.n0 = unorm16(texel.x & 0xFFFF); a.n1 = unorm16(texel.x >> 16);
 		a.n2 = unorm16(texel.y & 0xFFFF); a.n3 = unorm16(texel.y >> 16);
 		a.available = 4;
 		++a.sample_index;
+#if VKR_NOISE_AHEAD
+		// (one texel beyond the last one a pixel uses: the coordinates wrap, the read is harmless)
+		uint2 ahead = fetch_noise_texel(p, a);
+		a.ahead_x = ahead.x; a.ahead_y = ahead.y;
+#endif
 	}
 	a.available -= 2;
 	f2 r = mk2(a.n0, a.n1);
@@ -687,6 +733,8 @@ struct pixel_context {
 	// this thread's column of the LDS tables of the prepared polygons (strategies with two
 	// techniques per light: 2 x kPsaTableSlots(V) slots, [slot][thread]), else NULL
 	float2* psa_tables;
+	// the pixel's noise accessor (accumulate() settles its outstanding request before it stores), or NULL
+	noise_accessor* noise;
 };
 
 // get_polygon_radiance_visibility_brdf_product, shading_pass.frag.glsl:203-231, without
@@ -706,9 +754,13 @@ VKR_DEV bool all_zero(f3 v) { return ((__float_as_uint(v.x) | __float_as_uint(v.
 // The block of queue slots that a wave has reserved and not used up yet: (first free slot,
 // slots left, real rays written so far, unused).  Wave-uniform state that lanes update while
 // the wave is diverged, hence in LDS (one entry per wave of the workgroup) and volatile.
-VKR_DEV volatile uint32_t* ray_block_state() {
+// (As an LDS pointer, not a generic one: the compiler does not infer the address space of volatile
+// accesses, and FLAT loads return through the vector-memory counter IN ORDER - every push_ray() then waited
+// for the global stores of the term before it, a round trip to the L2 per ray.)
+typedef __attribute__((address_space(3))) volatile uint32_t lds_state_word;
+VKR_DEV lds_state_word* ray_block_state() {
 	__shared__ uint32_t state[4 * 4];
-	return state + 4 * (threadIdx.x >> 6);
+	return (lds_state_word*) (state + 4 * (threadIdx.x >> 6));
 }
 
 // Appends one shadow ray to the queue of this wave.  Lanes of the wave that arrive here
@@ -729,7 +781,7 @@ VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 dir, float t_max
 		slot_in_queue = __builtin_amdgcn_readfirstlane(base) + prefix;
 	}
 	else {
-		volatile uint32_t* state = ray_block_state();
+		lds_state_word* state = ray_block_state();
 		uint32_t old_base = __builtin_amdgcn_readfirstlane(state[0]), left = __builtin_amdgcn_readfirstlane(state[1]);
 		uint32_t new_base = 0;
 		if (count > left) {
@@ -752,7 +804,7 @@ VKR_DEV void push_ray(const shade_params& p, uint32_t queue, f3 dir, float t_max
 // At the end of a shading wave: slots of its last block that no ray took become null rays (the
 // tracing kernel skips them), and the wave's ray count goes to its XCD's counter.
 VKR_DEV void close_ray_block(const shade_params& p, uint32_t queue) {
-	volatile uint32_t* state = ray_block_state();
+	lds_state_word* state = ray_block_state();
 	uint64_t mask = __ballot(1);
 	uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 	uint32_t lanes = (uint32_t) __popcll(mask);
@@ -790,6 +842,7 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		bool needs_ray = candidate && (hidden_matters || !all_zero(visible_term));
 		bool is_final = !candidate && !all_zero(visible_term);
 		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
+			if (ctx.noise) settle_noise(*ctx.noise);
 			size_t code_index = code_slot(p.thread_count, ctx.code_cursor, ctx.tid);
 			size_t term_index = ((size_t) ctx.term_cursor * p.thread_count + ctx.tid) * 3;
 			// (terms_hidden exists for the one estimator whose blocked terms have values, the optimal heuristic)
@@ -891,6 +944,8 @@ VKR_DEV void mis_estimate_pair(int heuristic, f3 lit, f3 dark, f3 sw, float sd, 
 // get_polygonal_light_mis_estimate, shading_pass.frag.glsl:305-323
 template <int STRATEGY, int RAYS, bool TEXTURED>
 VKR_DEV void add_light_mis_estimate(pixel_context& ctx, f3& result, f3 dir, float density, const shading_data& sd, const light_ref& light) {
+	// (once per sample and on every path through it, so that no request is outstanding at the top of the loop)
+	if (ctx.noise) settle_noise(*ctx.noise);
 	float lambert;
 	bool candidate;
 	f3 rb = radiance_brdf<true, true, TEXTURED>(ctx.p, lambert, candidate, dir, sd, light);
@@ -952,6 +1007,9 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 	constexpr bool kTextured = ERROR == kLightTextures;
 	constexpr bool kBiased = TECHNIQUE == kTechniquePsaBiased;
 	constexpr bool kIsPsa = TECHNIQUE == kTechniquePsa || TECHNIQUE == kTechniquePsaBiased;
+	// (no request is outstanding when a sampling loop is entered - the first one was made when the pixel
+	// started - or the wait for it would sit at the top of the loop and be paid by every sample)
+	settle_noise(noise);
 	const uint32_t S = p.sample_count;
 	const uint32_t count = light_vertex_count(light);
 	const f3 zero = mk3(0.0f, 0.0f, 0.0f);
@@ -1201,6 +1259,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 				for (uint32_t s = 0; s != S; ++s) {
 					f3 dd = sample_psa_tables<V, kBiased>(pd, tables_d, next_noise_2(p, noise));
 					dd = mul_transposed(world_to_shading, dd);
+					settle_noise(noise);
 					float lambert;
 					bool candidate;
 					f3 rb = radiance_brdf<true, false, kTextured>(p, lambert, candidate, dd, sd, light);
@@ -1246,6 +1305,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 						dir_s = sample_psa_tables<V, kBiased>(ps, tables_s, next_noise_2(p, noise));
 						dir_s = normalize(cosine_to_shading(ltc_in, dir_s));
 					}
+					settle_noise(noise);
 					for (uint32_t j = 0; j != technique_count; ++j) {
 						f3 ds = (j == 0) ? dir_d : dir_s;
 						if (ds.z <= 0.0f) continue;
@@ -1284,6 +1344,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 					u.x = divide(u.x - offset, diffuse_ratio - offset);
 					f3 ds = specular_selected ? sample_psa_tables<V, kBiased>(ps, tables_s, u) : sample_psa_tables<V, kBiased>(pd, tables_d, u);
 					if (specular_selected) ds = normalize(cosine_to_shading(ltc_in, ds));
+					settle_noise(noise);
 					float lambert = ds.z;
 					float dens_d = lambert * diffuse_albedo;
 					float dens_s = evaluate_ltc_density(ltc_in, ds, specular_albedo);
@@ -1311,6 +1372,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 			float ggx_density;
 			f3 dg = sample_ggx_reflected(ggx_density, out_shading, sd.roughness, next_noise_2(p, noise));
 			f3 dw = mul_transposed(world_to_shading, dg);
+			settle_noise(noise);
 			if (dg.z > 0.0f && light_ray_intersection(light, p.max_light_vertex_count, sd.position, dw, 0.0f)) {
 				float lambert;
 				bool candidate;
@@ -1324,6 +1386,7 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 	if constexpr (is_deferred(RAYS)) {
 		// close this light's run of terms; the resolve kernel scales by 1 / S and adds it
 		if (ctx.light_has_terms && ctx.code_cursor + 1 < p.max_codes) {
+			if (ctx.noise) settle_noise(*ctx.noise);
 			p.codes[code_slot(p.thread_count, ctx.code_cursor, ctx.tid)] = (uint8_t) kCodeEndOfLight;
 			++ctx.code_cursor;
 			ctx.light_has_terms = false;
@@ -1418,10 +1481,10 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
-	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr};
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
-		volatile uint32_t* state = ray_block_state();
+		lds_state_word* state = ray_block_state();
 		if ((threadIdx.x & 63u) == 0) { state[0] = 0; state[1] = 0; state[2] = 0; }
 	}
 	if (inside) {
@@ -1455,9 +1518,8 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 		if (primitive != 0xFFFFFFFFu) {
 			float fresnel_luminance = (sd.fresnel_0.x * 0.2126f + sd.fresnel_0.y * 0.7152f) + sd.fresnel_0.z * 0.0722f;
 			ltc_coefficients ltc = get_ltc_coefficients(p, fresnel_luminance, sd.roughness, sd.position, sd.normal, sd.outgoing);
-			noise_accessor noise;
-			noise.n0 = noise.n1 = noise.n2 = noise.n3 = 0.0f;
-			noise.available = 0; noise.px = px; noise.py = py; noise.sample_index = 0;
+			noise_accessor noise = make_noise_accessor(p, px, py);
+			ctx.noise = &noise;
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);
