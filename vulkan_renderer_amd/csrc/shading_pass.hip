@@ -242,7 +242,17 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 
 // Slots a shading wave reserves per atomic (shade_params.ray_block): pays off when a lane
 // queues many rays; with one or two per lane the unused slots would outnumber the rays.
-static uint32_t ray_block_size(uint32_t max_terms) { return max_terms >= 8 ? 256u : 0u; }
+// VKR_RAY_BLOCK (a multiple of 64, read once per process): the slots per block; unused slots of a wave's last
+// block become null rays, a contiguous run that the tracing kernel skips a batch at a time.
+static uint32_t ray_block_size(uint32_t max_terms) {
+	static uint32_t slots = 0;
+	if (!slots) {
+		const char* text = getenv("VKR_RAY_BLOCK");
+		long value = text ? strtol(text, NULL, 10) : 0;
+		slots = (value >= 64 && value <= 8192 && value % 64 == 0) ? (uint32_t) value : 256u;
+	}
+	return max_terms >= 8 ? slots : 0u;
+}
 
 static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t in_lds, uint32_t trace_threads) {
 	size_t entries = stack_need > in_lds ? (size_t) (stack_need - in_lds) * trace_threads : 0;
