@@ -225,7 +225,7 @@ typedef struct shading_pass_s {
 	/*! Frames with wavefront shadow rays are rendered in `band_count` launches over consecutive parts of
 		the frame ("bands"), each shaded, traced and resolved with wavefront buffers sized for the band;
 		bands overlap on the frame streams like frames do.  0 (default): as few bands as keep all sets of
-		buffers in flight within the budget (24 GiB, environment VKR_WAVEFRONT_BUDGET_MIB) - one for
+		buffers in flight within the budget (36 GiB, environment VKR_WAVEFRONT_BUDGET_MIB) - one for
 		1920x1080 frames, eight for BASELINE config 4.  Set before create_shading_pass like
 		arithmetic_mode.  last_band_count: what the most recent frame used. */
 	uint32_t band_count, last_band_count;

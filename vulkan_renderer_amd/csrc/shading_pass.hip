@@ -179,7 +179,8 @@ struct frame_pipeline {
 	// two per wave: 0.129 -> 0.121 ms per frame)
 	// VKR_TRACE_SINGLE_WAVES: 0 / 1 overrides the choice of the tracing kernel's workgroup size (2: automatic)
 	// VKR_WAVEFRONT_BUDGET_MIB: most device memory that all sets of wavefront buffers in flight may take
-	// (default 24576: a frame whose worst case needs more is rendered in bands); VKR_BAND_COUNT forces
+	// (default 36864 - config 4 then runs as three bands of 12 GB, the fastest of 1 ... 12 bands, profiles/r04c/: a
+	// frame whose worst case needs more is rendered in bands); VKR_BAND_COUNT forces
 	// the number of bands per frame (0: automatic)
 	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count;
 };
@@ -224,7 +225,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
 	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
-	frames->wavefront_budget_mib = environment_knob("VKR_WAVEFRONT_BUDGET_MIB", 24576u, 64u, 262144u);
+	frames->wavefront_budget_mib = environment_knob("VKR_WAVEFRONT_BUDGET_MIB", 36864u, 64u, 262144u);
 	frames->band_count = environment_knob("VKR_BAND_COUNT", 0u, 0u, 4096u);
 	const char* priority = getenv("VKR_TRACE_STREAM_PRIORITY");
 	if (priority && strcmp(priority, "high") == 0) {
