@@ -2,7 +2,9 @@
 """Benchmark of the shading pass (BASELINE.json: Msamples/s = pixels x spp / s).
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...                      (starts its N ranks itself: launch_ranks() below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --dry-launch             (no GPU: the ranks only rendezvous over gloo)
 
 A step is one pass of the shading kernels over one frame: write_constants -> upload ->
 shade / trace / resolve over the rank's tiles [-> all-gather of the tile slabs -> scatter
@@ -110,6 +112,93 @@ def available_cpus():
     return count
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(rank_count, argv):
+    """`python bench.py --gpus N` without a launcher around it: starts N copies of this script, one per
+    GPU, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR = 127.0.0.1, a free MASTER_PORT) and waits for them.  The ranks inherit stdout, so the
+    one JSON line rank 0 prints is the last line of this process's output too.  If a rank fails, the
+    others are stopped (by PID) and its exit code is returned."""
+    import signal
+    import subprocess
+    port = free_port()
+    children = []
+    for rank in range(rank_count):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(rank_count), "LOCAL_WORLD_SIZE": str(rank_count),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VKR_BENCH_SELF_LAUNCHED": "1"})
+        # dmabuf IPC is the only kind the host driver supports (RCCL fails with hipIpcGetMemHandle otherwise)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("GPU_MAX_HW_QUEUES", "8")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    exit_code = 0
+    pending = set(range(rank_count))
+    try:
+        while pending:
+            for rank in sorted(pending):
+                code = children[rank].poll()
+                if code is None:
+                    continue
+                pending.discard(rank)
+                if code != 0 and exit_code == 0:
+                    exit_code = code if code > 0 else 1
+                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (rank, code), file=sys.stderr, flush=True)
+                    for other in pending:
+                        children[other].send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for rank in pending:
+            children[rank].send_signal(signal.SIGTERM)
+        exit_code = 130
+    for child in children:
+        try:
+            child.wait(timeout=10)
+        except Exception:
+            child.kill()
+    return exit_code
+
+
+def dry_launch(args):
+    """--dry-launch: what every rank does before it touches a GPU - join the process group (gloo, CPU),
+    carry rank 0's 128-byte rendezvous token to all ranks, a barrier and a max over ranks - and one
+    JSON line from rank 0.  Proves that the launch path of `--gpus N` works on a machine without GPUs."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    t0 = time.perf_counter()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    token = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        token.copy_(torch.arange(128, dtype=torch.uint8) * 3 + 1)
+    seen = torch.tensor([1.0], dtype=torch.float64)
+    slowest = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.broadcast(token, src=0)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    token_ok = bool((token == torch.arange(128, dtype=torch.uint8) * 3 + 1).all())
+    if world > 1:
+        dist.destroy_process_group()
+    if not token_ok:
+        raise SystemExit("rank %d did not receive rank 0's token" % rank)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": int(seen.item()), "highest_rank": int(slowest.item()), "token_ok": token_ok,
+                          "self_launched": os.environ.get("VKR_BENCH_SELF_LAUNCHED") == "1", "backend": "gloo",
+                          "rendezvous_ms": round((time.perf_counter() - t0) * 1e3, 1), "master_port": int(os.environ.get("MASTER_PORT", "0"))}), flush=True)
+
+
 class Job:
     """What all workloads of one bench.py run share: ranks, torch handles, the dataset."""
 
@@ -177,6 +266,24 @@ class Job:
         self.dist.broadcast(t, src=0)
         return bytes(t.cpu().numpy().tobytes())
 
+    def host_staged_gather(self):
+        """A slab_gather_function_t for a CPU process group: wait for the slab, copy it to the host, all-gather
+        there, copy the gathered slabs back.  Slow and synchronous - it exists so that the N-rank schedule of
+        this file can run end to end on a box with one GPU, never for a number."""
+        hip = ctypes.CDLL("libamdhip64.so")
+        torch, dist = self.torch, self.dist
+
+        def gather(rank, buffer_set, send, gathered, send_bytes, stream):
+            mine = torch.empty(send_bytes, dtype=torch.uint8)
+            everyone = torch.empty(send_bytes * self.world, dtype=torch.uint8)
+            if hip.hipStreamSynchronize(ctypes.c_void_p(stream)):
+                return 1
+            if hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send), ctypes.c_size_t(send_bytes), 2):
+                return 1
+            dist.all_gather_into_tensor(everyone, mine)
+            return int(hip.hipMemcpy(ctypes.c_void_p(gathered), ctypes.c_void_p(everyone.data_ptr()), ctypes.c_size_t(send_bytes * self.world), 1) != 0)
+        return gather
+
     def close(self):
         if self.process_group:
             self.dist.destroy_process_group()
@@ -229,8 +336,13 @@ def run_workload(job, config, primary):
     slab = None
     if exchange != "none":
         # the rendezvous token comes from rank 0 (ncclGetUniqueId behind the C-ABI) over the process group
-        token = job.broadcast_bytes(r.exchange_id() if rank == 0 else b"", 128)
-        r.create_exchange(token, exchange)
+        if job.backend == "nccl":
+            token = job.broadcast_bytes(r.exchange_id() if rank == 0 else b"", 128)
+            r.create_exchange(token, exchange)
+        else:
+            # CPU process group (VKR_BENCH_BACKEND=gloo: several ranks on ONE GPU, where RCCL refuses to form a
+            # communicator): the same schedule with the collective staged through the host
+            r.create_exchange_with_gather(job.host_staged_gather(), exchange)
 
         def step():
             r.render_and_exchange(None)
@@ -601,7 +713,15 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")
     ap.add_argument("--ltc-resolution", type=int, default=64, help="roughness / inclination resolution R of the generated LTC tables (SURVEY.md 8d: 64)")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path (slab layout, exchange) even with one rank")
+    ap.add_argument("--dry-launch", action="store_true", help="no GPU work: the ranks join a gloo process group, exchange a token, print one JSON line and leave (checks the launch path of --gpus N)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` by itself: become the launcher of N ranks (one per GPU)
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "VKR_BENCH_SELF_LAUNCHED" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_launch:
+        dry_launch(args)
+        return
 
     job = Job(args)
     result = run_workload(job, args.config, True)

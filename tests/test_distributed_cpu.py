@@ -84,3 +84,49 @@ def test_slab_sizes_are_balanced():
         sizes.append(lib.get_slab_pixel_count(C.byref(app), rank))
     assert max(sizes) - min(sizes) <= 32 * 32
     assert sum(sizes) >= 1920 * 8640
+
+
+def _run_bench(arguments, extra_env=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VKR_BENCH_SELF_LAUNCHED")}
+    env.update(extra_env or {})
+    done = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + arguments, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    return done, [json.loads(line) for line in lines]
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_starts_its_own_ranks_without_a_launcher(ranks):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver starts the N = 1 bench):
+    N ranks are spawned, rendezvous on a free port and rank 0 prints exactly one JSON line."""
+    done, lines = _run_bench(["--gpus", str(ranks), "--dry-launch"])
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert len(lines) == 1, done.stdout
+    line = lines[0]
+    assert line["dry_launch"] and line["self_launched"] and line["token_ok"]
+    assert line["n_gpus"] == ranks and line["ranks_seen"] == ranks and line["highest_rank"] == ranks - 1
+
+
+def test_bench_under_a_launcher_does_not_spawn_again():
+    """with RANK / WORLD_SIZE given (torch.distributed.run, or the ranks bench.py spawned) the script is a rank"""
+    port = _free_port()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    children = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("VKR_BENCH_SELF_LAUNCHED", None)
+        children.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, cwd=root, stdout=subprocess.PIPE, text=True))
+    outputs = [child.communicate(timeout=240)[0] for child in children]
+    assert all(child.returncode == 0 for child in children)
+    assert '"self_launched": false' in outputs[0] and "dry_launch" not in outputs[1]
+
+
+def test_a_failing_rank_ends_the_launcher_with_its_exit_code():
+    """a rank count that does not match: every rank refuses, the launcher reports failure instead of hanging"""
+    done, lines = _run_bench(["--gpus", "2", "--dry-launch"], {"VKR_BENCH_SELF_LAUNCHED": "1", "WORLD_SIZE": "1"})
+    assert done.returncode != 0 and not lines

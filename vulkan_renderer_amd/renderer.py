@@ -347,6 +347,24 @@ class Renderer(HostScene):
             self.exchange = None
             raise RuntimeError("create_slab_exchange failed")
 
+    def create_exchange_with_gather(self, gather, slab_format="rgba32f"):
+        """An exchange whose collective is the Python callable gather(rank, set, send_pointer, gathered_pointer,
+        send_bytes, stream) -> 0 on success (include/vkr_slab_exchange.h slab_gather_function_t): any transport
+        the caller has, e.g. a host-staged all-gather over a CPU process group."""
+        prototype = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+        def trampoline(context, rank, buffer_set, send, gathered, send_bytes, stream):
+            try:
+                return int(gather(int(rank), int(buffer_set), int(send or 0), int(gathered or 0), int(send_bytes), int(stream or 0)))
+            except Exception as error:  # an exception must not unwind through the C frames
+                print("slab gather callback failed: %r" % (error,), flush=True)
+                return 1
+        self._gather_keepalive = prototype(trampoline)
+        self.exchange = capi.SlabExchange()
+        if self.lib.create_slab_exchange_with_gather(C.byref(self.exchange), C.byref(self.app), C.cast(self._gather_keepalive, C.c_void_p), None, capi.SLAB_FORMAT[slab_format]):
+            self.exchange = None
+            raise RuntimeError("create_slab_exchange_with_gather failed")
+
     def create_local_exchange(self, group, slab_format="rgba32f"):
         """Joins a group made by capi.load().create_local_slab_group(rank_count): ranks of this process that
         exchange their slabs with device-to-device copies (call from the rank's own thread)"""
