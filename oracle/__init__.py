@@ -117,6 +117,20 @@ def set_math_mode(mode):
     lib().oracle_set_math_mode(int(mode))
 
 
+def set_libm_source(source):
+    """"port" (default): the oracle's transcendentals are the restatement of glibc 2.35 in
+    vulkan_renderer_amd/csrc/glibc_math.h - identical frames on every machine; "system": this machine's
+    C library (what the compiled reference shader under oracle/_ref calls)."""
+    lib().oracle_set_libm_source({"port": 0, "system": 1}[source])
+
+
+def libm_description():
+    if lib().oracle_get_libm_source():
+        return "transcendentals by the C library of this machine"
+    return ("transcendentals by the restatement of glibc 2.35's float functions (x86-64 FMA / AVX2 IFUNC variants; csrc/glibc_math.h), "
+            "equal to that library for all 2^32 arguments of every one-argument function (profiles/r03a/glibc_math_exhaustive.txt, tests/test_glibc_math.py)")
+
+
 # operation codes of oracle_libm.c == evaluate_device_arithmetic (include/vkr_shading_pass.h)
 LIBM_OPERATIONS = {"atan": 5, "acos": 6, "sin": 7, "cos": 8, "log2": 9, "pow": 10, "atan2": 11, "inverse_sqrt": 12, "atan_rows": 13}
 

@@ -116,6 +116,10 @@ void oracle_shade_pixel(const oracle_frame_t* frame, uint32_t x, uint32_t y, flo
 uint64_t oracle_last_ray_count(void);
 /* 0 = libm transcendental functions, 1 = the polynomial forms shared with the GPU */
 void oracle_set_math_mode(int mode);
+/* where the transcendentals of math mode 0 come from: 0 (default) the restatement of glibc 2.35 in
+ * vulkan_renderer_amd/csrc/glibc_math.h (the same on every machine), 1 the C library of this machine */
+void oracle_set_libm_source(int use_system_library);
+int oracle_get_libm_source(void);
 
 /* Output encodings of the reference (shading_pass.frag.glsl:871-892) */
 void oracle_encode_srgb8(const float* rgba, uint8_t* out_rgba8, uint64_t pixel_count);

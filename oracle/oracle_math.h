@@ -20,6 +20,24 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+/* glibc 2.35's float functions restated operation for operation (the header the kernels' "libm" arithmetic
+ * mode is compiled from; plain C99 here).  The oracle evaluates ITS transcendentals through this restatement
+ * by default, so that its frames - and every golden fixture made from them - are the same on any IEEE machine,
+ * whatever C library and CPU it has.  That the restatement equals the C library the reference shader was
+ * compiled against in this image (glibc 2.35, x86-64, FMA / AVX2 IFUNC variants) for every float is a separate
+ * claim with its own tests (tests/test_glibc_math.py, oracle/tools/check_glibc_math.c);
+ * oracle_set_libm_source(1) switches the oracle to the machine's C library itself. */
+#include "../vulkan_renderer_amd/csrc/glibc_math.h"
+
+/* 0 (default): gm_* restatement; 1: the C library of this machine */
+extern int g_oracle_system_libm;
+static inline float l_atanf(float x) { return g_oracle_system_libm ? atanf(x) : gm_atanf(x); }
+static inline float l_acosf(float x) { return g_oracle_system_libm ? acosf(x) : gm_acosf(x); }
+static inline float l_sinf(float x) { return g_oracle_system_libm ? sinf(x) : gm_sinf(x); }
+static inline float l_cosf(float x) { return g_oracle_system_libm ? cosf(x) : gm_cosf(x); }
+static inline float l_log2f(float x) { return g_oracle_system_libm ? log2f(x) : gm_log2f(x); }
+static inline float l_powf(float x, float y) { return g_oracle_system_libm ? powf(x, y) : gm_powf(x, y); }
+static inline float l_atan2f(float y, float x) { return g_oracle_system_libm ? atan2f(y, x) : gm_atan2f(y, x); }
 
 #define O_PI 3.1415926535897932384626433832795f
 #define O_INV_PI 0.31830988618379067153776752674503f
@@ -231,11 +249,11 @@ static inline float vkr_atan2f(float y, float x) {
  * division per arctangent of a ratio.  Everything else - inversesqrt as 1 / sqrt, acos, sin, cos,
  * log2, pow, atan2 - is the C library in both modes.  (Until round 3 mode 1 replaced all of them;
  * the Newton inversesqrt turned out to be what moved pixels into and out of the shader's NaN guard.) */
-static inline float o_log2(float x) { return log2f(x); }
-static inline float o_atan2(float y, float x) { return atan2f(y, x); }
-static inline float o_pow_third(float x) { return powf(x, 1.0f / 3.0f); }
-static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : atanf(t); }
-static inline float o_acos(float x) { return acosf(x); }
+static inline float o_log2(float x) { return l_log2f(x); }
+static inline float o_atan2(float y, float x) { return l_atan2f(y, x); }
+static inline float o_pow_third(float x) { return l_powf(x, 1.0f / 3.0f); }
+static inline float o_atan(float t) { return g_oracle_math_mode ? vkr_atanf(t) : l_atanf(t); }
+static inline float o_acos(float x) { return l_acosf(x); }
 /* atan(n / d) + (n / d < 0 ? pi : 0), i.e. positive_atan(n / d) of polygon_sampling.glsl:104-111.
  * Mode 0 evaluates exactly that with libm.  Mode 1 is the fused form shared with the GPU: the
  * range reduction divides the smaller by the larger magnitude directly, ONE division instead of
@@ -244,7 +262,7 @@ static inline float o_acos(float x) { return acosf(x); }
 static inline float o_positive_atan_ratio(float n, float d) {
 	if (!g_oracle_math_mode) {
 		float tangent = n / d;
-		return atanf(tangent) + ((tangent < 0.0f) ? O_PI : 0.0f);
+		return l_atanf(tangent) + ((tangent < 0.0f) ? O_PI : 0.0f);
 	}
 	float a = fabsf(n), b = fabsf(d);
 	int big = a > b;
@@ -255,7 +273,7 @@ static inline float o_positive_atan_ratio(float n, float d) {
 	int negative = differs && (big || z > 0.0f);
 	return (differs ? -r : r) + (negative ? O_PI : 0.0f);
 }
-static inline float o_acos_unit(float x) { return acosf(x); }
-static inline void o_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+static inline float o_acos_unit(float x) { return l_acosf(x); }
+static inline void o_sincos(float x, float* s, float* c) { *s = l_sinf(x); *c = l_cosf(x); }
 
 #endif

@@ -21,6 +21,9 @@ int g_oracle_math_mode = 0;
 static uint64_t g_ray_count = 0;
 
 void oracle_set_math_mode(int mode) { g_oracle_math_mode = mode; }
+int g_oracle_system_libm = 0;
+void oracle_set_libm_source(int use_system_library) { g_oracle_system_libm = use_system_library; }
+int oracle_get_libm_source(void) { return g_oracle_system_libm; }
 uint64_t oracle_last_ray_count(void) { return g_ray_count; }
 
 /* GLSL min/max as the specification words them */
@@ -291,7 +294,7 @@ const float* oracle_srgb_table(void) {
 	if (!ready) {
 		for (int i = 0; i != 256; ++i) {
 			float v = (float) i / 255.0f;
-			table[i] = (v <= 0.04045f) ? (v / 12.92f) : powf((v + 0.055f) / 1.055f, 2.4f);
+			table[i] = (v <= 0.04045f) ? (v / 12.92f) : l_powf((v + 0.055f) / 1.055f, 2.4f);
 		}
 		ready = 1;
 	}
@@ -1164,13 +1167,13 @@ static v3 error_to_color(const frame_constants_t* k, float error) {
 		{0.23074f, 0.04519f, 0.04092f}, {0.41789f, 0.06663f, 0.06848f}, {0.67244f, 0.11954f, 0.14703f}, {0.79910f, 0.30499f, 0.33245f},
 		{0.19807f, 0.05286f, 0.17144f}, {0.37626f, 0.08228f, 0.29614f}, {0.61721f, 0.15293f, 0.50888f}, {0.73046f, 0.34191f, 0.67244f}};
 	const float min_exponent = 0.0f, max_exponent = 5.0f, color_count = 20.0f;
-	const float min_error = powf(10.0f, min_exponent);
-	const float max_error = powf(10.0f, max_exponent - 0.01f);
+	const float min_error = l_powf(10.0f, min_exponent);
+	const float max_error = l_powf(10.0f, max_exponent - 0.01f);
 	error = g_min(g_max(fabsf(k->error_factor * error), min_error), max_error);
 	/* A NaN error (degenerate sample) passes through the clamp; in the reference the
 	 * colour index is then int(NaN), which is undefined.  Defined here: first colour. */
 	error = (error == error) ? error : min_error;
-	float color_index = fmaf(o_log2(error), color_count / ((max_exponent - min_exponent) * log2f(10.0f)), color_count * -min_exponent / (max_exponent - min_exponent));
+	float color_index = fmaf(o_log2(error), color_count / ((max_exponent - min_exponent) * l_log2f(10.0f)), color_count * -min_exponent / (max_exponent - min_exponent));
 	int index = (int) color_index;
 	return mk3(colors[index][0], colors[index][1], colors[index][2]);
 }
@@ -2160,11 +2163,11 @@ void oracle_primary_visibility(const uint8_t* constants, const void* bvh, uint32
 
 static float linear_to_srgb(float c) {
 	c = g_clamp(c, 0.0f, 1.0f);
-	return (c <= 0.0031308f) ? (12.92f * c) : (1.055f * powf(c, 1.0f / 2.4f) - 0.055f);
+	return (c <= 0.0031308f) ? (12.92f * c) : (1.055f * l_powf(c, 1.0f / 2.4f) - 0.055f);
 }
 static float srgb_to_linear(float c) {
 	c = g_clamp(c, 0.0f, 1.0f);
-	return (c <= 0.04045f) ? ((1.0f / 12.92f) * c) : powf(fmaf(c, 1.0f / 1.055f, 0.055f / 1.055f), 2.4f);
+	return (c <= 0.04045f) ? ((1.0f / 12.92f) * c) : l_powf(fmaf(c, 1.0f / 1.055f, 0.055f / 1.055f), 2.4f);
 }
 /* UNORM8 store of the render target: round to nearest */
 static uint8_t to_unorm8(float c) {

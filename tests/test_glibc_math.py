@@ -111,3 +111,30 @@ def test_the_arctangent_with_its_range_table_in_lds_equals_the_plain_one_for_eve
     out = (C.c_uint64 * 2)()
     assert device.lib.compare_device_arithmetic(C.byref(device.app.device), 17, 5, 0, 1 << 32, out) == 0
     assert out[0] == 0, (int(out[0]), hex(int(out[1])))
+
+
+def test_frames_of_the_oracle_do_not_depend_on_where_its_libm_comes_from(dataset):
+    """The oracle evaluates its transcendentals through the restatement (oracle.set_libm_source("port"), the
+    default: the same frames on every machine).  On a machine whose C library is the one the restatement
+    follows - glibc 2.35 on x86-64 with FMA and AVX2, i.e. this image - the C library itself gives the same
+    frames bit for bit, which ties the golden fixtures to the compiled reference shader (oracle/_ref calls the
+    C library).  Elsewhere this test is skipped: the goldens still hold, the tie is to this image's library."""
+    import platform
+    from helpers import oracle_render
+    from vulkan_renderer_amd import renderer
+    flags = open("/proc/cpuinfo").read() if platform.system() == "Linux" else ""
+    if platform.libc_ver() != ("glibc", "2.35") or platform.machine() != "x86_64" or " fma" not in flags or " avx2" not in flags:
+        pytest.skip("the C library of this machine is not the one csrc/glibc_math.h restates")
+    frames = {}
+    for source in ("port", "system"):
+        oracle.set_libm_source(source)
+        try:
+            for config in (2, 3):
+                hs = renderer.HostScene()
+                renderer.setup_config(hs, config, dataset, width=96, height=64, sample_count=2)
+                frames[(source, config)] = oracle_render(hs, math_mode=0)[0]
+                hs.close()
+        finally:
+            oracle.set_libm_source("port")
+    for config in (2, 3):
+        assert np.array_equal(frames[("port", config)].view(np.uint32), frames[("system", config)].view(np.uint32)), config

@@ -399,6 +399,112 @@ def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_coun
             assert same, (rank, index, exposure, int((got != want).any(axis=-1).sum()))
 
 
+def _local_ranks(rank_count, body):
+    """runs body(rank, group) on one thread per rank; -> (results, errors, stuck)"""
+    import threading
+    lib = renderer.capi.load()
+    group = lib.create_local_slab_group(rank_count)
+    assert group
+    results, errors = {}, {}
+
+    def run(rank):
+        try:
+            results[rank] = body(rank, group)
+        except Exception as error:
+            errors[rank] = repr(error)
+
+    threads = [threading.Thread(target=run, args=(rank,)) for rank in range(rank_count)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    stuck = [t for t in threads if t.is_alive()]
+    if not stuck:
+        lib.destroy_local_slab_group(group)
+    return results, errors, stuck
+
+
+def test_a_rank_that_fails_before_the_gather_releases_its_peers(dataset):
+    """the rendezvous of the local gather had no way out - a rank that returned from
+    render_and_exchange_frame() with an error before it reached the gather left its peers waiting forever.
+    Rank 1 changes its tile schedule after two frames (the exchange then refuses the frame); rank 0 must get an
+    error from its third frame instead of hanging."""
+    width, height = 200, 120
+
+    def body(rank, group):
+        r = renderer.Renderer(frames_in_flight=2)
+        renderer.setup_config(r, 3, dataset, width=width, height=height, acceleration_structure="sah_device")
+        r.set_tiles(32, rank, 2, slab_layout=True)
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        r.create_local_exchange(group)
+        submitted, failed_at = 0, None
+        for frame in range(6):
+            if rank == 1 and frame == 2:
+                r.set_tiles(16, rank, 2, slab_layout=True)
+            try:
+                r.render_and_exchange(None)
+                submitted += 1
+            except RuntimeError:
+                failed_at = frame
+                break
+        r.sync()
+        r.destroy_exchange()
+        r.close()
+        return submitted, failed_at
+
+    results, errors, stuck = _local_ranks(2, body)
+    assert not stuck, "a rank is stuck in the rendezvous of the local gather"
+    assert not errors, errors
+    assert results[1] == (2, 2), results
+    # (rank 0 is told at the frame whose rendezvous rank 1 never reaches - the third - or, if its thread was ahead, the next)
+    assert results[0][1] is not None and 2 <= results[0][1] <= 3, results
+
+
+def test_ranks_of_a_local_group_need_the_same_number_of_buffer_sets(dataset):
+    """sets are addressed by index across the ranks of a local group: a rank whose frames_in_flight gives it another
+    number of sets is refused when it joins"""
+    def body(rank, group):
+        r = renderer.Renderer(frames_in_flight=2 + rank)
+        renderer.setup_config(r, 2, dataset, width=128, height=72, acceleration_structure="sah_device")
+        r.set_tiles(32, rank, 2, slab_layout=True)
+        r.create_targets()
+        r.create_pass()
+        try:
+            r.create_local_exchange(group)
+            joined = True
+        except RuntimeError:
+            joined = False
+        r.sync()
+        if joined:
+            r.destroy_exchange()
+        r.close()
+        return joined
+
+    results, errors, stuck = _local_ranks(2, body)
+    assert not stuck and not errors, (errors, stuck)
+    assert sorted(results.values()) == [False, True], results
+
+
+def test_all_gather_slabs_refuses_a_foreign_buffer_with_a_set_addressed_transport(dataset):
+    """ADVICE round 3: all_gather_slabs() fell back to set 0 when `gathered` was not one of the exchange's buffers;
+    the local copies then wrote into the peers' set 0 and the caller's buffer stayed empty"""
+    r, _ = render_config(dataset, 2, 128, 72, frames_in_flight=2)
+    r.set_tiles(32, 0, 1, slab_layout=True)
+    lib = renderer.capi.load()
+    group = lib.create_local_slab_group(1)
+    r.create_local_exchange(group)
+    foreign = DeviceBuffer(int(r.exchange.send_bytes))
+    assert r.lib.all_gather_slabs(C.byref(r.exchange), r.exchange.send[0], foreign.ptr, r.exchange.stream) == 1
+    assert r.lib.all_gather_slabs(C.byref(r.exchange), r.exchange.send[0], r.exchange.gathered[1], r.exchange.stream) == 0
+    r.sync()
+    foreign.free()
+    r.destroy_exchange()
+    r.close()
+    lib.destroy_local_slab_group(group)
+
+
 def test_exchange_through_a_gather_function_of_the_caller(dataset):
     """create_slab_exchange_with_gather(): the collective is a function pointer; here a Python callback that
     copies the one rank's slab (hipMemcpyAsync on the stream it is given)"""

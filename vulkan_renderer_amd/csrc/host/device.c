@@ -47,6 +47,11 @@ int create_hip_device(device_t* device, int32_t hip_device, void* existing_strea
 		}
 		device->frame_streams[i] = stream;
 	}
+	/* tables the kernels read from device globals exist before anything can be launched on this device_t */
+	if (vkr_fill_device_tables(device->stream)) {
+		destroy_hip_device(device);
+		return 1;
+	}
 	/* The first kernel a process launches on a stream pays for the stream's hardware queue and for
 	   loading the code object: several milliseconds that would otherwise be billed to whatever
 	   comes first (the BVH build of the first scene: 7.8 instead of 3.5 ms).  An empty kernel on

@@ -31,14 +31,23 @@ static int hip_failed(hipError_t error, const char* what) {
 	return 1;
 }
 
+/* RCCL is loaded once per process and stays loaded: it registers exit handlers and keeps helper threads
+   (the bootstrap thread of a rendezvous token, proxy threads of a communicator) whose code must not be
+   unmapped under them - RTLD_NODELETE, and no dlclose() anywhere in this file. */
+static void* g_rccl_library = NULL;
+static pthread_mutex_t g_rccl_library_mutex = PTHREAD_MUTEX_INITIALIZER;
+
 /* Binds the handful of RCCL entry points the exchange uses.  A process that already holds an
    RCCL (PyTorch brings its own copy) gets that one: the loader matches the soname. */
 static int bind_rccl(rccl_binding_t* binding) {
 	memset(binding, 0, sizeof(*binding));
 	const char* requested = getenv("VKR_RCCL_LIBRARY");
 	const char* candidates[] = {requested, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-	for (uint32_t i = 0; i != VKR_COUNT_OF(candidates) && !binding->library; ++i)
-		if (candidates[i] && candidates[i][0]) binding->library = dlopen(candidates[i], RTLD_NOW | RTLD_LOCAL);
+	pthread_mutex_lock(&g_rccl_library_mutex);
+	for (uint32_t i = 0; i != VKR_COUNT_OF(candidates) && !g_rccl_library; ++i)
+		if (candidates[i] && candidates[i][0]) g_rccl_library = dlopen(candidates[i], RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
+	binding->library = g_rccl_library;
+	pthread_mutex_unlock(&g_rccl_library_mutex);
 	if (!binding->library) {
 		const char* reason = dlerror();
 		printf("The multi-GPU exchange needs RCCL, but librccl.so.1 could not be loaded (%s). Set VKR_RCCL_LIBRARY to its path.\n", reason ? reason : "no loader message");
@@ -51,7 +60,6 @@ static int bind_rccl(rccl_binding_t* binding) {
 	*(void**) &binding->get_error_string = dlsym(binding->library, "ncclGetErrorString");
 	if (!binding->get_unique_id || !binding->comm_init_rank || !binding->comm_destroy || !binding->all_gather || !binding->get_error_string) {
 		printf("The RCCL library lacks one of ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclGetErrorString.\n");
-		dlclose(binding->library);
 		memset(binding, 0, sizeof(*binding));
 		return 1;
 	}
@@ -72,8 +80,6 @@ int get_slab_exchange_id(slab_exchange_id_t* id) {
 	_Static_assert(sizeof(ncclUniqueId) <= sizeof(slab_exchange_id_t), "slab_exchange_id_t must hold an ncclUniqueId");
 	int failed = rccl_failed(&binding, binding.get_unique_id(&unique), "creating the rendezvous token");
 	if (!failed) memcpy(id->bytes, &unique, sizeof(unique));
-	/* (on success the library stays loaded: RCCL keeps the bootstrap thread of the token alive in it) */
-	if (failed) dlclose(binding.library);
 	return failed;
 }
 
@@ -89,6 +95,10 @@ static int gather_with_rccl(void* context, uint32_t rank, uint32_t set, const vo
 
 struct local_slab_group_s {
 	uint32_t rank_count, joined;
+	/* buffer sets per rank (the first rank to join decides; the others must agree: sets are addressed by index across ranks) */
+	uint32_t set_count;
+	/* a rank has left the frame loop with an error: every rendezvous returns at once, now and from now on */
+	int aborted;
 	pthread_mutex_t mutex;
 	pthread_cond_t changed;
 	/* rendezvous of the ranks' threads: `generation` advances when the last rank arrives */
@@ -124,17 +134,30 @@ void destroy_local_slab_group(local_slab_group_t* group) {
 	free(group);
 }
 
-/* all ranks' threads meet here */
-static void local_group_rendezvous(local_slab_group_t* group) {
+/* all ranks' threads meet here; 1 if a rank has aborted the group (then nobody waits) */
+static int local_group_rendezvous(local_slab_group_t* group) {
 	pthread_mutex_lock(&group->mutex);
 	uint64_t generation = group->generation;
-	if (++group->waiting == group->rank_count) {
-		group->waiting = 0;
-		++group->generation;
-		pthread_cond_broadcast(&group->changed);
+	if (!group->aborted) {
+		if (++group->waiting == group->rank_count) {
+			group->waiting = 0;
+			++group->generation;
+			pthread_cond_broadcast(&group->changed);
+		}
+		else
+			while (group->generation == generation && !group->aborted) pthread_cond_wait(&group->changed, &group->mutex);
 	}
-	else
-		while (group->generation == generation) pthread_cond_wait(&group->changed, &group->mutex);
+	int aborted = group->aborted;
+	pthread_mutex_unlock(&group->mutex);
+	return aborted;
+}
+
+/* A rank that cannot reach the rendezvous of a frame (its frame failed before the gather) says so, or its
+   peers would wait for it forever */
+static void local_group_abort(local_slab_group_t* group) {
+	pthread_mutex_lock(&group->mutex);
+	group->aborted = 1;
+	pthread_cond_broadcast(&group->changed);
 	pthread_mutex_unlock(&group->mutex);
 }
 
@@ -146,7 +169,7 @@ static int gather_with_copies(void* context, uint32_t rank, uint32_t set, const 
 	hipStream_t s = (hipStream_t) stream;
 	(void) gathered;
 	int failed = 0;
-	int reused = group->frames[rank] >= group->exchanges[rank]->set_count;
+	int reused = group->frames[rank] >= group->set_count;
 	for (uint32_t q = 0; q != group->rank_count && !failed; ++q) {
 		const slab_exchange_t* peer = group->exchanges[q];
 		if (!peer || !peer->gathered[set]) {
@@ -159,8 +182,12 @@ static int gather_with_copies(void* context, uint32_t rank, uint32_t set, const 
 	}
 	if (!failed) failed = hip_failed(hipEventRecord(group->copied[rank][set], s), "marking the copies");
 	++group->frames[rank];
-	/* (a rank that failed still has to show up, or its peers would wait forever) */
-	local_group_rendezvous(group);
+	/* (a rank that failed says so - its peers must not queue waits for copies that were never made) */
+	if (failed) local_group_abort(group);
+	if (local_group_rendezvous(group)) {
+		if (!failed) printf("Another rank of the local slab group has failed; rank %u leaves the frame.\n", rank);
+		return 1;
+	}
 	for (uint32_t q = 0; q != group->rank_count && !failed; ++q)
 		if (q != rank) failed = hip_failed(hipStreamWaitEvent(s, group->copied[q][set], 0), "waiting for a peer's copies");
 	return failed;
@@ -175,7 +202,6 @@ void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
 	rccl_binding_t* binding = (rccl_binding_t*) exchange->binding;
 	if (binding) {
 		if (binding->communicator) (void) binding->comm_destroy(binding->communicator);
-		if (binding->library) dlclose(binding->library);
 		free(binding);
 	}
 	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT; ++b) {
@@ -274,6 +300,16 @@ int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, lo
 	}
 	int failed = create_slab_exchange_with_gather(exchange, app, gather_with_copies, group, format);
 	uint32_t rank = app->tile_schedule.rank;
+	if (!failed) {
+		pthread_mutex_lock(&group->mutex);
+		if (!group->set_count) group->set_count = exchange->set_count;
+		int mismatch = group->set_count != exchange->set_count;
+		pthread_mutex_unlock(&group->mutex);
+		if (mismatch) {
+			printf("Rank %u joins the local slab group with %u buffer sets (frames in flight) but the group has %u: all ranks need the same.\n", rank, exchange->set_count, group->set_count);
+			failed = 1;
+		}
+	}
 	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++b)
 		if (!group->copied[rank][b]) failed = hip_failed(hipEventCreateWithFlags(&group->copied[rank][b], hipEventDisableTiming), "creating events");
 	if (!failed) {
@@ -282,7 +318,7 @@ int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, lo
 	}
 	/* every rank's buffers and events must exist before the first frame copies into them
 	   (a rank that failed still shows up; its peers find out at their first frame) */
-	local_group_rendezvous(group);
+	(void) local_group_rendezvous(group);
 	if (failed && exchange->stream) destroy_slab_exchange(exchange, app);
 	return failed;
 }
@@ -292,8 +328,17 @@ int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered
 		printf("all_gather_slabs() needs an exchange made by one of the create_*_slab_exchange() functions.\n");
 		return 1;
 	}
-	uint32_t set = 0;
+	/* transports that address buffers by set (the local copies write into the PEERS' gathered[set]) need one of
+	   the exchange's own buffers; ncclAllGather takes any */
+	uint32_t set = exchange->set_count;
 	for (uint32_t b = 0; b != exchange->set_count; ++b) if (exchange->gathered[b] == gathered) set = b;
+	if (set == exchange->set_count) {
+		if (exchange->gather != gather_with_rccl) {
+			printf("all_gather_slabs(): `gathered` must be one of exchange->gathered[] with this transport.\n");
+			return 1;
+		}
+		set = 0;
+	}
 	return exchange->gather(exchange->gather_context, exchange->rank, set, send, gathered, exchange->send_bytes, stream);
 }
 
@@ -302,6 +347,7 @@ int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, voi
 		|| exchange->rank != app->tile_schedule.rank || exchange->rank_count != (app->tile_schedule.rank_count > 1 ? app->tile_schedule.rank_count : 1))
 	{
 		printf("The slab exchange does not match the tile schedule or extent. Recreate it.\n");
+		if (exchange->gather == gather_with_copies) local_group_abort((local_slab_group_t*) exchange->gather_context);
 		return 1;
 	}
 	uint32_t b = exchange->next_set;
@@ -322,13 +368,19 @@ int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, voi
 		? render_shading_pass_encoded(app, exchange->slab_radiance[b], exchange->send[b])
 		: render_shading_pass(app, exchange->slab_radiance[b]);
 	app->shading_pass.wait_before_next_frame = NULL;
-	if (failed) return 1;
+	if (failed) {
+		if (exchange->gather == gather_with_copies) local_group_abort((local_slab_group_t*) exchange->gather_context);
+		return 1;
+	}
 	/* ... and the stream it did pick carries the frame */
 	hipStream_t used_stream = (hipStream_t) app->shading_pass.last_frame_stream;
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][1], used_stream);
 	if (hip_failed(hipEventRecord((hipEvent_t) exchange->rendered[b], used_stream), "marking the frame")
 		|| hip_failed(hipStreamWaitEvent(exchange_stream, (hipEvent_t) exchange->rendered[b], 0), "waiting for the frame"))
+	{
+		if (exchange->gather == gather_with_copies) local_group_abort((local_slab_group_t*) exchange->gather_context);
 		return 1;
+	}
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][2], exchange_stream);
 	if (exchange->gather(exchange->gather_context, exchange->rank, b, exchange->send[b], exchange->gathered[b], exchange->send_bytes, exchange_stream)) return 1;
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][3], exchange_stream);

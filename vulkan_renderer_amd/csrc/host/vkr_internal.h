@@ -27,6 +27,8 @@ int vkr_device_upload(void** out, const device_t* device, const void* host, size
 int vkr_host_alloc_pinned(void** out, size_t size);
 /* lbvh_build.hip: an empty kernel on `stream` (create_hip_device() warms the queues up with it) */
 int vkr_launch_empty_kernel(void* stream);
+/* fills the per-device tables of the kernels (sRGB code thresholds) and waits for it (shading_pass.hip) */
+int vkr_fill_device_tables(void* stream);
 void vkr_host_free_pinned(void* pointer);
 int vkr_copy_to_device_async(void* device_pointer, const void* host, size_t size, const device_t* device);
 int vkr_copy_to_host(void* host, const void* device_pointer, size_t size, const device_t* device);

@@ -375,7 +375,9 @@ static void note_target_reader(application_t* app) {
 // that is already on the device (static camera and lights: no upload at all, like the
 // reference's host-coherent uniform buffer, which costs no GPU time either).
 constexpr uint32_t kConstantSlots = VKR_MAX_FRAMES_IN_FLIGHT + 2;
-constexpr int kConstantReaders = 1 + VKR_MAX_FRAMES_IN_FLIGHT;
+// (device->stream, the frame streams and - VKR_TRACE_STREAM_PRIORITY=high - the tracing streams, whose resolve
+// kernels read the exposure)
+constexpr int kConstantReaders = 1 + 2 * VKR_MAX_FRAMES_IN_FLIGHT;
 struct constants_ring {
 	void* host[kConstantSlots];
 	void* device[kConstantSlots];
@@ -430,15 +432,25 @@ static int create_constants_ring(shading_pass_t* pass, const device_t* device) {
 static int upload_constants(application_t* app, hipStream_t stream) {
 	shading_pass_t* pass = &app->shading_pass;
 	constants_ring* ring = (constants_ring*) pass->constants_ring;
+	// an entry that does not exist (no tracing streams) is marked by `present`: a NULL stream is a stream too
 	hipStream_t readers[kConstantReaders] = {(hipStream_t) app->device.stream};
-	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i) readers[1 + i] = (hipStream_t) app->device.frame_streams[i];
+	bool present[kConstantReaders] = {true};
+	const frame_pipeline* pipeline = (const frame_pipeline*) pass->wavefront;
+	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i) {
+		readers[1 + i] = (hipStream_t) app->device.frame_streams[i];
+		present[1 + i] = app->device.frame_streams[i] != NULL;
+		hipStream_t tracing = pipeline ? pipeline->contexts[i].trace_stream : NULL;
+		readers[1 + VKR_MAX_FRAMES_IN_FLIGHT + i] = tracing;
+		present[1 + VKR_MAX_FRAMES_IN_FLIGHT + i] = tracing != NULL;
+	}
 	write_constants(ring->scratch, app);
 	if (!ring->valid || memcmp(ring->scratch, ring->host[ring->current], pass->constants_size) != 0) {
 		uint32_t slot = ring->valid ? (ring->current + 1) % kConstantSlots : 0;
 		// everything launched so far may read the old slot: it is free again once all
 		// streams have passed this point
 		if (ring->valid) {
-			for (int i = 0; i != kConstantReaders; ++i) (void) hipEventRecord(ring->consumed[ring->current][i], readers[i]);
+			// (an absent reader's event stays unrecorded, which completes at once)
+			for (int i = 0; i != kConstantReaders; ++i) if (present[i]) (void) hipEventRecord(ring->consumed[ring->current][i], readers[i]);
 			ring->in_flight[ring->current] = true;
 		}
 		if (ring->in_flight[slot])
@@ -450,7 +462,7 @@ static int upload_constants(application_t* app, hipStream_t stream) {
 			|| hip_failed(hipEventRecord(ring->uploaded[slot], stream), "recording the upload"))
 			return 1;
 		ring->ordered[slot] = 0;
-		for (int i = 0; i != kConstantReaders; ++i) if (readers[i] == stream) ring->ordered[slot] |= 1u << i;
+		for (int i = 0; i != kConstantReaders; ++i) if (present[i] && readers[i] == stream) ring->ordered[slot] |= 1u << i;
 		ring->current = slot;
 		ring->valid = true;
 		pass->constants_device = ring->device[slot];
@@ -459,7 +471,7 @@ static int upload_constants(application_t* app, hipStream_t stream) {
 	}
 	// unchanged constants that another stream uploaded: order this stream behind that upload
 	for (int i = 0; i != kConstantReaders; ++i)
-		if (readers[i] == stream) {
+		if (present[i] && readers[i] == stream) {
 			if (ring->ordered[ring->current] & (1u << i)) return 0;
 			ring->ordered[ring->current] |= 1u << i;
 		}
@@ -623,7 +635,6 @@ extern "C" uint64_t get_slab_pixel_count(const application_t* app, uint32_t rank
 }
 
 __global__ void k_encode_output_rgb8(const float4* radiance, uint32_t* packed, uint64_t quad_count, uint32_t frame_bits, int output_linear_rgb);
-static int ensure_srgb_code_thresholds(const device_t* device, hipStream_t stream);
 
 static int render_pass(application_t* app, void* out_radiance, void* out_rgb8);
 extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]);
@@ -931,7 +942,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			// (the resolves of the bands are chained, so the last band's stream has seen them all)
 			// slab layout: every thread of the grid owns a slot; full-frame layout: the pixels
 			uint64_t pixels = p.slab_layout ? (uint64_t) grid_blocks * 256u : (uint64_t) p.width * p.height;
-			if (pixels % 4 != 0 || ensure_srgb_code_thresholds(device, stream)) {
+			if (pixels % 4 != 0) {
 				printf("The frame cannot be encoded as packed RGB8 (its pixel count has to be a multiple of four).\n");
 				status = 1;
 			}
@@ -1414,15 +1425,13 @@ __global__ void k_fill_srgb_code_thresholds() {
 	if (c == 0) g_srgb_code_thresholds[256] = __builtin_inff();
 }
 
-static int ensure_srgb_code_thresholds(const device_t* device, hipStream_t stream) {
-	static bool filled[64];
-	int index = device->hip_device;
-	if (index < 0 || index >= 64) index = 63;
-	if (filled[index]) return 0;
-	k_fill_srgb_code_thresholds<<<1, 256, 0, stream>>>();
+// Called by create_hip_device() with the device selected: fills the table on THAT device and waits, so that
+// every stream of every thread that later encodes on the device finds it (the table is per device and its
+// content does not depend on who fills it: no host-side state, filling it again is harmless).
+extern "C" int vkr_fill_device_tables(void* stream) {
+	k_fill_srgb_code_thresholds<<<1, 256, 0, (hipStream_t) stream>>>();
 	if (hip_failed(hipGetLastError(), "filling the sRGB thresholds")) return 1;
-	filled[index] = true;
-	return 0;
+	return hip_failed(hipStreamSynchronize((hipStream_t) stream), "filling the sRGB thresholds");
 }
 
 __device__ __forceinline__ uint32_t srgb_code(float v) {
@@ -1477,7 +1486,7 @@ __global__ void __launch_bounds__(256) k_encode_output_rgb8(const float4* radian
 extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 	if (finish_frames(app)) return 1;
 	uint64_t pixels = (uint64_t) app->swapchain.extent.width * app->swapchain.extent.height;
-	if (!app->render_targets.radiance || !app->render_targets.encoded || ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
+	if (!app->render_targets.radiance || !app->render_targets.encoded) return 1;
 	k_encode_output<<<(uint32_t) ((pixels + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) app->render_targets.radiance, (uint32_t*) app->render_targets.encoded,
 		pixels, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
 	note_target_reader(app);
@@ -1486,7 +1495,7 @@ extern "C" int encode_output(application_t* app, VkBool32 output_linear_rgb) {
 
 extern "C" int encode_slab(application_t* app, const void* slab_radiance, void* slab_encoded, uint64_t pixel_count, VkBool32 output_linear_rgb) {
 	if (finish_frames(app)) return 1;
-	if (!slab_radiance || !slab_encoded || ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
+	if (!slab_radiance || !slab_encoded) return 1;
 	k_encode_output<<<(uint32_t) ((pixel_count + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_encoded,
 		pixel_count, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
 	note_target_reader(app);
@@ -1499,7 +1508,6 @@ extern "C" int encode_slab_rgb8(application_t* app, const void* slab_radiance, v
 		printf("encode_slab_rgb8() needs buffers and a pixel count that is a multiple of four (slabs are).\n");
 		return 1;
 	}
-	if (ensure_srgb_code_thresholds(&app->device, (hipStream_t) app->device.stream)) return 1;
 	k_encode_output_rgb8<<<(uint32_t) ((pixel_count / 4 + 255) / 256), 256, 0, (hipStream_t) app->device.stream>>>((const float4*) slab_radiance, (uint32_t*) slab_rgb8,
 		pixel_count / 4, app->screenshot.frame_bits, output_linear_rgb ? 1 : 0);
 	note_target_reader(app);
