@@ -229,10 +229,24 @@ class Job:
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % self.rank)
-        from vulkan_renderer_amd import synthetic
-        # ground plane of 2 x 256^2 triangles + 64 boxes, LTC tables with R = 64, 51 layers
-        self.dataset = synthetic.write_dataset(self.tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=args.ltc_resolution, fresnel_count=51)
+        self.datasets = {}
+        self.dataset = self.dataset_of(args.scene)
         self.stream = torch.cuda.current_stream()
+
+    def dataset_of(self, scene):
+        """"bench": SURVEY.md 8(d), ground plane of 2 x 256^2 triangles + 64 boxes; "large": 2.6 M triangles with stacked
+        occluders, long thin triangles, deep occlusion, eight materials (synthetic.make_large_scene_geometry).
+        LTC tables with R = 64, 51 layers either way."""
+        from vulkan_renderer_amd import synthetic
+        if scene not in self.datasets:
+            t = time.perf_counter()
+            directory = os.path.join(self.tmp.name, scene)
+            if scene == "large":
+                self.datasets[scene] = synthetic.write_dataset(directory, seed=4321, ltc_resolution=self.args.ltc_resolution, fresnel_count=51, large={})
+            else:
+                self.datasets[scene] = synthetic.write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=self.args.ltc_resolution, fresnel_count=51)
+            self.datasets[scene]["generate_seconds"] = round(time.perf_counter() - t, 2)
+        return self.datasets[scene]
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -307,13 +321,15 @@ def libm_identity():
     return "%s %s, %s, %s" % (name or "libc", version or "?", platform.machine(), variant)
 
 
-def run_workload(job, config, role):
+def run_workload(job, config, role, scene=None):
     """Sets one BASELINE configuration up, times it and returns the dict that describes the run.
     role: "primary" (the headline: CPU baseline, parity, other arithmetic modes), "extra" (a short run of another
     1920x1080 configuration with parity bits and roofline, attached to the headline line) or "secondary" (config 4)."""
     primary = role == "primary"
     from vulkan_renderer_amd import renderer, synthetic
     args, torch = job.args, job.torch
+    scene = scene or args.scene
+    dataset = job.dataset_of(scene)
     rank, world = job.rank, job.world
     settings = dict(synthetic.CONFIG_SETTINGS[config])
     strong = args.scaling == "strong"
@@ -340,7 +356,7 @@ def run_workload(job, config, role):
     r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=args.mode, inline_rays=args.inline_rays,
                           timing_stride=timing_stride, frames_in_flight=frames_in_flight_requested, binary_traversal=args.binary_traversal)
     t = time.perf_counter()
-    renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh,
+    renderer.setup_config(r, config, dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh,
                           trace_shadow_rays=settings["trace_shadow_rays"])
     r.sync()
     load_ms = (time.perf_counter() - t) * 1e3
@@ -474,13 +490,18 @@ def run_workload(job, config, role):
     pass_alone_ms = r.dispatch_ms(alone_frames)
     kernel_ms = float(np.mean(kernel_alone_ms)) if kernel_alone_ms else float("nan")
     traversal = None
-    if (args.traversal_stats or primary) and rays and not args.inline_rays and world == 1:
+    if (args.traversal_stats or primary or role == "extra") and rays and not args.inline_rays and world == 1:
         traversal = {}
         for wide in ([True, False] if structure.wide_nodes else [False]):
             s = r.traversal_statistics(wide)
             traversal[s["tree"]] = {"fetches_per_ray": round(s["node_visits"] / max(s["rays"], 1), 2), "boxes_tested_per_ray": round(s["boxes_tested"] / max(s["rays"], 1), 2),
                                     "triangle_tests_per_ray": round(s["triangle_tests"] / max(s["rays"], 1), 2), "lane_use": round(s["node_visits"] / max(64 * s["wave_steps"], 1), 3),
-                                    "longest_ray_fetches": s["longest_ray_visits"]}
+                                    "longest_ray_fetches": s["longest_ray_visits"], "blocked_fraction": round(s["blocked_rays"] / max(s["rays"], 1), 4)}
+            if wide:
+                visible_rays = max(s["rays"] - s["blocked_rays"], 1)
+                traversal[s["tree"]].update({"fetches_per_blocked_ray": round(s["node_visits_of_blocked_rays"] / max(s["blocked_rays"], 1), 2),
+                                             "fetches_per_visible_ray": round((s["node_visits"] - s["node_visits_of_blocked_rays"]) / visible_rays, 2),
+                                             "deepest_stack": s["deepest_stack"], "rays_beyond_lds_stack": s["rays_beyond_lds_stack"]})
         traversal["walked"] = "wide" if (structure.wide_nodes and not args.binary_traversal) else "binary"
     if assembled is not None:
         # single-GPU render of the whole frame with the same pass settings
@@ -557,18 +578,19 @@ def run_workload(job, config, role):
                       + ("; median_frame_period_ms = median of the periods between consecutive timed frames (the reference's protocol: median of >= 100 frame times)" if median_ms else "; the median of frame periods is reported from 100 steps on"),
         "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config %s: %dx%d, %d spp per technique, %d polygonal light(s), %s + %s, %s, %s arithmetic"
-                               % (config, width, height, sample_count, light_count, settings["sampling_strategies"], settings["polygon_technique"],
+                               % ("%s%s" % (config, "" if scene == "bench" else " on the large scene"), width, height, sample_count, light_count, settings["sampling_strategies"], settings["polygon_technique"],
                                   ("shadow rays through the %s BVH (%s)" % ("four-wide" if (structure.wide_nodes and not args.binary_traversal and not args.inline_rays) else "binary",
                                                                             renderer.BVH_BUILDER_NAME[int(structure.builder)])) if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
                    "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
                    "parallelism": ("tiles %dx%d round-robin over %d rank(s), %s" % (args.tile_size, args.tile_size, world,
                                    ("RCCL all-gather of %s slabs (ncclAllGather from C) + scatter per frame inside the timed region, overlapped with the next frame" % exchange) if exchange != "none" else "every rank keeps its slab of the frame (no data-path collective)")) if distributed else "one GPU, whole frame",
-                   "scene_triangles": int(r.app.scene.mesh.triangle_count), "ltc_resolution": int(r.app.ltc_table.roughness_count),
+                   "scene": scene, "scene_triangles": int(r.app.scene.mesh.triangle_count), "scene_materials": int(r.app.scene.materials.material_count), "ltc_resolution": int(r.app.ltc_table.roughness_count),
                    "arithmetic": args.mode, "bands_per_frame": bands_per_frame, "frames_in_flight": frames_in_flight},
         "prewarm_frames": prewarm, "host_issue_ms_per_step": round(issue_seconds / steps * 1e3, 4),
         "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (ms_per_step * 1e-3) / 1e6, 2) if rays else 0.0,
         "setup": {"load_and_upload_ms": round(load_ms - structure.build_milliseconds, 2), "bvh_build_ms": round(float(structure.build_milliseconds), 3),
-                  "bvh_builder": renderer.BVH_BUILDER_NAME[int(structure.builder)], "visibility_pass_ms": round(visibility_ms, 3), "first_visibility_pass_ms": round(first_visibility_ms, 3),
+                  "bvh_builder": renderer.BVH_BUILDER_NAME[int(structure.builder)], "bvh_node_bytes": 16 * int(structure.node_count) + 64 * int(structure.wide_node_count),
+                  "bvh_wide_nodes": int(structure.wide_node_count), "bvh_stack_need": int(structure.wide_stack_need), "visibility_pass_ms": round(visibility_ms, 3), "first_visibility_pass_ms": round(first_visibility_ms, 3),
                   "readback_ms": round(readback_ms, 3), "upload_ms": round(upload_ms, 3),
                   "note": "untimed set-up, once per scene (load = parse .vks / LTC fits / noise + copies to the device); visibility_pass_ms = primary visibility per frame (mean of 4 launches after the first, host clock around a synchronised device), first_visibility_pass_ms includes one-time costs; readback = RGBA32F frame to the host, upload = a visibility buffer from the host (what a PCIe-inclusive frame would add; never part of value)"},
         "roofline": roofline,
@@ -745,6 +767,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed frames (default 2000 / 2000 / 500 / 100 for configs 1-4)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed frames right before the timed ones (default: a tenth of the steps); --prewarm-frames come before them")
     ap.add_argument("--config", type=parse_config, default=3, choices=[1, 2, 3, 4, "target"], help="BASELINE.json configuration (default 3, the heaviest 1080p one); target = 1920x1080, 4 spp, 1 light")
+    ap.add_argument("--scene", default="bench", choices=["bench", "large"], help="bench: the scene of SURVEY.md 8(d) (131 840 triangles); large: 2.6 M triangles with stacked occluders, thin triangles, deep occlusion, eight materials")
     ap.add_argument("--no-secondary", action="store_true", help="do not also measure BASELINE config 4 (3840x2160, 8 spp, 8 lights)")
     ap.add_argument("--mode", default="libm", choices=["libm", "exact", "fast"],
                     help="libm: IEEE arithmetic with glibc's transcendentals, bit-identical to the CPU oracle in the mode that is pinned against the reference shader (default); "
@@ -763,6 +786,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", "--no-fast-mode", dest="no_other_modes", action="store_true", help="do not also measure the workload in the exact (polynomial arctangent) arithmetic mode (reported as \"other_modes\" next to the headline)")
     ap.add_argument("--fast-mode", action="store_true", help="also measure the fast arithmetic mode; it is OUTSIDE the stated tolerance (within_tolerance false) and never part of a claim")
+    ap.add_argument("--no-large-scene", action="store_true", help="do not also run config 3 on the large scene (2.6 M triangles) as an extra workload")
     ap.add_argument("--no-extra", action="store_true", help="do not also run the north_star target shape (1920x1080, 4 spp, 1 light) and BASELINE config 2 as short extra workloads")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=(1, 2, 3, 4),
@@ -789,11 +813,11 @@ def main():
     if not args.no_extra and args.config == 3 and not customised and job.world == 1:
         # the other 1920x1080 shapes the contract names, on the same clock: north_star's target and BASELINE config 2
         keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_frame_period_ms", "value_from_median", "latency_ms", "value_single_frame", "shaded_fraction",
-                "config", "shadow_rays_per_frame", "Mrays_per_s", "roofline", "parity")
+                "config", "shadow_rays_per_frame", "Mrays_per_s", "roofline", "parity", "traversal", "setup")
         result["extra_workloads"] = {}
-        for extra in ("target", 2):
-            line = run_workload(job, extra, "extra")
-            result["extra_workloads"]["config_%s" % extra] = {k: line[k] for k in keep if k in line}
+        for extra, scene in (("target", args.scene), (2, args.scene)) + ((("3", "large"),) if args.scene == "bench" and not args.no_large_scene else ()):
+            line = run_workload(job, int(extra) if extra != "target" else extra, "extra", scene)
+            result["extra_workloads"]["config_%s%s" % (extra, "" if scene == args.scene else "_large_scene")] = {k: line[k] for k in keep if k in line}
         target_value = result["extra_workloads"]["config_target"]["value"]
         result["north_star_target"] = {"shape": "1920x1080, 4 spp, 1 polygonal light", "target_Msamples_per_s": 1000.0, "value": target_value, "met": bool(target_value >= 1000.0),
                                        "parity": result["extra_workloads"]["config_target"].get("parity")}

@@ -382,8 +382,10 @@ VKR_API uint64_t get_last_ray_count(const application_t* app);
 VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]);
 /*! The same for the tree of the caller's choice - the binary one (one box per visit) or the
 	four-wide one (a visit fetches one node and tests up to four boxes) - whatever the frame itself
-	walked, plus [6] boxes tested (wide tree only) and [7] the deepest stack a ray reached (wide tree only) */
-VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]);
+	walked, plus (wide tree only) [6] boxes tested, [7] the deepest stack a ray reached, [8] rays whose stack
+	outgrows the part the tracing kernel keeps in LDS (they take its spill path), [9] node visits of the rays
+	that end up blocked; [10], [11] reserved (0) */
+VKR_API int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[12]);
 
 /*! Diagnostics for the arithmetic contract of the kernels (csrc/device_math.h, mirrored by
 	oracle/oracle_math.h): evaluates one primitive of the IEEE arithmetic modes element-wise on the

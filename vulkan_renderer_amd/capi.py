@@ -160,6 +160,8 @@ class ExperimentList(C.Structure):
                 ("frame_index", C.c_uint32), ("state", C.c_int32)]
 
 
+# stack entries per lane that trace_shadow_rays_wide keeps in LDS (csrc/lbvh.h kWideStackLds)
+WIDE_STACK_LDS = 16
 MAX_FRAMES_IN_FLIGHT = 4  # VKR_MAX_FRAMES_IN_FLIGHT
 
 
@@ -281,10 +283,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("libvkr_shading.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "or `make -C vulkan_renderer_amd/csrc -j`.")
-    lib = C.CDLL(LIB_PATH)
+    # VKR_SHADING_LIBRARY: another build of the same library, e.g. libvkr_shading_ieee.so (the check build whose
+    # divisions and square roots are the compiler's full-range IEEE expansions; tests/test_gpu_division_window.py)
+    path = os.environ.get("VKR_SHADING_LIBRARY") or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C vulkan_renderer_amd/csrc -j`." % os.path.basename(path))
+    lib = C.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = restype

@@ -101,6 +101,10 @@ VKR_DEV float divide_full_range(float a, float b) {
 	return __fdiv_rn(a, b);
 #endif
 }
+// VKR_IEEE_DIVISION_EVERYWHERE=1 (libvkr_shading_ieee.so, `make ieee`): every quotient and every square root is
+// the compiler's full-range IEEE expansion.  The check build of the test-suite: the product kernels must give the
+// same frames bit for bit (tests/test_gpu_division_window.py), i.e. no operand of the pass leaves the windows that
+// divide() and square_root() document.
 #ifndef VKR_IEEE_DIVISION_EVERYWHERE
 #define VKR_IEEE_DIVISION_EVERYWHERE 0
 #endif
@@ -158,6 +162,8 @@ VKR_DEV float square_root_unguarded(float x) {
 VKR_DEV float square_root(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_sqrtf(x);
+#elif VKR_IEEE_DIVISION_EVERYWHERE
+	return __fsqrt_rn(x);
 #elif VKR_SQRT_VARIANT == 2
 	float estimate = __builtin_amdgcn_sqrtf(x);
 	float s = fmaf(fmaf(-estimate, estimate, x), 0.5f * __builtin_amdgcn_rsqf(x), estimate);
@@ -175,7 +181,9 @@ VKR_DEV float square_root(float x) {
 // inversesqrt as the oracle's math mode 0 (and the reference shader compiled as C++) evaluates it:
 // two correctly rounded operations, 1 / sqrt(x)
 VKR_DEV float inverse_square_root_ieee(float x) {
-#if VKR_SQRT_VARIANT == 2
+#if VKR_IEEE_DIVISION_EVERYWHERE
+	return __fdiv_rn(1.0f, __fsqrt_rn(x));
+#elif VKR_SQRT_VARIANT == 2
 	return divide(1.0f, square_root(x));
 #else
 	return divide(1.0f, square_root_unguarded(x));

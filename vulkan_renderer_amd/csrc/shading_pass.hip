@@ -1072,11 +1072,13 @@ __global__ void __launch_bounds__(256) k_traversal_statistics(bvh_view bvh, ray_
 
 // The same for the four-wide tree: "visits" are fetched nodes (dependent loads), out[5] the longest
 // ray's, wave steps the longest ray of each group of 64; out[6] counts tested boxes, out[7] the
-// deepest stack a ray reached
-__global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh, const uint4* wide_nodes, ray_stream stream, unsigned long long* out) {
+// deepest stack a ray reached, out[8] the rays whose stack outgrows the `lds_entries` entries that
+// trace_shadow_rays_wide keeps in LDS (it holds the next item on the stack too: one entry more than the
+// scheme here), out[9] the node visits of the rays that end up blocked
+__global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh, const uint4* wide_nodes, ray_stream stream, uint32_t lds_entries, unsigned long long* out) {
 	uint32_t queue = blockIdx.y;
 	uint32_t size = stream.sizes[queue];
-	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0, boxes = 0;
+	unsigned long long visits = 0, tests = 0, blocked_rays = 0, rays = 0, wave_steps = 0, boxes = 0, beyond_lds = 0, blocked_visits = 0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ((size + 63u) & ~63u); i += gridDim.x * 256u) {
 		uint32_t my_visits = 0;
 		size_t slot = (size_t) queue * stream.capacity + i;
@@ -1119,6 +1121,8 @@ __global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh,
 				}
 			}
 			blocked_rays += blocked ? 1 : 0;
+			blocked_visits += blocked ? my_visits : 0u;
+			beyond_lds += (deepest + 1u > lds_entries) ? 1 : 0;
 			atomicMax(out + 7, (unsigned long long) deepest);
 		}
 		visits += my_visits;
@@ -1129,6 +1133,8 @@ __global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh,
 	}
 	atomicAdd(out + 0, rays); atomicAdd(out + 1, visits); atomicAdd(out + 2, tests);
 	atomicAdd(out + 3, blocked_rays); atomicAdd(out + 4, wave_steps); atomicAdd(out + 6, boxes);
+	if (beyond_lds) atomicAdd(out + 8, beyond_lds);
+	if (blocked_visits) atomicAdd(out + 9, blocked_visits);
 }
 
 // evaluate_device_arithmetic(): the primitives as the shading kernels use them (this translation unit
@@ -1264,13 +1270,13 @@ extern "C" int get_traversal_statistics(application_t* app, uint64_t out_statist
 		printf("get_traversal_statistics() needs a frame rendered with wavefront shadow rays.\n");
 		return 1;
 	}
-	uint64_t all[8];
+	uint64_t all[12];
 	int failed = get_traversal_statistics_of_tree(app, app->scene.acceleration_structure.wide_nodes && !app->shading_pass.binary_traversal, all);
 	memcpy(out_statistics, all, sizeof(uint64_t) * 6);
 	return failed;
 }
 
-extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[8]) {
+extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wide_tree, uint64_t out_statistics[12]) {
 	const frame_pipeline* frames = (const frame_pipeline*) app->shading_pass.wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
 	const acceleration_structure_t* structure = &app->scene.acceleration_structure;
@@ -1279,16 +1285,16 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 		return 1;
 	}
 	unsigned long long* counters = NULL;
-	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 8), "allocating traversal counters")) return 1;
+	if (hip_failed(hipMalloc(&counters, sizeof(unsigned long long) * 12), "allocating traversal counters")) return 1;
 	hipStream_t stream = (hipStream_t) app->device.stream;
 	(void) finish_frames(app);
-	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, stream);
+	(void) hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 12, stream);
 	bvh_view bvh = make_bvh_view(structure);
 	// (the queues of the most recent launch - the last band of the last frame - with the sizes the resolve kernel kept)
 	ray_stream rays = {w->ray_directions, w->ray_records, w->ray_origins, w->ray_queue_size + kRayCounterCount, w->queue_capacity, w->thread_bits, w->thread_count};
-	if (wide_tree) k_traversal_statistics_wide<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, (const uint4*) structure->wide_nodes, rays, counters);
+	if (wide_tree) k_traversal_statistics_wide<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, (const uint4*) structure->wide_nodes, rays, frames->wide_stack_lds, counters);
 	else k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, rays, counters);
-	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 8, &app->device);
+	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 12, &app->device);
 	(void) hipFree(counters);
 	return failed;
 }

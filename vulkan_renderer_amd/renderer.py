@@ -318,17 +318,18 @@ class Renderer(HostScene):
     def traversal_statistics(self, wide_tree=None):
         """Work of the BVH traversal for the rays of the last wavefront frame (diagnostics).
         wide_tree None: the tree the frame walked; True / False: the four-wide / the binary one."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         if wide_tree is None:
             wide_tree = bool(self.app.scene.acceleration_structure.wide_nodes) and not self.app.shading_pass.binary_traversal
         if self.lib.get_traversal_statistics_of_tree(C.byref(self.app), int(wide_tree), out):
             raise RuntimeError("get_traversal_statistics_of_tree failed")
-        keys = ("rays", "node_visits", "triangle_tests", "blocked_rays", "wave_steps", "longest_ray_visits", "boxes_tested", "deepest_stack")
+        keys = ("rays", "node_visits", "triangle_tests", "blocked_rays", "wave_steps", "longest_ray_visits", "boxes_tested", "deepest_stack", "rays_beyond_lds_stack", "node_visits_of_blocked_rays")
         stats = dict(zip(keys, (int(v) for v in out)))
         stats["tree"] = "wide" if wide_tree else "binary"
         if not wide_tree:
             stats["boxes_tested"] = stats["node_visits"]
-            del stats["deepest_stack"]
+            for key in ("deepest_stack", "rays_beyond_lds_stack", "node_visits_of_blocked_rays"):
+                del stats[key]
         return stats
 
     # -- multi-GPU exchange (include/vkr_slab_exchange.h) ---------------------------------

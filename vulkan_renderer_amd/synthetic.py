@@ -140,6 +140,109 @@ def make_scene_geometry(grid=256, box_count=64, seed=1234, extent=10.0, material
     return positions, normals, uvs, mats
 
 
+def _boxes_triangles(centers, halves, rotations):
+    """Vectorised _box_triangles: (n, 3) centres and half extents, (n,) rotations about z -> (12 n, 3, 3) positions and normals."""
+    centers, halves, rotations = np.asarray(centers, np.float64), np.asarray(halves, np.float64), np.asarray(rotations, np.float64)
+    n = len(centers)
+    c, s = np.cos(rotations), np.sin(rotations)
+    R = np.zeros((n, 3, 3))
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = c, -s, s, c, 1.0
+    unit = np.array([[x, y, z] for z in (-1, 1) for y in (-1, 1) for x in (-1, 1)], np.float64)
+    corners = np.einsum("nij,nkj->nki", R, unit[None] * halves[:, None, :]) + centers[:, None, :]
+    faces = np.array([(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)])
+    quads = corners[:, faces]                                   # (n, 6, 4, 3)
+    normal = np.cross(quads[:, :, 1] - quads[:, :, 0], quads[:, :, 2] - quads[:, :, 0])
+    normal /= np.linalg.norm(normal, axis=-1, keepdims=True)
+    tris = np.stack([quads[:, :, [0, 1, 2]], quads[:, :, [0, 2, 3]]], 2).reshape(-1, 3, 3)
+    normals = np.repeat(np.repeat(normal[:, :, None, None, :], 2, 2), 3, 3).reshape(-1, 3, 3)
+    return tris, normals
+
+
+def _sphere_triangles(center, radius, segments, rings):
+    """UV sphere: 2 * segments * (rings - 1) triangles (thin ones at the poles) with smooth normals."""
+    theta = np.linspace(0.0, math.pi, rings + 1)
+    phi = np.linspace(0.0, 2.0 * math.pi, segments + 1)
+    T, P = np.meshgrid(theta, phi, indexing="ij")
+    unit = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], -1)
+    a, b, c, d = unit[:-1, :-1], unit[1:, :-1], unit[1:, 1:], unit[:-1, 1:]
+    upper = np.stack([a, b, c], -2)[:-1].reshape(-1, 3, 3)     # (b = c at the last ring, a = d at the first: those would be degenerate)
+    lower = np.stack([a, c, d], -2)[1:].reshape(-1, 3, 3)
+    normals = np.concatenate([upper, lower], 0)
+    return normals * radius + np.asarray(center, np.float64), normals
+
+
+def make_large_scene_geometry(grid=768, tower_count=700, sphere_count=160, fence_count=220, louvre_count=36, seed=4321, extent=10.0, materials=8):
+    """The second, harder scene ("any scene but one"): 2 - 3 M triangles with what the benchmark
+    scene lacks - stacked occluders (towers of boxes), long thin triangles (fence bars 4 cm x 2.4 m, louvre slats
+    3 m x 6 cm hanging between the floor and the lights), small dense meshes next to large sparse ones (spheres of
+    8 k triangles on a floor of 2 * grid^2), deep occlusion (most shadow rays pass several fences) and several
+    materials.  Same lights and camera as the benchmark scene.  Returns positions, normals, uvs, material indices."""
+    rng = np.random.default_rng(seed)
+    positions, normals, uvs, mats = make_scene_geometry(grid, 0, seed, extent, materials)
+    positions, normals, mats = [positions], [normals], [mats]
+    camera_xy = np.array(DEFAULT_CAMERA["position"][:2])
+
+    def place(low, high):
+        """a position in [low, high]^2 that leaves 1.5 m around the camera free"""
+        while True:
+            xy = rng.uniform(low, high, 2)
+            if np.linalg.norm(xy - camera_xy) > 1.5:
+                return xy
+
+    def add(tris, nrms, material):
+        positions.append(tris)
+        normals.append(nrms)
+        mats.append(np.full(len(tris), material) if np.isscalar(material) else np.asarray(material))
+
+    # towers: three to eight boxes on top of each other, shrinking and turning
+    for _ in range(tower_count):
+        x, y = place(-extent * 0.9, extent * 0.9)
+        levels = int(rng.integers(3, 9))
+        half = rng.uniform(0.12, 0.45, 3) * np.array([1.0, 1.0, 0.5])
+        z, centers, halves, rotations = 0.0, [], [], []
+        rotation = rng.uniform(0, math.pi)
+        for _level in range(levels):
+            centers.append((x, y, z + half[2]))
+            halves.append(half.copy())
+            rotations.append(rotation)
+            z += 2.0 * half[2]
+            half = half * rng.uniform(0.7, 0.95)
+            rotation += rng.uniform(0.1, 0.6)
+        tris, nrms = _boxes_triangles(centers, halves, rotations)
+        add(tris, nrms, int(rng.integers(0, materials)))
+    # fences: rows of thin vertical bars (each bar a box 4 cm x 4 cm x up to 2.4 m: twelve long thin triangles)
+    for _ in range(fence_count):
+        x, y = place(-extent * 0.85, extent * 0.85)
+        angle, bars, height = rng.uniform(0, math.pi), int(rng.integers(12, 40)), rng.uniform(1.2, 2.4)
+        step = np.array([math.cos(angle), math.sin(angle)]) * 0.11
+        offsets = (np.arange(bars) - 0.5 * bars)[:, None] * step
+        centers = np.concatenate([np.array([x, y]) + offsets, np.full((bars, 1), 0.5 * height)], 1)
+        halves = np.tile(np.array([0.02, 0.02, 0.5 * height]), (bars, 1))
+        tris, nrms = _boxes_triangles(centers, halves, np.full(bars, angle))
+        add(tris, nrms, int(rng.integers(0, materials)))
+    # louvres: horizontal slats (3 m x 6 cm x 1 cm, tilted) in layers between the floor and the lights
+    for _ in range(louvre_count):
+        x, y = rng.uniform(-4.5, 4.5), rng.uniform(-1.0, 6.5)
+        angle, slats, z = rng.uniform(0, math.pi), int(rng.integers(10, 28)), rng.uniform(1.1, 2.0)
+        step = np.array([-math.sin(angle), math.cos(angle)]) * 0.13
+        offsets = (np.arange(slats) - 0.5 * slats)[:, None] * step
+        centers = np.concatenate([np.array([x, y]) + offsets, np.full((slats, 1), z)], 1)
+        halves = np.tile(np.array([rng.uniform(0.8, 1.5), 0.03, 0.005]), (slats, 1))
+        tris, nrms = _boxes_triangles(centers, halves, np.full(slats, angle))
+        add(tris, nrms, int(rng.integers(0, materials)))
+    # spheres: 64 x 64 segments, i.e. 8 064 small triangles each
+    for _ in range(sphere_count):
+        radius = rng.uniform(0.12, 0.5)
+        center = (*place(-extent * 0.85, extent * 0.85), radius * rng.uniform(1.0, 2.5))
+        tris, nrms = _sphere_triangles(center, radius, 64, 64)
+        add(tris, nrms, int(rng.integers(0, materials)))
+    positions = np.concatenate(positions, 0)
+    normals = np.concatenate(normals, 0)
+    mats = np.concatenate(mats, 0)
+    uvs = positions[:, :, :2] * 0.5
+    return positions, normals, uvs, mats
+
+
 # ---- .vkt constant textures --------------------------------------------------------
 
 def write_constant_vkt(path, rgba):
@@ -159,6 +262,15 @@ DEFAULT_MATERIALS = {
     "glossy_red": ((0.7, 0.25, 0.2), (1.0, 0.35, 0.0)),
     "brushed_metal": ((0.9, 0.8, 0.6), (1.0, 0.25, 1.0)),
 }
+
+
+LARGE_SCENE_MATERIALS = dict(DEFAULT_MATERIALS, **{
+    "matte_blue": ((0.2, 0.3, 0.7), (1.0, 0.8, 0.0)),
+    "polished_green": ((0.2, 0.6, 0.3), (1.0, 0.15, 0.0)),
+    "copper": ((0.95, 0.64, 0.54), (1.0, 0.3, 1.0)),
+    "chalk": ((0.9, 0.9, 0.85), (1.0, 0.95, 0.0)),
+    "dark_steel": ((0.4, 0.42, 0.45), (1.0, 0.4, 1.0)),
+})
 
 
 def write_material_textures(directory, materials=None):
@@ -463,14 +575,19 @@ CONFIG_SETTINGS = {
 }
 
 
-def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51, textured=False, texture_size=64, shuffle_seed=None):
+def write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=32, fresnel_count=51, textured=False, texture_size=64, shuffle_seed=None, large=None):
     """Writes scene.vks, textures/, ltc/ below `directory` and returns the paths.  textured:
-    real images (BC1 / RGBA8 / BC5 with mip chains) instead of constant material textures."""
+    real images (BC1 / RGBA8 / BC5 with mip chains) instead of constant material textures.
+    large: a dict of make_large_scene_geometry() arguments ({} for its defaults: 2.7 M triangles, eight
+    materials) instead of the benchmark scene of make_scene_geometry(grid, box_count)."""
     os.makedirs(directory, exist_ok=True)
-    names = write_material_textures(os.path.join(directory, "textures"))
+    names = write_material_textures(os.path.join(directory, "textures"), LARGE_SCENE_MATERIALS if large is not None else None)
     if textured:
         write_textured_material_textures(os.path.join(directory, "textures"), names, texture_size)
-    positions, normals, uvs, mats = make_scene_geometry(grid, box_count, seed, materials=len(names))
+    if large is not None:
+        positions, normals, uvs, mats = make_large_scene_geometry(**dict({"seed": seed, "materials": len(names)}, **large))
+    else:
+        positions, normals, uvs, mats = make_scene_geometry(grid, box_count, seed, materials=len(names))
     scene_path = os.path.join(directory, "scene.vks")
     write_vks(scene_path, positions, normals, uvs, mats, names, shuffle_seed=shuffle_seed)
     ltc_dir = os.path.join(directory, "ltc")
