@@ -415,15 +415,21 @@ def run_workload(job, config, role, scene=None):
 
     # clocks and the frame pipeline reach their steady state only after a few hundred frames (config 2:
     # 100 frames are 14 ms); the driver's --warmup 5 alone would time a cold GPU
+    # Every rank must submit the SAME number of frames (each frame is one collective): the ranks agree on when the
+    # prewarm ends - after a chunk of frames the slowest rank's clock decides for all.  (Until round 3 every rank
+    # looked at its own clock, and a rank that fitted one frame more into the time than its peers left the job hanging
+    # in its last all-gather: found by the first self-launched two-rank run, profiles/r05a/.)
     prewarm = 0
     t0 = time.perf_counter()
     prewarm_seconds = args.prewarm_seconds if role != "extra" else min(args.prewarm_seconds, 0.5)
-    while prewarm < args.prewarm_frames and (prewarm < 8 or time.perf_counter() - t0 < prewarm_seconds):
-        step()
-        prewarm += 1
-        if prewarm % 16 == 0:
-            drain()
-            torch.cuda.synchronize()
+    while prewarm < args.prewarm_frames:
+        for _ in range(min(8 if prewarm == 0 else 16, args.prewarm_frames - prewarm)):
+            step()
+            prewarm += 1
+        drain()
+        torch.cuda.synchronize()
+        if job.max_over_ranks(time.perf_counter() - t0) >= prewarm_seconds:
+            break
     for _ in range(warmup):
         step()
     fence()
@@ -445,6 +451,7 @@ def run_workload(job, config, role, scene=None):
     bands_per_frame = int(r.app.shading_pass.last_band_count)
     frames_in_flight = int(r.app.shading_pass.last_frame_in_flight) if pipelined else 1
     rays = r.last_ray_count()
+    shafts = r.light_shaft_statistics()
     stages = None
     if exchange != "none":
         mine = r.exchange_ms() or [float("nan")] * 3
@@ -588,6 +595,8 @@ def run_workload(job, config, role, scene=None):
                    "arithmetic": args.mode, "bands_per_frame": bands_per_frame, "frames_in_flight": frames_in_flight},
         "prewarm_frames": prewarm, "host_issue_ms_per_step": round(issue_seconds / steps * 1e3, 4),
         "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (ms_per_step * 1e-3) / 1e6, 2) if rays else 0.0,
+        "light_shafts": {"patch_light_pairs": shafts["pairs"], "clear_pairs": shafts["clear_pairs"], "clear_fraction": round(shafts["clear_pairs"] / max(shafts["pairs"], 1), 4),
+                         "note": "csrc/light_shafts.h: (8x8 pixel patch, light) pairs of the last launch whose shadow rays cannot be blocked (one conservative BVH walk per pair); their rays are not queued - shadow_rays_per_frame counts the rays that were traced; VKR_LIGHT_SHAFTS=0 traces them all; frames are bit-identical either way (tests/test_gpu_light_shafts.py)"},
         "setup": {"load_and_upload_ms": round(load_ms - structure.build_milliseconds, 2), "bvh_build_ms": round(float(structure.build_milliseconds), 3),
                   "bvh_builder": renderer.BVH_BUILDER_NAME[int(structure.builder)], "bvh_node_bytes": 16 * int(structure.node_count) + 64 * int(structure.wide_node_count),
                   "bvh_wide_nodes": int(structure.wide_node_count), "bvh_stack_need": int(structure.wide_stack_need), "visibility_pass_ms": round(visibility_ms, 3), "first_visibility_pass_ms": round(first_visibility_ms, 3),
@@ -813,7 +822,7 @@ def main():
     if not args.no_extra and args.config == 3 and not customised and job.world == 1:
         # the other 1920x1080 shapes the contract names, on the same clock: north_star's target and BASELINE config 2
         keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_frame_period_ms", "value_from_median", "latency_ms", "value_single_frame", "shaded_fraction",
-                "config", "shadow_rays_per_frame", "Mrays_per_s", "roofline", "parity", "traversal", "setup")
+                "config", "shadow_rays_per_frame", "Mrays_per_s", "light_shafts", "roofline", "parity", "traversal", "setup")
         result["extra_workloads"] = {}
         for extra, scene in (("target", args.scene), (2, args.scene)) + ((("3", "large"),) if args.scene == "bench" and not args.no_large_scene else ()):
             line = run_workload(job, int(extra) if extra != "target" else extra, "extra", scene)
@@ -823,7 +832,7 @@ def main():
                                        "parity": result["extra_workloads"]["config_target"].get("parity")}
     if not args.no_secondary and args.config != 4 and not customised:
         second = run_workload(job, 4, "secondary")
-        keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "shadow_rays_per_frame", "Mrays_per_s", "stages", "scaling_parity", "setup", "roofline", "traversal")
+        keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "shadow_rays_per_frame", "Mrays_per_s", "light_shafts", "stages", "scaling_parity", "setup", "roofline", "traversal")
         result["secondary"] = {k: second[k] for k in keep if k in second}
     # the library reports like the reference does (printf): every rank flushes C stdio before rank 0
     # prints, so that the JSON line is the last line of the job's output

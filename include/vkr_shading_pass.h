@@ -229,6 +229,12 @@ typedef struct shading_pass_s {
 		1920x1080 frames, eight for BASELINE config 4.  Set before create_shading_pass like
 		arithmetic_mode.  last_band_count: what the most recent frame used. */
 	uint32_t band_count, last_band_count;
+	/*! Light shafts (csrc/light_shafts.h): before a launch with wavefront shadow rays one conservative walk of the
+		BVH per 8x8 pixel patch and light finds the pairs whose shadow rays cannot be blocked by anything; their
+		terms are final at once and their rays are never queued.  Results of ray queries - and frames - are
+		unchanged.  Environment VKR_LIGHT_SHAFTS=0 turns it off.  last_shaft_groups: patches of the most recent
+		launch that were tested (0: the launch ran without the test); get_light_shaft_statistics() counts. */
+	uint32_t last_shaft_groups, reserved;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
@@ -380,6 +386,9 @@ VKR_API uint64_t get_last_ray_count(const application_t* app);
 	and writes {rays, node visits, triangle tests, blocked rays, wave steps (sum over
 	groups of 64 rays of the longest ray's visits), longest ray's visits}.  0 on success. */
 VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]);
+/*! Light shafts of the most recent launch: {(patch, light) pairs tested, pairs found clear - no shadow ray queued
+	for them -, patches, lights}; all zero when the launch ran without the shaft test.  0 on success. */
+VKR_API int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[4]);
 /*! The same for the tree of the caller's choice - the binary one (one box per visit) or the
 	four-wide one (a visit fetches one node and tests up to four boxes) - whatever the frame itself
 	walked, plus (wide tree only) [6] boxes tested, [7] the deepest stack a ray reached, [8] rays whose stack

@@ -16,7 +16,7 @@ from vulkan_renderer_amd import renderer, synthetic
 
 pytestmark = pytest.mark.gpu
 
-BANDS = ((60, 100), (400, 440), (700, 736), (1030, 1080))
+BANDS = ((200, 240), (400, 440), (700, 736), (1030, 1080))
 
 
 @pytest.fixture(scope="module")
@@ -75,7 +75,7 @@ def test_libm_frame_of_the_large_scene_equals_the_oracle_in_every_bit(large_orac
         compared += (y1 - y0) * 1920
         assert stats["nan"] == 0 and stats["bit_exact"], ((y0, y1), stats)
         # (a band that sees nothing would prove nothing)
-        assert (cpu[..., :3] > 0).any(axis=-1).mean() > 0.05
+        assert (cpu[..., :3] > 0).any(axis=-1).mean() > 0.02
     assert differing == 0 and compared >= 300_000
 
 

@@ -1,0 +1,106 @@
+"""Light shafts (csrc/light_shafts.h): (8x8 pixel patch, light) pairs whose shadow rays cannot be blocked by anything are
+found by one conservative walk of the BVH per pair, and their rays are never queued.  Every ray query keeps its
+result, so every frame keeps every bit: rendered with the test (the default) and without it (VKR_LIGHT_SHAFTS=0)
+on both scenes, on a slice of the random sweep and on lights that graze, touch or surround the geometry.
+(The whole GPU suite runs with the test on: every bit-parity test against the oracle checks it as well.)"""
+import math
+
+import numpy as np
+import pytest
+
+import golden_cases
+import test_gpu_sweep
+from vulkan_renderer_amd import renderer, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def frames_with_and_without(monkeypatch, setup, frames_in_flight=1):
+    """-> (frame with shafts, frame without, rays with, rays without, shaft statistics)"""
+    out = {}
+    for shafts in (1, 0):
+        monkeypatch.setenv("VKR_LIGHT_SHAFTS", str(shafts))
+        r = renderer.Renderer(frames_in_flight=frames_in_flight)
+        setup(r)
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        for _ in range(frames_in_flight):
+            r.render()
+        out[shafts] = (r.read_radiance(), r.last_ray_count(), r.light_shaft_statistics())
+        r.close()
+    monkeypatch.delenv("VKR_LIGHT_SHAFTS")
+    return out[1][0], out[0][0], out[1][1], out[0][1], out[1][2], out[0][2]
+
+
+@pytest.mark.parametrize("config, width, height", [(2, 960, 540), (3, 1920, 1080), ("target", 1280, 720), (4, 1920, 1080)])
+def test_benchmark_scene_same_frame_fewer_rays(big_dataset, monkeypatch, config, width, height):
+    on, off, rays_on, rays_off, stats, stats_off = frames_with_and_without(
+        monkeypatch, lambda r: renderer.setup_config(r, config, big_dataset, width=width, height=height, acceleration_structure="sah_device"), frames_in_flight=2)
+    print(config, stats, rays_on, rays_off)
+    assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), int((on != off).any(axis=-1).sum())
+    assert stats_off["pairs"] == 0 and stats["pairs"] > 0
+    # an open scene: most patches see most lights freely
+    assert stats["clear_pairs"] > 0.3 * stats["pairs"], stats
+    assert 0 < rays_on < 0.7 * rays_off, (rays_on, rays_off)
+
+
+def test_large_scene_same_frame(monkeypatch, tmp_path):
+    dataset = synthetic.write_dataset(str(tmp_path / "large"), seed=4321, ltc_resolution=32, fresnel_count=16, large={})
+    on, off, rays_on, rays_off, stats, _ = frames_with_and_without(
+        monkeypatch, lambda r: renderer.setup_config(r, 3, dataset, width=1920, height=1080, acceleration_structure="sah_device"))
+    print(stats, rays_on, rays_off)
+    assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), int((on != off).any(axis=-1).sum())
+    assert stats["pairs"] > 0 and rays_on <= rays_off
+
+
+@pytest.mark.parametrize("seed", [s for s in range(60) if test_gpu_sweep.random_case(s)["rays"]][:24])
+def test_random_configurations_same_frame(seed, monkeypatch, tmp_path_factory):
+    dataset = synthetic.write_dataset(str(tmp_path_factory.mktemp("shafts_sweep")), **golden_cases.DATASET)
+    case = test_gpu_sweep.random_case(seed)
+
+    def setup(r):
+        golden_cases.apply_case(r, case, dataset, 160, 96)
+        cam = dict(synthetic.DEFAULT_CAMERA, **case["camera"])
+        r.set_camera(cam["position"], cam["rotation_x"], cam["rotation_z"], cam["vertical_fov"], cam["near"], cam["far"])
+        r.set_settings(roughness_factor=case["roughness_factor"], exposure_factor=case["exposure_factor"], mis_visibility_estimate=case["mis_visibility_estimate"])
+    on, off, rays_on, rays_off, stats, _ = frames_with_and_without(monkeypatch, setup, frames_in_flight=1 + seed % 3)
+    assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), (seed, int((on != off).any(axis=-1).sum()), stats)
+    assert rays_on <= rays_off
+
+
+def test_lights_that_touch_graze_or_surround_the_geometry(monkeypatch, tmp_path):
+    """where a shaft has no business being clear: a light lying on the floor, one standing in it, one that the floor
+    cuts in two, a ceiling over the whole scene, a light inside a box's footprint, a speck, a light far away"""
+    pi = math.pi
+    dataset = synthetic.write_dataset(str(tmp_path / "small"), **golden_cases.DATASET)
+    quad = synthetic.QUAD
+    lights = [
+        synthetic.light_spec(quad, (-1.0, 1.0, 2.0e-3), (pi, 0.0, 0.0), (10, 10, 10), (2.0, 2.0)),            # on the floor, facing up
+        synthetic.light_spec(quad, (-2.0, 0.0, 0.0), (0.5 * pi, 0.0, 0.7), (8, 8, 8), (1.5, 1.5)),               # upright, its lower edge in the floor
+        synthetic.light_spec(quad, (0.5, 2.0, -0.4), (0.5 * pi, 0.0, 2.0), (8, 8, 8), (1.0, 1.2)),               # cut in two by the floor
+        synthetic.light_spec(quad, (-12.0, 12.0, 4.0), (pi, 0.0, 0.0), (40, 40, 40), (24.0, 24.0)),             # a ceiling over everything
+        synthetic.light_spec(synthetic.regular_polygon(7, 0.5, 0.1), (-1.5, 1.5, 0.3), (0.6 * pi, 0.15, 1.1), (14, 12, 9), (1.8, 1.3)),  # between the boxes
+        synthetic.light_spec([(0, 0), (1, 0), (0, 1)], (-2.0, 0.5, 0.8), (0.7 * pi, 0.2, 1.0), (1e3, 1e3, 1e3), (2e-3, 5e-3)),          # a speck
+        synthetic.light_spec(synthetic.regular_polygon(5), (300.0, 500.0, 800.0), (pi, 0.0, 0.0), (1e7, 1e7, 1e7), (40.0, 40.0)),      # far away
+    ]
+    for strategy, heuristic, technique in ((3, 3, "projected_solid_angle"), (3, 4, "projected_solid_angle"), (1, 0, "projected_solid_angle"),
+                                           (0, 0, "solid_angle"), (1, 0, "clipped_solid_angle"), (2, 0, "projected_solid_angle_biased")):
+        case = dict(lights=lights, strategy=strategy, heuristic=heuristic, samples=2, rays=True, technique=technique)
+        on, off, rays_on, rays_off, stats, _ = frames_with_and_without(monkeypatch, lambda r: golden_cases.apply_case(r, case, dataset, 192, 108))
+        assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), (strategy, heuristic, technique, int((on != off).any(axis=-1).sum()), stats)
+        assert rays_on <= rays_off
+
+
+def test_techniques_whose_samples_may_miss_the_polygon_are_left_alone(big_dataset, monkeypatch):
+    """the shaft holds the rays of techniques that aim at the light polygon; the related-work samplers are not on the list"""
+    monkeypatch.setenv("VKR_LIGHT_SHAFTS", "1")
+    r = renderer.Renderer()
+    renderer.setup_config(r, 3, big_dataset, width=640, height=360, acceleration_structure="sah_device", sampling_strategies="diffuse_only", polygon_technique="area_turk")
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    r.render()
+    stats = r.light_shaft_statistics()
+    r.close()
+    assert stats["pairs"] == 0

@@ -139,7 +139,8 @@ class ShadingPass(C.Structure):
                 ("constants_device", C.c_void_p), ("constants_host", C.c_void_p), ("constants_size", C.c_size_t), ("constants_ring", C.c_void_p),
                 ("arithmetic_mode", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("last_frame_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("pixel_materials", C.c_void_p), ("pixel_materials_size", C.c_size_t), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
                 ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32), ("last_frame_traced_rays", C.c_uint32), ("binary_traversal", C.c_int32),
-                ("wait_before_next_frame", C.c_void_p), ("last_frame_stream", C.c_void_p), ("band_count", C.c_uint32), ("last_band_count", C.c_uint32)]
+                ("wait_before_next_frame", C.c_void_p), ("last_frame_stream", C.c_void_p), ("band_count", C.c_uint32), ("last_band_count", C.c_uint32),
+                ("last_shaft_groups", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Application(C.Structure):
@@ -242,6 +243,7 @@ SIGNATURES = {
     "encode_slab_rgb8": (C.c_int, [P(Application), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "assemble_rgb8_frame_from_slabs": (C.c_int, [P(Application), C.c_void_p, C.c_void_p]),
     "get_traversal_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
+    "get_light_shaft_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_shading_kernel_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "get_frame_period_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),

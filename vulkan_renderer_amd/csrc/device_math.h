@@ -163,7 +163,8 @@ VKR_DEV float square_root(float x) {
 #if VKR_FAST_MATH
 	return __builtin_amdgcn_sqrtf(x);
 #elif VKR_IEEE_DIVISION_EVERYWHERE
-	return __fsqrt_rn(x);
+	// (the compiler's correctly rounded root - the default of hipcc; __fsqrt_rn() is NOT: it maps to the native instruction)
+	return __builtin_sqrtf(x);
 #elif VKR_SQRT_VARIANT == 2
 	float estimate = __builtin_amdgcn_sqrtf(x);
 	float s = fmaf(fmaf(-estimate, estimate, x), 0.5f * __builtin_amdgcn_rsqf(x), estimate);
@@ -182,7 +183,7 @@ VKR_DEV float square_root(float x) {
 // two correctly rounded operations, 1 / sqrt(x)
 VKR_DEV float inverse_square_root_ieee(float x) {
 #if VKR_IEEE_DIVISION_EVERYWHERE
-	return __fdiv_rn(1.0f, __fsqrt_rn(x));
+	return __fdiv_rn(1.0f, __builtin_sqrtf(x));
 #elif VKR_SQRT_VARIANT == 2
 	return divide(1.0f, square_root(x));
 #else

@@ -43,7 +43,7 @@
 #define GM_DIVF(a, b) __fdiv_rn((a), (b))
 #endif
 #ifndef GM_SQRTF
-#define GM_SQRTF(x) __fsqrt_rn(x)
+#define GM_SQRTF(x) __builtin_sqrtf(x) /* (correctly rounded under hipcc's default; __fsqrt_rn() maps to the native instruction) */
 #endif
 GM_FN uint32_t gm_bits(float f) { return __float_as_uint(f); }
 GM_FN float gm_float(uint32_t u) { return __uint_as_float(u); }

@@ -1,0 +1,335 @@
+// Light shafts: which (8x8 pixel patch, polygonal light) pairs need no shadow rays at all.
+//
+// The reference traces one ray query per sample (src/shaders/shading_pass.frag.glsl:120-138).  Most of those
+// rays cross empty space: every sample of a patch of neighbouring pixels toward one light lies inside the convex
+// hull of the patch's shading positions and the light polygon - the shaft of Haines & Wallace, "Shaft Culling for
+// Efficient Ray-Cast Radiosity" (1991) - and if no triangle of the scene reaches into that hull, every one of
+// those rays arrives, whatever its direction.  k_light_shafts decides that per patch and light with ONE
+// conservative walk of the four-wide BVH by the whole wave (64 boxes or 64 triangles per step, one per lane,
+// the shaft's planes wave-uniform); the shading kernel then writes the terms of such a light as final ones
+// instead of queueing their rays (accumulate(), shading_kernel.h).  The result of every ray query is unchanged:
+// "clear" is only ever claimed when no triangle can be hit, with margins that cover the rounding of the kernels
+// that would have traced the rays, so frames stay bit-identical (tests/test_gpu_light_shafts.py renders them
+// with and without).  What it buys depends on the scene: 83 % of the lit (patch, light) pairs of the benchmark
+// scene at config 3 are clear, 7 % of the large scene's (profiles/).
+//
+// Conservative by construction.  With c, rho the centre and radius (plus margin) of the patch's shading
+// positions, L'_i the light's vertices moved away from their centroid by 1/32 (sampled directions may leave the
+// polygon by rounding), n_L the light's plane:
+//   side plane k     through c, L'_k, L'_k+1, pushed outwards by rho      contains the sphere and the polygon
+//   far cap          n_L . x <= n_L . L_0 + margin                          rays end on the light's plane
+//   near cap         a . x >= a . c - rho, a towards the centroid         only if every L'_i lies in front of it
+// Their intersection contains every ray of the patch toward the light.  A box is skipped when it lies outside
+// one plane (or outside the bounding box of sphere and polygon); a triangle is harmless when
+//   (i)  its three vertices lie outside one of those planes, or
+//   (ii) its own plane separates it from the rays: the light's vertices lie on one side of it by a margin and
+//        every ray's first point o + t_min u (t_min = 1e-3, the ray query's) does too - which is what lets a
+//        patch see past the very surface it lies on.
+// Anything else - also a walk that gets long or a queue that fills up - means "trace the rays".
+#pragma once
+#include "shading_kernel.h"
+
+namespace vkr {
+
+constexpr uint32_t kShaftMaxVertices = 8;                     // light polygons with more vertices are never clear
+constexpr uint32_t kShaftMaxPlanes = kShaftMaxVertices + 2;   // sides, far cap, near cap
+constexpr uint32_t kShaftFrontier = 320;                      // inner nodes waiting (LDS); more -> not clear
+constexpr uint32_t kShaftLeaves = 192;                        // triangles waiting
+constexpr uint32_t kShaftMaxSteps = 48;                       // steps of 16 nodes; more -> not clear
+constexpr float kShaftDilation = 1.0f / 32.0f;
+
+// what the walk needs to know about one (patch, light), wave-uniform, in LDS
+struct shaft_state {
+	float plane[kShaftMaxPlanes][4];   // n . x <= d  (n unit length)
+	float box_lo[3], box_hi[3];        // bounding box of sphere and dilated polygon
+	float light[kShaftMaxVertices][3]; // dilated vertices
+	uint32_t plane_count, vertex_count;
+	// rays toward the light climb at least this steeply out of a plane that the light lies `h` above:
+	// (h - g) / reach for an origin at height g
+	float reach;                        // largest distance from an origin to a light vertex
+	// flat patches: how far above the patch's own plane the first point of every ray lies at least (the light on one
+	// side of that plane, else negative), measured along the plane's normal
+	float flat_first;
+};
+
+struct shaft_patch {
+	float origin[64][3];
+	uint64_t valid;                     // lanes with a shading position
+	float centre[3], radius;
+	// the patch's own plane if all its positions lie on one (within flat_tolerance): n unit, n . x = d
+	float flat_normal[3], flat_d;
+	uint32_t flat;
+};
+
+VKR_DEV float wave_min(float v) {
+#pragma unroll
+	for (int offset = 32; offset > 0; offset >>= 1) v = fminf(v, __shfl_xor(v, offset));
+	return v;
+}
+VKR_DEV float wave_max(float v) {
+#pragma unroll
+	for (int offset = 32; offset > 0; offset >>= 1) v = fmaxf(v, __shfl_xor(v, offset));
+	return v;
+}
+
+// One box or triangle per lane against the planes of the shaft.  true: the box may reach into the shaft.
+VKR_DEV bool shaft_box_inside(const shaft_state& s, f3 lo, f3 hi) {
+	if (hi.x < s.box_lo[0] || lo.x > s.box_hi[0] || hi.y < s.box_lo[1] || lo.y > s.box_hi[1] || hi.z < s.box_lo[2] || lo.z > s.box_hi[2]) return false;
+	f3 centre = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+	f3 half = mk3(0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z));
+	bool inside = true;
+	for (uint32_t k = 0; k != s.plane_count; ++k) {
+		float nx = s.plane[k][0], ny = s.plane[k][1], nz = s.plane[k][2];
+		// the corner of the box that is deepest inside the half space
+		float nearest = fmaf(nx, centre.x, fmaf(ny, centre.y, nz * centre.z)) - fmaf(fabsf(nx), half.x, fmaf(fabsf(ny), half.y, fabsf(nz) * half.z));
+		inside = inside && nearest <= s.plane[k][3];
+	}
+	return inside;
+}
+
+// true: the triangle cannot be hit by any ray of the patch toward the light
+VKR_DEV bool shaft_triangle_harmless(const shaft_state& s, const shaft_patch& patch, f3 a, f3 b, f3 c, float margin) {
+	// (i) outside one plane of the shaft
+	for (uint32_t k = 0; k != s.plane_count; ++k) {
+		float nx = s.plane[k][0], ny = s.plane[k][1], nz = s.plane[k][2], d = s.plane[k][3];
+		float da = fmaf(nx, a.x, fmaf(ny, a.y, nz * a.z)), db = fmaf(nx, b.x, fmaf(ny, b.y, nz * b.z)), dc = fmaf(nx, c.x, fmaf(ny, c.y, nz * c.z));
+		if (fminf(da, fminf(db, dc)) > d) return true;
+	}
+	// (ii) for a flat patch and a triangle in the patch's own plane (the surface the patch lies on - the common case):
+	// the triangle stays within `margin` of that plane, the rays' first points lie higher
+	if (patch.flat && s.flat_first > 3.0f * margin) {
+		float ha = fabsf(patch.flat_normal[0] * a.x + patch.flat_normal[1] * a.y + patch.flat_normal[2] * a.z - patch.flat_d);
+		float hb = fabsf(patch.flat_normal[0] * b.x + patch.flat_normal[1] * b.y + patch.flat_normal[2] * b.z - patch.flat_d);
+		float hc = fabsf(patch.flat_normal[0] * c.x + patch.flat_normal[1] * c.y + patch.flat_normal[2] * c.z - patch.flat_d);
+		if (fmaxf(ha, fmaxf(hb, hc)) <= margin) return true;
+	}
+	// (ii) in general: the triangle's own plane separates it from the rays - the light's vertices and the first
+	// points of all rays on one side
+	f3 n = cross(b - a, c - a);
+	float length_squared = dot(n, n);
+	if (!(length_squared > 1.0e-30f)) return false;  // (no plane to speak of: whether rounding lets a ray "hit" a sliver is the tracing kernel's business)
+	float scale = __builtin_amdgcn_rsqf(length_squared);
+	n = n * scale;
+	float h_min = 3.0e38f, h_max = -3.0e38f;
+	for (uint32_t i = 0; i != s.vertex_count; ++i) {
+		float h = n.x * (s.light[i][0] - a.x) + n.y * (s.light[i][1] - a.y) + n.z * (s.light[i][2] - a.z);
+		h_min = fminf(h_min, h); h_max = fmaxf(h_max, h);
+	}
+	// look at the triangle from the light's side
+	if (h_max < 0.0f) { n = -n; float t = h_min; h_min = -h_max; h_max = -t; }
+	if (!(h_min > 4.0f * margin)) return false;
+	// lowest origin above the plane
+	float g_min = 3.0e38f;
+	uint64_t lanes = patch.valid;
+	while (lanes) {
+		int j = __builtin_ctzll(lanes);
+		lanes &= lanes - 1;
+		float g = n.x * (patch.origin[j][0] - a.x) + n.y * (patch.origin[j][1] - a.y) + n.z * (patch.origin[j][2] - a.z);
+		g_min = fminf(g_min, g);
+	}
+	g_min -= margin;
+	// the first point of a ray from height g: g + t_min n . u with n . u >= (h_min - g) / reach; grows with g
+	float first = g_min + 1.0e-3f * (h_min - g_min) / s.reach;
+	return g_min <= h_min && first > 2.0f * margin;
+}
+
+// `b` numbers the workgroups like shade_pixels does (one 8x8 patch each); out_clear[b * light_count + i] = 1 when no
+// ray of that patch toward light i can be blocked.  extent: largest coordinate difference of the scene (margins).
+__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float extent) {
+	__shared__ shaft_patch patch;
+	__shared__ shaft_state s;
+	__shared__ uint32_t frontier[kShaftFrontier];
+	__shared__ uint32_t leaves[kShaftLeaves];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t b = blockIdx.x;
+	const uint32_t local_block = ((b >> 5) << 3) | (b & 7u);
+	const uint32_t thread = (((b >> 3) & 3u) << 6) | lane;
+	uint32_t px, py;
+	size_t out_index;
+	bool inside = local_block < p.block_count && locate_pixel(p, p.first_block + local_block, thread, px, py, out_index);
+	uint32_t primitive = inside ? p.visibility[(size_t) py * p.width + px] : 0xFFFFFFFFu;
+	bool shaded = primitive != 0xFFFFFFFFu;
+	uint32_t* clear = out_clear + (size_t) b * p.light_count;
+	const uint64_t valid = __ballot(shaded);
+	if (valid == 0) {
+		for (uint32_t i = lane; i < p.light_count; i += 64u) clear[i] = 0u;
+		return;
+	}
+	// ---- the patch: shading positions as the shading kernel computes them (get_shading_data) ---------------
+	const float margin = 2.0e-6f * extent;
+	f3 position = mk3(0.0f, 0.0f, 0.0f), face_normal = position;
+	float face_d = 0.0f;
+	if (shaded) {
+		const uint8_t* c = p.constants;
+		float fx = (float) (int32_t) px, fy = (float) (int32_t) py;
+		f3 ray = mk3(
+			(load_f(c, 96) * fx + load_f(c, 100) * fy) + load_f(c, 104) * 1.0f,
+			(load_f(c, 112) * fx + load_f(c, 116) * fy) + load_f(c, 120) * 1.0f,
+			(load_f(c, 128) * fx + load_f(c, 132) * fy) + load_f(c, 136) * 1.0f);
+		triangle_hit t = intersect_primitive(p, primitive, ray);
+		position = fma3(t.b0, t.pos[0], fma3(t.b1, t.pos[1], t.pos[2] * t.b2));
+		face_normal = cross(t.e0, t.e1);
+		face_normal = face_normal * __builtin_amdgcn_rsqf(fmaxf(dot(face_normal, face_normal), 1.0e-38f));
+		face_d = dot(face_normal, t.pos[0]);
+		patch.origin[lane][0] = position.x; patch.origin[lane][1] = position.y; patch.origin[lane][2] = position.z;
+	}
+	const float big = 3.0e38f;
+	f3 lo = mk3(wave_min(shaded ? position.x : big), wave_min(shaded ? position.y : big), wave_min(shaded ? position.z : big));
+	f3 hi = mk3(wave_max(shaded ? position.x : -big), wave_max(shaded ? position.y : -big), wave_max(shaded ? position.z : -big));
+	f3 centre = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+	f3 diagonal = hi - lo;
+	float radius = 0.5f * __builtin_sqrtf(dot(diagonal, diagonal)) * 1.0001f + 2.0f * margin;
+	// is the patch flat?  the plane of the first valid lane's triangle, and every position on it
+	const int first_lane = __builtin_ctzll(valid);
+	f3 plane_n = mk3(__shfl(face_normal.x, first_lane), __shfl(face_normal.y, first_lane), __shfl(face_normal.z, first_lane));
+	float plane_d = __shfl(face_d, first_lane);
+	float off_plane = wave_max(shaded ? fabsf(dot(plane_n, position) - plane_d) : 0.0f);
+	if (lane == 0) {
+		patch.valid = valid;
+		patch.centre[0] = centre.x; patch.centre[1] = centre.y; patch.centre[2] = centre.z;
+		patch.radius = radius;
+		patch.flat_normal[0] = plane_n.x; patch.flat_normal[1] = plane_n.y; patch.flat_normal[2] = plane_n.z;
+		patch.flat_d = plane_d;
+		patch.flat = (off_plane <= margin && dot(plane_n, plane_n) > 0.5f) ? 1u : 0u;
+	}
+	__syncthreads();
+	const f3 grid_origin = p.bvh.grid_origin;
+	const f3 cell = mk3(1.0f / p.bvh.grid_inverse_cell.x, 1.0f / p.bvh.grid_inverse_cell.y, 1.0f / p.bvh.grid_inverse_cell.z);
+	for (uint32_t light_index = 0; light_index != p.light_count; ++light_index) {
+		light_ref light = get_light(p, light_index);
+		const uint32_t vertex_count = light_vertex_count(light);
+		// ---- the shaft of this light (lanes build one plane each) ---------------------------------------------
+		bool possible = vertex_count >= 3u && vertex_count <= kShaftMaxVertices;
+		// every position on the same side of the light's plane, away from it
+		float side = shaded ? plane_distance(light, position) : 0.0f;
+		float side_min = wave_min(shaded ? side : big), side_max = wave_max(shaded ? side : -big);
+		possible = possible && (side_min > 8.0f * margin || side_max < -8.0f * margin);
+		__syncthreads();  // (the previous light's walk is over: the shared state may change)
+		if (possible) {
+			f3 centroid = mk3(0.0f, 0.0f, 0.0f);
+			for (uint32_t i = 0; i != vertex_count; ++i) centroid = centroid + light_vertex(light, i);
+			centroid = centroid * (1.0f / (float) vertex_count);
+			// dilated vertex of this lane (lanes beyond the polygon repeat vertices; unused)
+			uint32_t k = lane % vertex_count, k1 = (k + 1u) % vertex_count;
+			f3 v0 = light_vertex(light, k), v1 = light_vertex(light, k1);
+			float grow = 1.0f + kShaftDilation;
+			f3 pad_direction = v0 - centroid;
+			v0 = centroid + (v0 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
+			pad_direction = v1 - centroid;
+			v1 = centroid + (v1 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
+			f3 axis = centroid - centre;
+			float axis_length = __builtin_sqrtf(dot(axis, axis));
+			axis = axis * (1.0f / fmaxf(axis_length, 1.0e-30f));
+			float along = dot(v0 - centre, axis);
+			float reach = __builtin_sqrtf(dot(v0 - centre, v0 - centre));
+			float along_min = wave_min(lane < vertex_count ? along : big);
+			float reach_max = wave_max(lane < vertex_count ? reach : 0.0f);
+			// heights of the light above the patch's own plane (flat patches)
+			float above = dot(plane_n, v0) - plane_d;
+			float above_min = wave_min(lane < vertex_count ? above : big), above_max = wave_max(lane < vertex_count ? above : -big);
+			if (above_max < 0.0f) { float t = above_min; above_min = -above_max; above_max = -t; }
+			// side plane k: through the centre and the edge, the rest of the light behind it
+			f3 n = cross(v0 - centre, v1 - centre);
+			float n_length_squared = dot(n, n);
+			bool degenerate = !(n_length_squared > 1.0e-30f);
+			n = n * __builtin_amdgcn_rsqf(fmaxf(n_length_squared, 1.0e-30f));
+			if (dot(n, centroid - centre) > 0.0f) n = -n;
+			// (a polygon seen edge-on or a centre inside it leaves no pyramid: every plane must keep the centroid well inside)
+			bool bad = lane < vertex_count && (degenerate || !(dot(n, centroid - centre) < -1.0e-3f * axis_length));
+			possible = __ballot(bad) == 0 && axis_length > 4.0f * radius;
+			if (lane < vertex_count) {
+				s.plane[lane][0] = n.x; s.plane[lane][1] = n.y; s.plane[lane][2] = n.z;
+				s.plane[lane][3] = dot(n, centre) + radius;
+				s.light[lane][0] = v0.x; s.light[lane][1] = v0.y; s.light[lane][2] = v0.z;
+			}
+			if (lane == 0) {
+				// far cap: nothing behind the light's plane matters
+				f3 nl = plane_normal(light);
+				float nl_length = __builtin_sqrtf(dot(nl, nl));
+				float sign = (side_min > 0.0f) ? -1.0f : 1.0f;  // positions on the positive side: the far side is the negative one
+				f3 far_n = nl * (sign / fmaxf(nl_length, 1.0e-30f));
+				float light_offset = dot(far_n, light_vertex(light, 0));
+				s.plane[vertex_count][0] = far_n.x; s.plane[vertex_count][1] = far_n.y; s.plane[vertex_count][2] = far_n.z;
+				s.plane[vertex_count][3] = light_offset + 8.0f * margin;
+				uint32_t planes = vertex_count + 1u;
+				// near cap: only if the whole light lies in front of it
+				if (along_min > 0.0f) {
+					s.plane[planes][0] = -axis.x; s.plane[planes][1] = -axis.y; s.plane[planes][2] = -axis.z;
+					s.plane[planes][3] = -(dot(axis, centre) - radius);
+					++planes;
+				}
+				s.plane_count = planes;
+				s.vertex_count = vertex_count;
+				s.reach = reach_max + radius;
+				// (positions within `margin` of the plane; a ray toward a point `h` above it climbs at least (h - margin) / reach)
+				s.flat_first = above_min > 2.0f * margin ? -margin + 1.0e-3f * (above_min - margin) / s.reach : -1.0f;
+			}
+			// bounding box of sphere and polygon
+			f3 box_lo = mk3(wave_min(lane < vertex_count ? v0.x : big), wave_min(lane < vertex_count ? v0.y : big), wave_min(lane < vertex_count ? v0.z : big));
+			f3 box_hi = mk3(wave_max(lane < vertex_count ? v0.x : -big), wave_max(lane < vertex_count ? v0.y : -big), wave_max(lane < vertex_count ? v0.z : -big));
+			if (lane == 0) {
+				s.box_lo[0] = fminf(box_lo.x, centre.x - radius); s.box_lo[1] = fminf(box_lo.y, centre.y - radius); s.box_lo[2] = fminf(box_lo.z, centre.z - radius);
+				s.box_hi[0] = fmaxf(box_hi.x, centre.x + radius); s.box_hi[1] = fmaxf(box_hi.y, centre.y + radius); s.box_hi[2] = fmaxf(box_hi.z, centre.z + radius);
+			}
+		}
+		__syncthreads();
+		// ---- the walk ----------------------------------------------------------------------------------------------
+		bool is_clear = possible;
+		if (possible) {
+			uint32_t waiting = 1, leaf_count = 0, steps = 0;
+			if (lane == 0) frontier[0] = 0u;
+			__syncthreads();
+			while (waiting != 0 || leaf_count != 0) {
+				if (++steps > kShaftMaxSteps) { is_clear = false; break; }
+				if (waiting != 0) {
+					// the last (up to) sixteen nodes of the frontier, four lanes each
+					uint32_t take = waiting < 16u ? waiting : 16u;
+					bool active = (lane >> 2) < take;
+					uint32_t link = kWideEmpty;
+					bool hit = false;
+					if (active) {
+						uint32_t node = frontier[waiting - take + (lane >> 2)];
+						const uint32_t* words = (const uint32_t*) (wide_nodes + 4 * (size_t) node);
+						uint32_t child = lane & 3u;
+						uint32_t qx = words[child], qy = words[4 + child], qz = words[8 + child];
+						link = words[12 + child];
+						if (link != kWideEmpty) {
+							f3 box_lo = mk3(fmaf((float) (qx & 0xFFFFu), cell.x, grid_origin.x), fmaf((float) (qy & 0xFFFFu), cell.y, grid_origin.y), fmaf((float) (qz & 0xFFFFu), cell.z, grid_origin.z));
+							f3 box_hi = mk3(fmaf((float) (qx >> 16), cell.x, grid_origin.x), fmaf((float) (qy >> 16), cell.y, grid_origin.y), fmaf((float) (qz >> 16), cell.z, grid_origin.z));
+							box_lo = box_lo - mk3(margin, margin, margin);
+							box_hi = box_hi + mk3(margin, margin, margin);
+							hit = shaft_box_inside(s, box_lo, box_hi);
+						}
+					}
+					__syncthreads();  // (everyone has read its frontier entry before the entries are overwritten)
+					waiting -= take;
+					bool to_frontier = hit && !(link & kLeafBit), to_leaves = hit && (link & kLeafBit) != 0;
+					uint64_t inner_mask = __ballot(to_frontier), leaf_mask = __ballot(to_leaves);
+					uint32_t inner_new = (uint32_t) __popcll((unsigned long long) inner_mask), leaf_new = (uint32_t) __popcll((unsigned long long) leaf_mask);
+					if (waiting + inner_new > kShaftFrontier || leaf_count + leaf_new > kShaftLeaves) { is_clear = false; break; }
+					if (to_frontier) frontier[waiting + __builtin_amdgcn_mbcnt_hi((uint32_t) (inner_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) inner_mask, 0u))] = link;
+					if (to_leaves) leaves[leaf_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (leaf_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) leaf_mask, 0u))] = link & ~kLeafBit;
+					waiting += inner_new;
+					leaf_count += leaf_new;
+					__syncthreads();
+				}
+				// triangles: as soon as a good part of the wave has one, or nothing else is left
+				if (leaf_count >= 32u || (waiting == 0 && leaf_count != 0)) {
+					uint32_t take = leaf_count < 64u ? leaf_count : 64u;
+					bool harmless = true;
+					if (lane < take) {
+						const float4* t = p.bvh.triangles + 3 * (size_t) leaves[leaf_count - take + lane];
+						float4 a = t[0], bq = t[1], cq = t[2];
+						harmless = shaft_triangle_harmless(s, patch, mk3(a.x, a.y, a.z), mk3(bq.x, bq.y, bq.z), mk3(cq.x, cq.y, cq.z), margin);
+					}
+					__syncthreads();
+					leaf_count -= take;
+					if (__ballot(!harmless) != 0) { is_clear = false; break; }
+				}
+			}
+		}
+		if (lane == 0) clear[light_index] = is_clear ? 1u : 0u;
+	}
+}
+
+}  // namespace vkr

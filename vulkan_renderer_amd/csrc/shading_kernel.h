@@ -85,6 +85,9 @@ struct shade_params {
 	uint32_t* ray_queue_size;
 	uint32_t ray_queue_capacity, ray_thread_bits;
 	uint32_t thread_count, max_terms, max_codes;
+	// light shafts (light_shafts.h): [shading workgroup][light] = 1 when no shadow ray of that 8x8 patch toward that
+	// light can be blocked - its terms are then written as final ones and no ray is queued; NULL: every ray is traced
+	const uint32_t* shaft_clear;
 	// first 16x16 pixel block of this launch in the rank's schedule (a frame may be rendered as
 	// several launches, "bands", each with wavefront buffers of its own size)
 	uint32_t first_block, block_count;
@@ -729,6 +732,8 @@ struct pixel_context {
 	// deferred mode: this thread's slot in the term streams and its write cursors
 	uint32_t tid, code_cursor, term_cursor;
 	bool light_has_terms;
+	// nothing can block a ray toward the current light (shade_params::shaft_clear; wave-uniform)
+	bool light_clear;
 	uint32_t queue;
 	// this thread's column of the LDS tables of the prepared polygons (strategies with two
 	// techniques per light: 2 x kPsaTableSlots(V) slots, [slot][thread]), else NULL
@@ -838,9 +843,10 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		// Adding +-0 never changes the running sum (it starts at +0), so such terms are
 		// dropped; everything else is written in program order.
 		const shade_params& p = ctx.p;
+		// (a ray toward a light whose shaft is clear would arrive: its term is the visible one, right away)
 		bool hidden_matters = !all_zero(hidden_term);
-		bool needs_ray = candidate && (hidden_matters || !all_zero(visible_term));
-		bool is_final = !candidate && !all_zero(visible_term);
+		bool needs_ray = candidate && !ctx.light_clear && (hidden_matters || !all_zero(visible_term));
+		bool is_final = (!candidate || ctx.light_clear) && !all_zero(visible_term);
 		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
 			if (ctx.noise) settle_noise(*ctx.noise);
 			size_t code_index = code_slot(p.thread_count, ctx.code_cursor, ctx.tid);
@@ -1481,7 +1487,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
-	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, queue, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, queue, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		lds_state_word* state = ray_block_state();
@@ -1522,6 +1528,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 			ctx.noise = &noise;
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
+				if constexpr (is_deferred(RAYS)) ctx.light_clear = p.shaft_clear != nullptr && *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) != 0u;
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);
 			}
 		}

@@ -3,6 +3,7 @@
 // (create_shading_pass src/main.c:598, write_constants :2114, the vkCmdDraw of
 // record_render_frame_commands :1428-1434, implement_screenshot :1719).
 #include "wavefront_kernels.h"
+#include "light_shafts.h"
 #include "host/vkr_internal.h"
 #include <hip/hip_fp16.h>
 
@@ -134,12 +135,17 @@ struct wavefront_buffers {
 	// allocated only for trees that can need them
 	uint32_t* spill;
 	size_t spill_entries;
+	// light shafts (light_shafts.h): one word per shading workgroup and light, 1 = no ray of that patch toward that
+	// light can be blocked; allocated when the feature first runs
+	uint32_t* shaft_clear;
+	size_t shaft_words;
 };
 
 static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->codes); (void) hipFree(w->terms_visible); (void) hipFree(w->terms_hidden);
 	(void) hipFree(w->base_color); (void) hipFree(w->ray_directions); (void) hipFree(w->ray_records); (void) hipFree(w->ray_origins); (void) hipFree(w->ray_queue_size);
 	(void) hipFree(w->spill);
+	(void) hipFree(w->shaft_clear);
 	memset(w, 0, sizeof(*w));
 }
 
@@ -182,7 +188,8 @@ struct frame_pipeline {
 	// (default 36864 - config 4 then runs as three bands of 12 GB, the fastest of 1 ... 12 bands, profiles/r04c/: a
 	// frame whose worst case needs more is rendered in bands); VKR_BAND_COUNT forces
 	// the number of bands per frame (0: automatic)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count;
+	// VKR_LIGHT_SHAFTS: 0 turns the shaft test off (every shadow ray is traced, as until round 3); default 1
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -221,6 +228,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 		return NULL;
 	}
 	frames->wide_stack_lds = environment_knob("VKR_WIDE_STACK_LDS", kWideStackLds, 4u, kWideStackLds);
+	frames->light_shafts = environment_knob("VKR_LIGHT_SHAFTS", 1u, 0u, 1u);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
@@ -253,6 +261,18 @@ static uint32_t ray_block_size(uint32_t max_terms) {
 		slots = (value >= 64 && value <= 8192 && value % 64 == 0) ? (uint32_t) value : 256u;
 	}
 	return max_terms >= 8 ? slots : 0u;
+}
+
+static int ensure_shaft_words(wavefront_buffers* w, size_t words) {
+	if (words <= w->shaft_words) return 0;
+	(void) hipFree(w->shaft_clear);
+	w->shaft_clear = NULL; w->shaft_words = 0;
+	if (hipMalloc(&w->shaft_clear, words * sizeof(uint32_t)) != hipSuccess) {
+		printf("Failed to allocate %.1f MiB for the light shafts.\n", words * 4.0 / 1048576.0);
+		return 1;
+	}
+	w->shaft_words = words;
+	return 0;
 }
 
 static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t in_lds, uint32_t trace_threads) {
@@ -895,6 +915,24 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			p.pixel_materials = (const float*) pass->pixel_materials;
 		}
 		if (timed && band == 0) (void) hipEventRecord(ring[3 * slot], stream);
+		// light shafts: which patches need no shadow rays toward which lights (light_shafts.h).  For the techniques
+		// whose samples aim at the light polygon itself (every ray then lies inside the shaft); the walk uses the
+		// four-wide tree whatever tree the rays walk.
+		p.shaft_clear = NULL;
+		if (frame && frames->light_shafts && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
+			&& (technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueSolidAngle || technique == kTechniqueClippedSolidAngle))
+		{
+			const acceleration_structure_t* structure = &app->scene.acceleration_structure;
+			uint32_t shaft_groups = shade_grid_size(p.block_count);
+			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count)) return 1;
+			float extent = 0.0f;
+			for (int j = 0; j != 3; ++j) extent = fmaxf(extent, kGridMax / structure->grid_inverse_cell[j]);
+			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, extent);
+			if (hip_failed(hipGetLastError(), "launching the light shaft kernel")) return 1;
+			p.shaft_clear = frame->buffers.shaft_clear;
+			pass->last_shaft_groups = shaft_groups;
+		}
+		else pass->last_shaft_groups = 0;
 		status = error_mode != kErrorNone
 			? g_error_launchers[pass->arithmetic_mode](strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, p.block_count, stream)
 			: g_launchers[pass->arithmetic_mode + (p.light_texture_descriptors ? 3 : 0)][strategy](technique, capacity, ray_mode, &p, p.block_count, stream);
@@ -1296,6 +1334,36 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 	else k_traversal_statistics<<<dim3(16, kRayQueueCount), 256, 0, stream>>>(bvh, rays, counters);
 	int failed = vkr_copy_to_host(out_statistics, counters, sizeof(uint64_t) * 12, &app->device);
 	(void) hipFree(counters);
+	return failed;
+}
+
+// sums the words of the most recent launch's shaft table
+__global__ void __launch_bounds__(256) k_count_clear_shafts(const uint32_t* words, size_t count, unsigned long long* out) {
+	unsigned long long mine = 0;
+	for (size_t i = (size_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (size_t) gridDim.x * 256u) mine += words[i] ? 1u : 0u;
+	if (mine) atomicAdd(out, mine);
+}
+
+extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[4]) {
+	memset(out_statistics, 0, sizeof(uint64_t) * 4);
+	const shading_pass_t* pass = &app->shading_pass;
+	const frame_pipeline* frames = (const frame_pipeline*) pass->wavefront;
+	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
+	if (!w || !pass->last_shaft_groups || !w->shaft_clear) return 0;  // the last frame ran without the shaft test: all zero
+	if (finish_frames(app)) return 1;
+	size_t words = (size_t) pass->last_shaft_groups * app->scene_specification.polygonal_light_count;
+	unsigned long long* counter = NULL;
+	if (hip_failed(hipMalloc(&counter, sizeof(unsigned long long)), "allocating a counter")) return 1;
+	hipStream_t stream = (hipStream_t) app->device.stream;
+	(void) hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
+	k_count_clear_shafts<<<256, 256, 0, stream>>>(w->shaft_clear, words, counter);
+	unsigned long long clear = 0;
+	int failed = vkr_copy_to_host(&clear, counter, sizeof(clear), &app->device);
+	(void) hipFree(counter);
+	out_statistics[0] = words;
+	out_statistics[1] = clear;
+	out_statistics[2] = pass->last_shaft_groups;
+	out_statistics[3] = app->scene_specification.polygonal_light_count;
 	return failed;
 }
 

@@ -332,6 +332,13 @@ class Renderer(HostScene):
                 del stats[key]
         return stats
 
+    def light_shaft_statistics(self):
+        """(patch, light) pairs of the last launch and how many of them needed no shadow rays (csrc/light_shafts.h)"""
+        out = (C.c_uint64 * 4)()
+        if self.lib.get_light_shaft_statistics(C.byref(self.app), out):
+            raise RuntimeError("get_light_shaft_statistics failed")
+        return {"pairs": int(out[0]), "clear_pairs": int(out[1]), "patches": int(out[2]), "lights": int(out[3])}
+
     # -- multi-GPU exchange (include/vkr_slab_exchange.h) ---------------------------------
     def exchange_id(self):
         """The rendezvous token of a new communicator as 128 bytes (call on one rank, broadcast)."""
