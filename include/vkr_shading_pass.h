@@ -387,8 +387,17 @@ VKR_API uint64_t get_last_ray_count(const application_t* app);
 	groups of 64 rays of the longest ray's visits), longest ray's visits}.  0 on success. */
 VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]);
 /*! Light shafts of the most recent launch: {(patch, light) pairs tested, pairs found clear - no shadow ray queued
-	for them -, patches, lights}; all zero when the launch ran without the shaft test.  0 on success. */
-VKR_API int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[4]);
+	for them -, patches, lights, then the pairs that are not clear by reason: patch without a shaded pixel, light and
+	patch do not form a shaft (light behind the patch, seen edge-on, too close), walk too long, queue full, a triangle
+	in the way, other}; all zero when the launch ran without the shaft test.  0 on success. */
+VKR_API int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[10]);
+/*! (diagnostics) The verdicts themselves, one word per patch and light ([patch][light]; patches in the order of the
+	shading workgroups): the low byte is 1 = clear or 16 ... 20 = the reasons above; with 20 (a triangle in the way) bits
+	8 ... 31 name one such triangle (its index in the mesh, if below 2^24).  Returns the number of words written. */
+VKR_API uint64_t read_back_light_shafts(application_t* app, uint32_t* out_words, uint64_t capacity);
+/*! (diagnostics, only with VKR_SHAFT_COUNTERS=1 in the environment) work of the shaft kernel of the most recent
+	launch: {steps of its walks (16 nodes each), batches of triangles, walks}.  0 on success. */
+VKR_API int get_light_shaft_work(application_t* app, uint64_t out_work[3]);
 /*! The same for the tree of the caller's choice - the binary one (one box per visit) or the
 	four-wide one (a visit fetches one node and tests up to four boxes) - whatever the frame itself
 	walked, plus (wide tree only) [6] boxes tested, [7] the deepest stack a ray reached, [8] rays whose stack

@@ -90,7 +90,18 @@ def main():
                 merged.setdefault(k, {}).update(v)
             meta.update(m)
         for kernel, c in merged.items():
-            lines += ["PMC, per dispatch of `%s` (%s):" % (kernel[:70], ", ".join("%s=%s" % kv for kv in meta.get(kernel, {}).items() if kv[1] is not None)), ""]
+            # rocprofv3 reports VGPR_Count in allocation units of two registers on gfx950 (84 = the 168 registers that
+            # profiles/tools/kernel_resources.sh reads from the code object) and LDS_Block_Size without the dynamic
+            # part (the polygon tables of shade_pixels, 11.3 KB per wave at V = 5, are dynamic LDS)
+            labels = {"VGPR_Count": "VGPR_Count [units of 2 registers]", "LDS_Block_Size": "LDS_Block_Size [static part only, bytes]"}
+            shown = []
+            for key, value in meta.get(kernel, {}).items():
+                if value is None:
+                    continue
+                shown.append("%s=%s" % (labels.get(key, key), value))
+                if key == "VGPR_Count" and str(value).isdigit():
+                    shown.append("registers=%d" % (2 * int(value)))
+            lines += ["PMC, per dispatch of `%s` (%s):" % (kernel[:70], ", ".join(shown)), ""]
             lines += ["| counter | value |", "|---|---|"]
             for name in sorted(c):
                 lines.append("| %s | %.5g |" % (name, c[name]))

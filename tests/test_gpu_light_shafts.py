@@ -40,9 +40,11 @@ def test_benchmark_scene_same_frame_fewer_rays(big_dataset, monkeypatch, config,
     print(config, stats, rays_on, rays_off)
     assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), int((on != off).any(axis=-1).sum())
     assert stats_off["pairs"] == 0 and stats["pairs"] > 0
-    # an open scene: most patches see most lights freely
-    assert stats["clear_pairs"] > 0.3 * stats["pairs"], stats
-    assert 0 < rays_on < 0.7 * rays_off, (rays_on, rays_off)
+    # an open scene: a good part of the patches see a good part of the lights freely (40 % of the patches are sky,
+    # a quarter of the rest faces away from a given light)
+    assert stats["clear_pairs"] > 0.15 * stats["pairs"], stats
+    assert stats["clear_pairs"] + sum(stats["not_clear"].values()) == stats["pairs"]
+    assert 0 < rays_on < 0.8 * rays_off, (rays_on, rays_off)
 
 
 def test_large_scene_same_frame(monkeypatch, tmp_path):

@@ -598,7 +598,10 @@ __device__ __forceinline__ float quantized_half_area(uint4 n) {
 
 // One thread per wide node of this level.  counters: [0] items of the next level, [1] wide nodes
 // allocated so far, [2] deepest stack a ray can need.
-__global__ void __launch_bounds__(64) k_collapse_level(const uint4* binary, const wide_item* items, uint32_t item_count, wide_item* next_items, uint32_t* counters, uint4* wide) {
+// order_children: the children of a node are stored largest box first.  trace_shadow_rays_wide takes child 0 off its
+// stack first, and a shadow ray is done with the first triangle it hits: the child that covers the most space is
+// the one most likely to hold a blocker (any-hit results do not depend on the order, only the work of blocked rays).
+__global__ void __launch_bounds__(64) k_collapse_level(const uint4* binary, const wide_item* items, uint32_t item_count, wide_item* next_items, uint32_t* counters, uint4* wide, uint32_t order_children) {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= item_count) return;
 	wide_item item = items[i];
@@ -625,6 +628,20 @@ __global__ void __launch_bounds__(64) k_collapse_level(const uint4* binary, cons
 		position[widest] = left; node[widest] = left_node;
 		position[count] = right; node[count] = binary[right];
 		++count;
+	}
+	if (order_children) {
+		// insertion sort of at most four children by the area of their boxes, descending
+		for (uint32_t c = 1; c < count; ++c) {
+			uint4 moved = node[c];
+			uint32_t moved_position = position[c];
+			float area = quantized_half_area(moved);
+			uint32_t slot = c;
+			while (slot > 0 && quantized_half_area(node[slot - 1]) < area) {
+				node[slot] = node[slot - 1]; position[slot] = position[slot - 1];
+				--slot;
+			}
+			node[slot] = moved; position[slot] = moved_position;
+		}
 	}
 	uint32_t inner = 0;
 	for (uint32_t c = 0; c != count; ++c) inner += (node[c].w & kLeafBit) ? 0u : 1u;
@@ -711,6 +728,9 @@ static int collapse_to_wide(acceleration_structure_t* structure, const device_t*
 	uint32_t triangle_count = (structure->node_count + 1) / 2;
 	if (triangle_count < 2) return 0;
 	hipStream_t stream = (hipStream_t) device->stream;
+	// VKR_WIDE_CHILD_ORDER=0: children in the order of the binary tree (until round 3); default: largest box first
+	const char* order_knob = getenv("VKR_WIDE_CHILD_ORDER");
+	const uint32_t order_children = (order_knob && order_knob[0] == '0') ? 0u : 1u;
 	wide_item* items[2] = {NULL, NULL};
 	uint32_t* counters = NULL;
 	uint8_t* arena = NULL;
@@ -730,7 +750,7 @@ static int collapse_to_wide(acceleration_structure_t* structure, const device_t*
 		uint32_t item_count = 1, level = 0;
 		bool ok = true;
 		while (item_count && ok) {
-			k_collapse_level<<<(item_count + 63) / 64, 64, 0, stream>>>((const uint4*) structure->nodes, items[level & 1], item_count, items[(level + 1) & 1], counters, wide);
+			k_collapse_level<<<(item_count + 63) / 64, 64, 0, stream>>>((const uint4*) structure->nodes, items[level & 1], item_count, items[(level + 1) & 1], counters, wide, order_children);
 			k_publish_counters<<<1, 64, 0, stream>>>(counters, 3u, host_words);
 			ok = hipStreamSynchronize(stream) == hipSuccess && ++level < 4096;
 			for (int i = 0; i != 3; ++i) host_counters[i] = ((volatile uint32_t*) host_words)[i];

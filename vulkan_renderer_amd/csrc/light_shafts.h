@@ -13,12 +13,14 @@
 // with and without).  What it buys depends on the scene: 83 % of the lit (patch, light) pairs of the benchmark
 // scene at config 3 are clear, 7 % of the large scene's (profiles/).
 //
-// Conservative by construction.  With c, rho the centre and radius (plus margin) of the patch's shading
-// positions, L'_i the light's vertices moved away from their centroid by 1/32 (sampled directions may leave the
-// polygon by rounding), n_L the light's plane:
-//   side plane k     through c, L'_k, L'_k+1, pushed outwards by rho      contains the sphere and the polygon
-//   far cap          n_L . x <= n_L . L_0 + margin                          rays end on the light's plane
-//   near cap         a . x >= a . c - rho, a towards the centroid         only if every L'_i lies in front of it
+// Conservative by construction.  With B the bounding box of the patch's shading positions (plus margin), c its
+// centre, support(n) = |n.x| h.x + |n.y| h.y + |n.z| h.z the reach of B along n, L'_i the light's vertices moved
+// away from their centroid by 1/32 (sampled directions may leave the polygon by rounding), n_L the light's plane:
+//   side plane k     through c, L'_k, L'_k+1, pushed outwards by support(n)   contains the box and the polygon
+//   far cap          n_L . x <= n_L . L_0 + margin                              rays end on the light's plane
+//   near cap         a . x >= a . c - support(a), a towards the centroid      only if every L'_i lies in front of it
+// (A box, not a sphere: a patch on a floor seen at a grazing angle is long and flat, and a sphere around it would
+// make the shaft swallow a strip of the floor as wide as the patch is long.)
 // Their intersection contains every ray of the patch toward the light.  A box is skipped when it lies outside
 // one plane (or outside the bounding box of sphere and polygon); a triangle is harmless when
 //   (i)  its three vertices lie outside one of those planes, or
@@ -32,11 +34,19 @@
 namespace vkr {
 
 constexpr uint32_t kShaftMaxVertices = 8;                     // light polygons with more vertices are never clear
-constexpr uint32_t kShaftMaxPlanes = kShaftMaxVertices + 2;   // sides, far cap, near cap
-constexpr uint32_t kShaftFrontier = 320;                      // inner nodes waiting (LDS); more -> not clear
-constexpr uint32_t kShaftLeaves = 192;                        // triangles waiting
-constexpr uint32_t kShaftMaxSteps = 48;                       // steps of 16 nodes; more -> not clear
+constexpr uint32_t kShaftMaxPlanes = kShaftMaxVertices + 3;   // sides, far cap, near cap, the patch's own plane
+constexpr uint32_t kShaftLights = 8;                          // lights whose shafts are walked together
+constexpr uint32_t kShaftLightShift = 27;                     // an entry of the queues: node or triangle | light << 27
+constexpr uint32_t kShaftFrontier = 640;                      // inner nodes waiting (LDS); more -> not clear
+constexpr uint32_t kShaftLeaves = 320;                        // triangles waiting
+constexpr uint32_t kShaftMaxSteps = 40;                       // steps of 16 nodes (plus 8 per light); more -> not clear
 constexpr float kShaftDilation = 1.0f / 32.0f;
+// Measured and not adopted (profiles/r05h/): cutting every candidate triangle by all planes of the shaft (test (iii) below)
+// finds 7 % more clear pairs at config 3 (25.0 instead of 23.3 % of all pairs) but costs the kernel 17 registers and 300
+// bytes of scratch per lane: 1.459 instead of 1.414 ms per frame.
+#ifndef VKR_SHAFT_CLIPPING
+#define VKR_SHAFT_CLIPPING 0
+#endif
 
 // what the walk needs to know about one (patch, light), wave-uniform, in LDS
 struct shaft_state {
@@ -48,14 +58,17 @@ struct shaft_state {
 	// (h - g) / reach for an origin at height g
 	float reach;                        // largest distance from an origin to a light vertex
 	// flat patches: how far above the patch's own plane the first point of every ray lies at least (the light on one
-	// side of that plane, else negative), measured along the plane's normal
-	float flat_first;
+	// side of that plane, else negative), measured along the plane's normal towards the light (flat_sign x the normal)
+	float flat_first, flat_sign;
 };
+
+// why a pair is not clear (the word that the shading kernel reads is 1 for clear pairs and one of these otherwise)
+enum { kShaftClear = 1, kShaftNoPixels = 16, kShaftGeometry = 17, kShaftTooLong = 18, kShaftQueueFull = 19, kShaftTriangle = 20 };
 
 struct shaft_patch {
 	float origin[64][3];
 	uint64_t valid;                     // lanes with a shading position
-	float centre[3], radius;
+	float centre[3], half[3], radius;   // bounding box of the positions (with margin), length of its half diagonal
 	// the patch's own plane if all its positions lie on one (within flat_tolerance): n unit, n . x = d
 	float flat_normal[3], flat_d;
 	uint32_t flat;
@@ -95,14 +108,49 @@ VKR_DEV bool shaft_triangle_harmless(const shaft_state& s, const shaft_patch& pa
 		float da = fmaf(nx, a.x, fmaf(ny, a.y, nz * a.z)), db = fmaf(nx, b.x, fmaf(ny, b.y, nz * b.z)), dc = fmaf(nx, c.x, fmaf(ny, c.y, nz * c.z));
 		if (fminf(da, fminf(db, dc)) > d) return true;
 	}
-	// (ii) for a flat patch and a triangle in the patch's own plane (the surface the patch lies on - the common case):
-	// the triangle stays within `margin` of that plane, the rays' first points lie higher
+	// (ii) for a flat patch with the light on one side of its plane: every ray starts on that plane (within `margin`),
+	// its first point lies flat_first above it and it climbs from there - a triangle that stays on or below the plane
+	// (the surface the patch lies on, the other faces of the same box, the floor under it) cannot be reached
 	if (patch.flat && s.flat_first > 3.0f * margin) {
-		float ha = fabsf(patch.flat_normal[0] * a.x + patch.flat_normal[1] * a.y + patch.flat_normal[2] * a.z - patch.flat_d);
-		float hb = fabsf(patch.flat_normal[0] * b.x + patch.flat_normal[1] * b.y + patch.flat_normal[2] * b.z - patch.flat_d);
-		float hc = fabsf(patch.flat_normal[0] * c.x + patch.flat_normal[1] * c.y + patch.flat_normal[2] * c.z - patch.flat_d);
+		float ha = s.flat_sign * (patch.flat_normal[0] * a.x + patch.flat_normal[1] * a.y + patch.flat_normal[2] * a.z - patch.flat_d);
+		float hb = s.flat_sign * (patch.flat_normal[0] * b.x + patch.flat_normal[1] * b.y + patch.flat_normal[2] * b.z - patch.flat_d);
+		float hc = s.flat_sign * (patch.flat_normal[0] * c.x + patch.flat_normal[1] * c.y + patch.flat_normal[2] * c.z - patch.flat_d);
 		if (fmaxf(ha, fmaxf(hb, hc)) <= margin) return true;
 	}
+#if VKR_SHAFT_CLIPPING
+	// (iii) what is left of the triangle inside ALL planes at once: nothing?  (A large triangle next to the narrow end
+	// of the shaft - the top of a box beside a patch on the floor - lies outside the shaft without lying outside any one
+	// of its planes.)  The triangle is cut by one plane after the other; planes are moved outwards by `margin` first.
+	{
+		constexpr int kMost = 12;
+		float x[2][kMost], y[2][kMost], z[2][kMost];
+		x[0][0] = a.x; y[0][0] = a.y; z[0][0] = a.z;
+		x[0][1] = b.x; y[0][1] = b.y; z[0][1] = b.z;
+		x[0][2] = c.x; y[0][2] = c.y; z[0][2] = c.z;
+		int count = 3, from = 0;
+		for (uint32_t k = 0; k != s.plane_count && count != 0 && count <= kMost - 2; ++k) {
+			float nx = s.plane[k][0], ny = s.plane[k][1], nz = s.plane[k][2], d = s.plane[k][3] + margin;
+			int to = from ^ 1, kept = 0;
+			float previous_x = x[from][count - 1], previous_y = y[from][count - 1], previous_z = z[from][count - 1];
+			float previous_distance = fmaf(nx, previous_x, fmaf(ny, previous_y, nz * previous_z)) - d;
+			for (int i = 0; i != count; ++i) {
+				float cx = x[from][i], cy = y[from][i], cz = z[from][i];
+				float distance = fmaf(nx, cx, fmaf(ny, cy, nz * cz)) - d;
+				if ((distance <= 0.0f) != (previous_distance <= 0.0f)) {
+					// the edge crosses the plane
+					float t = previous_distance / (previous_distance - distance);
+					x[to][kept] = fmaf(t, cx - previous_x, previous_x); y[to][kept] = fmaf(t, cy - previous_y, previous_y); z[to][kept] = fmaf(t, cz - previous_z, previous_z);
+					++kept;
+				}
+				if (distance <= 0.0f) { x[to][kept] = cx; y[to][kept] = cy; z[to][kept] = cz; ++kept; }
+				previous_x = cx; previous_y = cy; previous_z = cz; previous_distance = distance;
+			}
+			count = kept;
+			from = to;
+		}
+		if (count == 0) return true;
+	}
+#endif
 	// (ii) in general: the triangle's own plane separates it from the rays - the light's vertices and the first
 	// points of all rays on one side
 	f3 n = cross(b - a, c - a);
@@ -135,11 +183,13 @@ VKR_DEV bool shaft_triangle_harmless(const shaft_state& s, const shaft_patch& pa
 
 // `b` numbers the workgroups like shade_pixels does (one 8x8 patch each); out_clear[b * light_count + i] = 1 when no
 // ray of that patch toward light i can be blocked.  extent: largest coordinate difference of the scene (margins).
-__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float extent) {
+// work_counters (diagnostics, may be NULL): [0] steps of the walks, [1] batches of triangles, [2] walks
+__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float extent, unsigned long long* work_counters) {
 	__shared__ shaft_patch patch;
-	__shared__ shaft_state s;
+	__shared__ shaft_state shafts[kShaftLights];
 	__shared__ uint32_t frontier[kShaftFrontier];
 	__shared__ uint32_t leaves[kShaftLeaves];
+	__shared__ uint32_t failed_lights, failed_triangle[kShaftLights];
 	const uint32_t lane = threadIdx.x;
 	const uint32_t b = blockIdx.x;
 	const uint32_t local_block = ((b >> 5) << 3) | (b & 7u);
@@ -152,11 +202,14 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 	uint32_t* clear = out_clear + (size_t) b * p.light_count;
 	const uint64_t valid = __ballot(shaded);
 	if (valid == 0) {
-		for (uint32_t i = lane; i < p.light_count; i += 64u) clear[i] = 0u;
+		for (uint32_t i = lane; i < p.light_count; i += 64u) clear[i] = kShaftNoPixels;
 		return;
 	}
 	// ---- the patch: shading positions as the shading kernel computes them (get_shading_data) ---------------
-	const float margin = 2.0e-6f * extent;
+	// What the tests below allow for: shading positions and triangle vertices are a few units in the last place of the
+	// scene's coordinates off the planes they lie on, and so is what the tracing kernels compute with them - 5e-7 of
+	// the extent is ten units in the last place of the largest coordinate.
+	const float margin = 5.0e-7f * extent;
 	f3 position = mk3(0.0f, 0.0f, 0.0f), face_normal = position;
 	float face_d = 0.0f;
 	if (shaded) {
@@ -178,7 +231,8 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 	f3 hi = mk3(wave_max(shaded ? position.x : -big), wave_max(shaded ? position.y : -big), wave_max(shaded ? position.z : -big));
 	f3 centre = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
 	f3 diagonal = hi - lo;
-	float radius = 0.5f * __builtin_sqrtf(dot(diagonal, diagonal)) * 1.0001f + 2.0f * margin;
+	const f3 half = mk3(0.5f * diagonal.x * 1.0001f + 2.0f * margin, 0.5f * diagonal.y * 1.0001f + 2.0f * margin, 0.5f * diagonal.z * 1.0001f + 2.0f * margin);
+	float radius = __builtin_sqrtf(dot(half, half)) * 1.0001f;
 	// is the patch flat?  the plane of the first valid lane's triangle, and every position on it
 	const int first_lane = __builtin_ctzll(valid);
 	f3 plane_n = mk3(__shfl(face_normal.x, first_lane), __shfl(face_normal.y, first_lane), __shfl(face_normal.z, first_lane));
@@ -187,6 +241,7 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 	if (lane == 0) {
 		patch.valid = valid;
 		patch.centre[0] = centre.x; patch.centre[1] = centre.y; patch.centre[2] = centre.z;
+		patch.half[0] = half.x; patch.half[1] = half.y; patch.half[2] = half.z;
 		patch.radius = radius;
 		patch.flat_normal[0] = plane_n.x; patch.flat_normal[1] = plane_n.y; patch.flat_normal[2] = plane_n.z;
 		patch.flat_d = plane_d;
@@ -195,100 +250,135 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 	__syncthreads();
 	const f3 grid_origin = p.bvh.grid_origin;
 	const f3 cell = mk3(1.0f / p.bvh.grid_inverse_cell.x, 1.0f / p.bvh.grid_inverse_cell.y, 1.0f / p.bvh.grid_inverse_cell.z);
-	for (uint32_t light_index = 0; light_index != p.light_count; ++light_index) {
-		light_ref light = get_light(p, light_index);
-		const uint32_t vertex_count = light_vertex_count(light);
-		// ---- the shaft of this light (lanes build one plane each) ---------------------------------------------
-		bool possible = vertex_count >= 3u && vertex_count <= kShaftMaxVertices;
-		// every position on the same side of the light's plane, away from it
-		float side = shaded ? plane_distance(light, position) : 0.0f;
-		float side_min = wave_min(shaded ? side : big), side_max = wave_max(shaded ? side : -big);
-		possible = possible && (side_min > 8.0f * margin || side_max < -8.0f * margin);
-		__syncthreads();  // (the previous light's walk is over: the shared state may change)
-		if (possible) {
-			f3 centroid = mk3(0.0f, 0.0f, 0.0f);
-			for (uint32_t i = 0; i != vertex_count; ++i) centroid = centroid + light_vertex(light, i);
-			centroid = centroid * (1.0f / (float) vertex_count);
-			// dilated vertex of this lane (lanes beyond the polygon repeat vertices; unused)
-			uint32_t k = lane % vertex_count, k1 = (k + 1u) % vertex_count;
-			f3 v0 = light_vertex(light, k), v1 = light_vertex(light, k1);
-			float grow = 1.0f + kShaftDilation;
-			f3 pad_direction = v0 - centroid;
-			v0 = centroid + (v0 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
-			pad_direction = v1 - centroid;
-			v1 = centroid + (v1 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
-			f3 axis = centroid - centre;
-			float axis_length = __builtin_sqrtf(dot(axis, axis));
-			axis = axis * (1.0f / fmaxf(axis_length, 1.0e-30f));
-			float along = dot(v0 - centre, axis);
-			float reach = __builtin_sqrtf(dot(v0 - centre, v0 - centre));
-			float along_min = wave_min(lane < vertex_count ? along : big);
-			float reach_max = wave_max(lane < vertex_count ? reach : 0.0f);
-			// heights of the light above the patch's own plane (flat patches)
-			float above = dot(plane_n, v0) - plane_d;
-			float above_min = wave_min(lane < vertex_count ? above : big), above_max = wave_max(lane < vertex_count ? above : -big);
-			if (above_max < 0.0f) { float t = above_min; above_min = -above_max; above_max = -t; }
-			// side plane k: through the centre and the edge, the rest of the light behind it
-			f3 n = cross(v0 - centre, v1 - centre);
-			float n_length_squared = dot(n, n);
-			bool degenerate = !(n_length_squared > 1.0e-30f);
-			n = n * __builtin_amdgcn_rsqf(fmaxf(n_length_squared, 1.0e-30f));
-			if (dot(n, centroid - centre) > 0.0f) n = -n;
-			// (a polygon seen edge-on or a centre inside it leaves no pyramid: every plane must keep the centroid well inside)
-			bool bad = lane < vertex_count && (degenerate || !(dot(n, centroid - centre) < -1.0e-3f * axis_length));
-			possible = __ballot(bad) == 0 && axis_length > 4.0f * radius;
-			if (lane < vertex_count) {
-				s.plane[lane][0] = n.x; s.plane[lane][1] = n.y; s.plane[lane][2] = n.z;
-				s.plane[lane][3] = dot(n, centre) + radius;
-				s.light[lane][0] = v0.x; s.light[lane][1] = v0.y; s.light[lane][2] = v0.z;
-			}
-			if (lane == 0) {
-				// far cap: nothing behind the light's plane matters
-				f3 nl = plane_normal(light);
-				float nl_length = __builtin_sqrtf(dot(nl, nl));
-				float sign = (side_min > 0.0f) ? -1.0f : 1.0f;  // positions on the positive side: the far side is the negative one
-				f3 far_n = nl * (sign / fmaxf(nl_length, 1.0e-30f));
-				float light_offset = dot(far_n, light_vertex(light, 0));
-				s.plane[vertex_count][0] = far_n.x; s.plane[vertex_count][1] = far_n.y; s.plane[vertex_count][2] = far_n.z;
-				s.plane[vertex_count][3] = light_offset + 8.0f * margin;
-				uint32_t planes = vertex_count + 1u;
-				// near cap: only if the whole light lies in front of it
-				if (along_min > 0.0f) {
-					s.plane[planes][0] = -axis.x; s.plane[planes][1] = -axis.y; s.plane[planes][2] = -axis.z;
-					s.plane[planes][3] = -(dot(axis, centre) - radius);
-					++planes;
+	// The lights are walked TOGETHER, kShaftLights at a time: a step of the walk is one round trip to memory (the
+	// nodes), and a shaft through open space needs about one step per level of the tree - walked one after the
+	// other, a patch with four lights spent forty round trips where ten do (profiles/r05f/).  An entry of the frontier
+	// is a node and the light whose shaft reached it.
+	for (uint32_t chunk = 0; chunk < p.light_count; chunk += kShaftLights) {
+		const uint32_t chunk_lights = min(kShaftLights, p.light_count - chunk);
+		uint32_t alive = 0;  // lights of the chunk whose shafts are still being walked (bit k: light chunk + k)
+		__syncthreads();    // (the previous chunk's walk is over: the shared state may change)
+		for (uint32_t k = 0; k != chunk_lights; ++k) {
+			shaft_state& s = shafts[k];
+			light_ref light = get_light(p, chunk + k);
+			const uint32_t vertex_count = light_vertex_count(light);
+			// ---- the shaft of this light (lanes build one plane each) -------------------------------------------
+			bool possible = vertex_count >= 3u && vertex_count <= kShaftMaxVertices;
+			// every position on the same side of the light's plane, away from it
+			float side = shaded ? plane_distance(light, position) : 0.0f;
+			float side_min = wave_min(shaded ? side : big), side_max = wave_max(shaded ? side : -big);
+			possible = possible && (side_min > 8.0f * margin || side_max < -8.0f * margin);
+			if (possible) {
+				f3 centroid = mk3(0.0f, 0.0f, 0.0f);
+				for (uint32_t i = 0; i != vertex_count; ++i) centroid = centroid + light_vertex(light, i);
+				centroid = centroid * (1.0f / (float) vertex_count);
+				// dilated vertex of this lane (lanes beyond the polygon repeat vertices; unused)
+				uint32_t v = lane % vertex_count, v_next = (v + 1u) % vertex_count;
+				f3 v0 = light_vertex(light, v), v1 = light_vertex(light, v_next);
+				float grow = 1.0f + kShaftDilation;
+				f3 pad_direction = v0 - centroid;
+				v0 = centroid + (v0 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
+				pad_direction = v1 - centroid;
+				v1 = centroid + (v1 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
+				f3 axis = centroid - centre;
+				float axis_length = __builtin_sqrtf(dot(axis, axis));
+				axis = axis * (1.0f / fmaxf(axis_length, 1.0e-30f));
+				float along = dot(v0 - centre, axis);
+				float reach = __builtin_sqrtf(dot(v0 - centre, v0 - centre));
+				float along_min = wave_min(lane < vertex_count ? along : big);
+				float reach_max = wave_max(lane < vertex_count ? reach : 0.0f);
+				// heights of the light above the patch's own plane (flat patches)
+				float above = dot(plane_n, v0) - plane_d;
+				float above_min = wave_min(lane < vertex_count ? above : big), above_max = wave_max(lane < vertex_count ? above : -big);
+				float above_sign = 1.0f;
+				// (a flat patch is seen from the front of its plane: a light that lies behind that plane altogether sends it no
+				// light - whatever rays rounding or a bent shading normal may still produce are traced as before, without a walk)
+				const bool light_behind_patch = (off_plane <= margin) && above_max <= margin;
+				if (above_max < 0.0f) { float t = above_min; above_min = -above_max; above_max = -t; above_sign = -1.0f; }
+				// side plane v: through the centre and the edge, the rest of the light behind it
+				f3 n = cross(v0 - centre, v1 - centre);
+				float n_length_squared = dot(n, n);
+				bool degenerate = !(n_length_squared > 1.0e-30f);
+				n = n * __builtin_amdgcn_rsqf(fmaxf(n_length_squared, 1.0e-30f));
+				if (dot(n, centroid - centre) > 0.0f) n = -n;
+				// (a polygon seen edge-on or a centre inside it leaves no pyramid: every plane must keep the centroid well inside)
+				bool bad = lane < vertex_count && (degenerate || !(dot(n, centroid - centre) < -1.0e-3f * axis_length));
+				possible = __ballot(bad) == 0 && axis_length > 4.0f * radius && !light_behind_patch;
+				if (lane < vertex_count) {
+					s.plane[lane][0] = n.x; s.plane[lane][1] = n.y; s.plane[lane][2] = n.z;
+					s.plane[lane][3] = dot(n, centre) + (fabsf(n.x) * half.x + fabsf(n.y) * half.y + fabsf(n.z) * half.z);
+					s.light[lane][0] = v0.x; s.light[lane][1] = v0.y; s.light[lane][2] = v0.z;
 				}
-				s.plane_count = planes;
-				s.vertex_count = vertex_count;
-				s.reach = reach_max + radius;
-				// (positions within `margin` of the plane; a ray toward a point `h` above it climbs at least (h - margin) / reach)
-				s.flat_first = above_min > 2.0f * margin ? -margin + 1.0e-3f * (above_min - margin) / s.reach : -1.0f;
+				// bounding box of patch and polygon
+				f3 box_lo = mk3(wave_min(lane < vertex_count ? v0.x : big), wave_min(lane < vertex_count ? v0.y : big), wave_min(lane < vertex_count ? v0.z : big));
+				f3 box_hi = mk3(wave_max(lane < vertex_count ? v0.x : -big), wave_max(lane < vertex_count ? v0.y : -big), wave_max(lane < vertex_count ? v0.z : -big));
+				if (lane == 0) {
+					// far cap: nothing behind the light's plane matters
+					f3 nl = plane_normal(light);
+					float nl_length = __builtin_sqrtf(dot(nl, nl));
+					float sign = (side_min > 0.0f) ? -1.0f : 1.0f;  // positions on the positive side: the far side is the negative one
+					f3 far_n = nl * (sign / fmaxf(nl_length, 1.0e-30f));
+					float light_offset = dot(far_n, light_vertex(light, 0));
+					s.plane[vertex_count][0] = far_n.x; s.plane[vertex_count][1] = far_n.y; s.plane[vertex_count][2] = far_n.z;
+					s.plane[vertex_count][3] = light_offset + 8.0f * margin;
+					uint32_t planes = vertex_count + 1u;
+					// near cap: only if the whole light lies in front of it
+					if (along_min > 0.0f) {
+						s.plane[planes][0] = -axis.x; s.plane[planes][1] = -axis.y; s.plane[planes][2] = -axis.z;
+						s.plane[planes][3] = -(dot(axis, centre) - (fabsf(axis.x) * half.x + fabsf(axis.y) * half.y + fabsf(axis.z) * half.z));
+						++planes;
+					}
+					s.vertex_count = vertex_count;
+					s.reach = reach_max + radius;
+					// (positions within `margin` of the plane; a ray toward a point `h` above it climbs at least (h - margin) / reach)
+					const bool flat = off_plane <= margin && dot(plane_n, plane_n) > 0.5f;
+					s.flat_first = (flat && above_min > 2.0f * margin) ? -margin + 1.0e-3f * (above_min - margin) / s.reach : -1.0f;
+					s.flat_sign = above_sign;
+					// ... and nothing below the plane of a flat patch is inside the shaft (boxes: two margins of slack)
+					if (s.flat_first > 3.0f * margin) {
+						s.plane[planes][0] = -above_sign * plane_n.x; s.plane[planes][1] = -above_sign * plane_n.y; s.plane[planes][2] = -above_sign * plane_n.z;
+						s.plane[planes][3] = -above_sign * plane_d + 2.0f * margin;
+						++planes;
+					}
+					s.plane_count = planes;
+					s.box_lo[0] = fminf(box_lo.x, centre.x - half.x); s.box_lo[1] = fminf(box_lo.y, centre.y - half.y); s.box_lo[2] = fminf(box_lo.z, centre.z - half.z);
+					s.box_hi[0] = fmaxf(box_hi.x, centre.x + half.x); s.box_hi[1] = fmaxf(box_hi.y, centre.y + half.y); s.box_hi[2] = fmaxf(box_hi.z, centre.z + half.z);
+				}
 			}
-			// bounding box of sphere and polygon
-			f3 box_lo = mk3(wave_min(lane < vertex_count ? v0.x : big), wave_min(lane < vertex_count ? v0.y : big), wave_min(lane < vertex_count ? v0.z : big));
-			f3 box_hi = mk3(wave_max(lane < vertex_count ? v0.x : -big), wave_max(lane < vertex_count ? v0.y : -big), wave_max(lane < vertex_count ? v0.z : -big));
-			if (lane == 0) {
-				s.box_lo[0] = fminf(box_lo.x, centre.x - radius); s.box_lo[1] = fminf(box_lo.y, centre.y - radius); s.box_lo[2] = fminf(box_lo.z, centre.z - radius);
-				s.box_hi[0] = fmaxf(box_hi.x, centre.x + radius); s.box_hi[1] = fmaxf(box_hi.y, centre.y + radius); s.box_hi[2] = fmaxf(box_hi.z, centre.z + radius);
-			}
+			if (possible) alive |= 1u << k;
+			else if (lane == 0) clear[chunk + k] = kShaftGeometry;
 		}
+		uint32_t waiting = 0, leaf_count = 0, steps = 0, batches = 0;
+		const uint32_t walked = alive;
+		if (lane == 0) {
+			// every shaft starts at the root
+			uint32_t lights = alive;
+			while (lights) {
+				uint32_t k = (uint32_t) __builtin_ctz(lights);
+				lights &= lights - 1u;
+				frontier[waiting++] = k << kShaftLightShift;
+			}
+			failed_lights = 0u;
+		}
+		waiting = (uint32_t) __popc(alive);
 		__syncthreads();
 		// ---- the walk ----------------------------------------------------------------------------------------------
-		bool is_clear = possible;
-		if (possible) {
-			uint32_t waiting = 1, leaf_count = 0, steps = 0;
-			if (lane == 0) frontier[0] = 0u;
-			__syncthreads();
-			while (waiting != 0 || leaf_count != 0) {
-				if (++steps > kShaftMaxSteps) { is_clear = false; break; }
-				if (waiting != 0) {
-					// the last (up to) sixteen nodes of the frontier, four lanes each
-					uint32_t take = waiting < 16u ? waiting : 16u;
-					bool active = (lane >> 2) < take;
-					uint32_t link = kWideEmpty;
-					bool hit = false;
-					if (active) {
-						uint32_t node = frontier[waiting - take + (lane >> 2)];
+		const uint32_t step_limit = kShaftMaxSteps + 8u * waiting;
+		uint32_t too_long = 0, queue_full = 0;
+		while (alive != 0 && (waiting != 0 || leaf_count != 0)) {
+			if (++steps > step_limit) { too_long = alive; alive = 0; break; }
+			if (waiting != 0) {
+				// the last (up to) sixteen entries of the frontier, four lanes each
+				uint32_t take = waiting < 16u ? waiting : 16u;
+				bool active = (lane >> 2) < take;
+				uint32_t link = kWideEmpty, k = 0;
+				bool hit = false;
+				if (active) {
+					uint32_t entry = frontier[waiting - take + (lane >> 2)];
+					k = entry >> kShaftLightShift;
+					uint32_t node = entry & ((1u << kShaftLightShift) - 1u);
+					// (a light that has failed in the meantime: its entries are dropped as they come up)
+					if ((alive >> k) & 1u) {
 						const uint32_t* words = (const uint32_t*) (wide_nodes + 4 * (size_t) node);
 						uint32_t child = lane & 3u;
 						uint32_t qx = words[child], qy = words[4 + child], qz = words[8 + child];
@@ -298,37 +388,58 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 							f3 box_hi = mk3(fmaf((float) (qx >> 16), cell.x, grid_origin.x), fmaf((float) (qy >> 16), cell.y, grid_origin.y), fmaf((float) (qz >> 16), cell.z, grid_origin.z));
 							box_lo = box_lo - mk3(margin, margin, margin);
 							box_hi = box_hi + mk3(margin, margin, margin);
-							hit = shaft_box_inside(s, box_lo, box_hi);
+							hit = shaft_box_inside(shafts[k], box_lo, box_hi);
 						}
 					}
-					__syncthreads();  // (everyone has read its frontier entry before the entries are overwritten)
-					waiting -= take;
-					bool to_frontier = hit && !(link & kLeafBit), to_leaves = hit && (link & kLeafBit) != 0;
-					uint64_t inner_mask = __ballot(to_frontier), leaf_mask = __ballot(to_leaves);
-					uint32_t inner_new = (uint32_t) __popcll((unsigned long long) inner_mask), leaf_new = (uint32_t) __popcll((unsigned long long) leaf_mask);
-					if (waiting + inner_new > kShaftFrontier || leaf_count + leaf_new > kShaftLeaves) { is_clear = false; break; }
-					if (to_frontier) frontier[waiting + __builtin_amdgcn_mbcnt_hi((uint32_t) (inner_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) inner_mask, 0u))] = link;
-					if (to_leaves) leaves[leaf_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (leaf_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) leaf_mask, 0u))] = link & ~kLeafBit;
-					waiting += inner_new;
-					leaf_count += leaf_new;
-					__syncthreads();
 				}
-				// triangles: as soon as a good part of the wave has one, or nothing else is left
-				if (leaf_count >= 32u || (waiting == 0 && leaf_count != 0)) {
-					uint32_t take = leaf_count < 64u ? leaf_count : 64u;
-					bool harmless = true;
-					if (lane < take) {
-						const float4* t = p.bvh.triangles + 3 * (size_t) leaves[leaf_count - take + lane];
+				__syncthreads();  // (everyone has read its frontier entry before the entries are overwritten)
+				waiting -= take;
+				bool to_frontier = hit && !(link & kLeafBit), to_leaves = hit && (link & kLeafBit) != 0;
+				uint64_t inner_mask = __ballot(to_frontier), leaf_mask = __ballot(to_leaves);
+				uint32_t inner_new = (uint32_t) __popcll((unsigned long long) inner_mask), leaf_new = (uint32_t) __popcll((unsigned long long) leaf_mask);
+				if (waiting + inner_new > kShaftFrontier || leaf_count + leaf_new > kShaftLeaves) { queue_full = alive; alive = 0; break; }
+				if (to_frontier) frontier[waiting + __builtin_amdgcn_mbcnt_hi((uint32_t) (inner_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) inner_mask, 0u))] = link | (k << kShaftLightShift);
+				if (to_leaves) leaves[leaf_count + __builtin_amdgcn_mbcnt_hi((uint32_t) (leaf_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) leaf_mask, 0u))] = (link & ~kLeafBit) | (k << kShaftLightShift);
+				waiting += inner_new;
+				leaf_count += leaf_new;
+				__syncthreads();
+			}
+			// triangles: as soon as a good part of the wave has one, or nothing else is left
+			if (leaf_count >= 32u || (waiting == 0 && leaf_count != 0)) {
+				uint32_t take = leaf_count < 64u ? leaf_count : 64u;
+				++batches;
+				if (lane < take) {
+					uint32_t entry = leaves[leaf_count - take + lane];
+					uint32_t k = entry >> kShaftLightShift;
+					if ((alive >> k) & 1u) {
+						const float4* t = p.bvh.triangles + 3 * (size_t) (entry & ((1u << kShaftLightShift) - 1u));
 						float4 a = t[0], bq = t[1], cq = t[2];
-						harmless = shaft_triangle_harmless(s, patch, mk3(a.x, a.y, a.z), mk3(bq.x, bq.y, bq.z), mk3(cq.x, cq.y, cq.z), margin);
+						if (!shaft_triangle_harmless(shafts[k], patch, mk3(a.x, a.y, a.z), mk3(bq.x, bq.y, bq.z), mk3(cq.x, cq.y, cq.z), margin)) {
+							atomicOr(&failed_lights, 1u << k);
+							// (diagnostics: bits 8 ... 31 of the verdict name one triangle that is in the way, if its index fits)
+							uint32_t which = __float_as_uint(a.w);
+							failed_triangle[k] = which < (1u << 24) ? which << 8 : 0u;
+						}
 					}
-					__syncthreads();
-					leaf_count -= take;
-					if (__ballot(!harmless) != 0) { is_clear = false; break; }
 				}
+				__syncthreads();
+				leaf_count -= take;
+				alive &= ~failed_lights;
 			}
 		}
-		if (lane == 0) clear[light_index] = is_clear ? 1u : 0u;
+		__syncthreads();
+		if (lane < chunk_lights && ((walked >> lane) & 1u)) {
+			uint32_t verdict = kShaftClear;
+			if ((failed_lights >> lane) & 1u) verdict = kShaftTriangle | failed_triangle[lane];
+			else if ((too_long >> lane) & 1u) verdict = kShaftTooLong;
+			else if ((queue_full >> lane) & 1u) verdict = kShaftQueueFull;
+			clear[chunk + lane] = verdict;
+		}
+		if (lane == 0 && work_counters && walked) {
+			atomicAdd(work_counters, (unsigned long long) steps);
+			atomicAdd(work_counters + 1, (unsigned long long) batches);
+			atomicAdd(work_counters + 2, (unsigned long long) __popc(walked));
+		}
 	}
 }
 

@@ -86,7 +86,8 @@ struct shade_params {
 	uint32_t ray_queue_capacity, ray_thread_bits;
 	uint32_t thread_count, max_terms, max_codes;
 	// light shafts (light_shafts.h): [shading workgroup][light] = 1 when no shadow ray of that 8x8 patch toward that
-	// light can be blocked - its terms are then written as final ones and no ray is queued; NULL: every ray is traced
+	// light can be blocked - its terms are then written as final ones and no ray is queued (any other value: why the
+	// pair is not clear); NULL: every ray is traced
 	const uint32_t* shaft_clear;
 	// first 16x16 pixel block of this launch in the rank's schedule (a frame may be rendered as
 	// several launches, "bands", each with wavefront buffers of its own size)
@@ -1528,7 +1529,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 			ctx.noise = &noise;
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
-				if constexpr (is_deferred(RAYS)) ctx.light_clear = p.shaft_clear != nullptr && *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) != 0u;
+				if constexpr (is_deferred(RAYS)) ctx.light_clear = p.shaft_clear != nullptr && *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) == 1u;
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);
 			}
 		}

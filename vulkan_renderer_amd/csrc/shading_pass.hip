@@ -920,14 +920,22 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		// four-wide tree whatever tree the rays walk.
 		p.shaft_clear = NULL;
 		if (frame && frames->light_shafts && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
+			&& app->scene.acceleration_structure.node_count < (1u << kShaftLightShift)  // (a queue entry of the walk is a node or triangle index and a light)
 			&& (technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueSolidAngle || technique == kTechniqueClippedSolidAngle))
 		{
 			const acceleration_structure_t* structure = &app->scene.acceleration_structure;
 			uint32_t shaft_groups = shade_grid_size(p.block_count);
-			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count)) return 1;
+			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8)) return 1;
 			float extent = 0.0f;
 			for (int j = 0; j != 3; ++j) extent = fmaxf(extent, kGridMax / structure->grid_inverse_cell[j]);
-			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, extent);
+			// (VKR_SHAFT_COUNTERS=1: the walks count their steps into three words behind the table, for get_light_shaft_work())
+			static const bool count_work = getenv("VKR_SHAFT_COUNTERS") != NULL;
+			unsigned long long* work = NULL;
+			if (count_work) {
+				work = (unsigned long long*) (frame->buffers.shaft_clear + (((size_t) shaft_groups * p.light_count + 1u) & ~(size_t) 1u));
+				(void) hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream);
+			}
+			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, extent, work);
 			if (hip_failed(hipGetLastError(), "launching the light shaft kernel")) return 1;
 			p.shaft_clear = frame->buffers.shaft_clear;
 			pass->last_shaft_groups = shaft_groups;
@@ -1144,12 +1152,13 @@ __global__ void __launch_bounds__(256) k_traversal_statistics_wide(bvh_view bvh,
 					const uint32_t x[4] = {qx.x, qx.y, qx.z, qx.w}, y[4] = {qy.x, qy.y, qy.z, qy.w}, z[4] = {qz.x, qz.y, qz.z, qz.w}, links[4] = {link.x, link.y, link.z, link.w};
 					++my_visits;
 					item = 0xFFFFFFFFu;
-					for (int c = 0; c != 4; ++c) {
+					// the order of trace_shadow_rays_wide: child 0 next, then 1, 2, 3 (pushed last to first)
+					for (int c = 3; c >= 0; --c) {
 						if (links[c] == kWideEmpty) continue;
 						++boxes;
 						if (!wide_ray_box(x[c], y[c], z[c], ray, 1.0e-3f, t_max)) continue;
-						if (item == 0xFFFFFFFFu) item = links[c];
-						else if (depth < kWideStackMax) stack[depth++] = links[c];
+						if (item != 0xFFFFFFFFu && depth < kWideStackMax) stack[depth++] = item;
+						item = links[c];
 					}
 					deepest = max(deepest, depth);
 				}
@@ -1338,14 +1347,17 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 }
 
 // sums the words of the most recent launch's shaft table
+// out[0]: clear pairs, out[1 ... 5]: pairs that are not, by reason (kShaftNoPixels ... kShaftTriangle, light_shafts.h)
 __global__ void __launch_bounds__(256) k_count_clear_shafts(const uint32_t* words, size_t count, unsigned long long* out) {
-	unsigned long long mine = 0;
-	for (size_t i = (size_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (size_t) gridDim.x * 256u) mine += words[i] ? 1u : 0u;
-	if (mine) atomicAdd(out, mine);
+	for (size_t i = (size_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (size_t) gridDim.x * 256u) {
+		uint32_t verdict = words[i] & 0xFFu;
+		uint32_t slot = verdict == kShaftClear ? 0u : (verdict >= kShaftNoPixels && verdict <= kShaftTriangle ? 1u + (verdict - kShaftNoPixels) : 6u);
+		atomicAdd(out + slot, 1ull);
+	}
 }
 
-extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[4]) {
-	memset(out_statistics, 0, sizeof(uint64_t) * 4);
+extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[10]) {
+	memset(out_statistics, 0, sizeof(uint64_t) * 10);
 	const shading_pass_t* pass = &app->shading_pass;
 	const frame_pipeline* frames = (const frame_pipeline*) pass->wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
@@ -1353,18 +1365,42 @@ extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_stati
 	if (finish_frames(app)) return 1;
 	size_t words = (size_t) pass->last_shaft_groups * app->scene_specification.polygonal_light_count;
 	unsigned long long* counter = NULL;
-	if (hip_failed(hipMalloc(&counter, sizeof(unsigned long long)), "allocating a counter")) return 1;
+	if (hip_failed(hipMalloc(&counter, sizeof(unsigned long long) * 8), "allocating counters")) return 1;
 	hipStream_t stream = (hipStream_t) app->device.stream;
-	(void) hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
+	(void) hipMemsetAsync(counter, 0, sizeof(unsigned long long) * 8, stream);
 	k_count_clear_shafts<<<256, 256, 0, stream>>>(w->shaft_clear, words, counter);
-	unsigned long long clear = 0;
-	int failed = vkr_copy_to_host(&clear, counter, sizeof(clear), &app->device);
+	unsigned long long counts[8] = {0};
+	int failed = vkr_copy_to_host(counts, counter, sizeof(counts), &app->device);
 	(void) hipFree(counter);
 	out_statistics[0] = words;
-	out_statistics[1] = clear;
+	out_statistics[1] = counts[0];
 	out_statistics[2] = pass->last_shaft_groups;
 	out_statistics[3] = app->scene_specification.polygonal_light_count;
+	for (int i = 0; i != 6; ++i) out_statistics[4 + i] = counts[1 + i];
 	return failed;
+}
+
+// (diagnostics, VKR_SHAFT_COUNTERS=1) {steps, triangle batches, walks} of the most recent launch's shaft kernel
+extern "C" int get_light_shaft_work(application_t* app, uint64_t out_work[3]) {
+	out_work[0] = out_work[1] = out_work[2] = 0;
+	const shading_pass_t* pass = &app->shading_pass;
+	const frame_pipeline* frames = (const frame_pipeline*) pass->wavefront;
+	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
+	if (!w || !pass->last_shaft_groups || !w->shaft_clear || !getenv("VKR_SHAFT_COUNTERS") || finish_frames(app)) return 0;
+	size_t words = ((size_t) pass->last_shaft_groups * app->scene_specification.polygonal_light_count + 1u) & ~(size_t) 1u;
+	return vkr_copy_to_host(out_work, w->shaft_clear + words, 3 * sizeof(uint64_t), &app->device);
+}
+
+// (diagnostics) the verdict words of the most recent launch, [patch][light]; returns how many were written
+extern "C" uint64_t read_back_light_shafts(application_t* app, uint32_t* out_words, uint64_t capacity) {
+	const shading_pass_t* pass = &app->shading_pass;
+	const frame_pipeline* frames = (const frame_pipeline*) pass->wavefront;
+	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
+	if (!w || !pass->last_shaft_groups || !w->shaft_clear || finish_frames(app)) return 0;
+	uint64_t words = (uint64_t) pass->last_shaft_groups * app->scene_specification.polygonal_light_count;
+	if (words > capacity) words = capacity;
+	if (vkr_copy_to_host(out_words, w->shaft_clear, sizeof(uint32_t) * words, &app->device)) return 0;
+	return words;
 }
 
 extern "C" uint64_t get_last_ray_count(const application_t* app) {
