@@ -120,6 +120,8 @@ void oracle_set_math_mode(int mode);
  * vulkan_renderer_amd/csrc/glibc_math.h (the same on every machine), 1 the C library of this machine */
 void oracle_set_libm_source(int use_system_library);
 int oracle_get_libm_source(void);
+/* diagnostics: print every shadow ray (origin, direction, t_max, the light's plane, blocked) to stdout */
+void oracle_set_ray_log(int on);
 
 /* Output encodings of the reference (shading_pass.frag.glsl:871-892) */
 void oracle_encode_srgb8(const float* rgba, uint8_t* out_rgba8, uint64_t pixel_count);

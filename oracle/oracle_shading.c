@@ -19,6 +19,8 @@
 
 int g_oracle_math_mode = 0;
 static uint64_t g_ray_count = 0;
+static int g_log_rays = 0;
+void oracle_set_ray_log(int on) { g_log_rays = on; }
 
 void oracle_set_math_mode(int mode) { g_oracle_math_mode = mode; }
 int g_oracle_system_libm = 0;
@@ -1045,7 +1047,10 @@ static int polygon_visibility(pixel_ctx_t* ctx, int visibility, v3 dir, v3 posit
 	float max_t = -dot4_point(position, light->plane) / dot3(dir, plane_normal(light->plane));
 	float o[3] = {position.x, position.y, position.z}, d[3] = {dir.x, dir.y, dir.z};
 	++ctx->rays;
-	return !oracle_bvh_any_hit(ctx->f->bvh, o, d, 1.0e-3f, max_t, ctx->f->brute_force_rays);
+	int blocked = oracle_bvh_any_hit(ctx->f->bvh, o, d, 1.0e-3f, max_t, ctx->f->brute_force_rays);
+	/* (diagnostics: ORACLE_LOG_RAYS=1 prints every shadow ray - used with one-pixel calls to explain a pixel) */
+	if (g_log_rays) printf("ray o %.9g %.9g %.9g d %.9g %.9g %.9g tmax %.9g plane %.9g %.9g %.9g %.9g blocked %d\n", o[0], o[1], o[2], d[0], d[1], d[2], max_t, light->plane.x, light->plane.y, light->plane.z, light->plane.w, blocked);
+	return !blocked;
 }
 
 /* get_polygon_radiance, :151-185 */

@@ -3,6 +3,7 @@ experiment (table entry -> scene, settings, timing, screenshot file)."""
 import ctypes as C
 import glob
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -101,3 +102,24 @@ def test_c_program_on_the_c_abi_reproduces_the_python_runner(tmp_path):
     image = decode_png(open(files[0], "rb").read())
     assert image.shape == expected.shape and image.max() > 0
     assert np.array_equal(image, expected)
+
+
+def test_bench_launches_two_ranks_by_itself_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's scaling run would have ended
+    with "--gpus 8 does not match WORLD_SIZE 1"): two ranks share the one GPU, the process group is gloo, the slabs travel
+    through the host (RCCL refuses two ranks on one device); tiles, slabs, exchange, scatter and the bookkeeping of
+    bench.py are the code of an N-GPU run.  One JSON line, the assembled frame equal to the single-GPU frame."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VKR_BENCH_SELF_LAUNCHED")}
+    env.update({"VKR_BENCH_DEVICE": "0", "VKR_BENCH_BACKEND": "gloo"})
+    done = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--prewarm-frames", "24", "--prewarm-seconds", "0.2",
+                           "--no-secondary", "--no-cpu-baseline", "--no-extra", "--ltc-resolution", "16"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-1500:] + done.stderr[-1500:]
+    lines = [json.loads(line) for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["scaling_parity"]["pixels_differing_from_single_gpu_frame"] == 0
+    assert len(line["stages"]["shade_ms"]) == 2

@@ -13,9 +13,16 @@
 // with and without).  What it buys depends on the scene: 83 % of the lit (patch, light) pairs of the benchmark
 // scene at config 3 are clear, 7 % of the large scene's (profiles/).
 //
+// Which rays a shaft holds.  Samples aim at the polygon, but where the sampling breaks down numerically (a polygon that
+// is a sliver in the space it is sampled in: seed 6 of the random sweep has a specular sample 2.5 degrees off a light
+// seen edge-on) the reference's directions leave it, and the ray query toward the light's PLANE still decides the term.
+// So the shaft is built around a rectangle R in the light's plane space that contains the polygon with a margin of
+// 1/32 of its size, and the shading kernel lets a ray skip the tracing only if it meets the light's plane inside a
+// slightly smaller rectangle (shaft_holds_ray, shading_kernel.h; out_rectangles carries it); every other ray is traced.
+//
 // Conservative by construction.  With B the bounding box of the patch's shading positions (plus margin), c its
-// centre, support(n) = |n.x| h.x + |n.y| h.y + |n.z| h.z the reach of B along n, L'_i the light's vertices moved
-// away from their centroid by 1/32 (sampled directions may leave the polygon by rounding), n_L the light's plane:
+// centre, support(n) = |n.x| h.x + |n.y| h.y + |n.z| h.z the reach of B along n, L'_i the four corners of R in world
+// space, n_L the light's plane:
 //   side plane k     through c, L'_k, L'_k+1, pushed outwards by support(n)   contains the box and the polygon
 //   far cap          n_L . x <= n_L . L_0 + margin                              rays end on the light's plane
 //   near cap         a . x >= a . c - support(a), a towards the centroid      only if every L'_i lies in front of it
@@ -33,7 +40,7 @@
 
 namespace vkr {
 
-constexpr uint32_t kShaftMaxVertices = 8;                     // light polygons with more vertices are never clear
+constexpr uint32_t kShaftMaxVertices = 4;                     // the shaft is built around a rectangle in the light's plane
 constexpr uint32_t kShaftMaxPlanes = kShaftMaxVertices + 3;   // sides, far cap, near cap, the patch's own plane
 constexpr uint32_t kShaftLights = 8;                          // lights whose shafts are walked together
 constexpr uint32_t kShaftLightShift = 27;                     // an entry of the queues: node or triangle | light << 27
@@ -181,10 +188,34 @@ VKR_DEV bool shaft_triangle_harmless(const shaft_state& s, const shaft_patch& pa
 	return g_min <= h_min && first > 2.0f * margin;
 }
 
+// The rectangle of a light in its plane space (u_min, v_min, u_max, v_max): the bounding box of the polygon's plane-space
+// vertices (reference polygonal_light.h: vertices_plane_space) grown on every side by `room` x (1/32 of its size + eight
+// margins in plane units).
+VKR_DEV float4 shaft_rectangle(const light_ref& light, float margin, float room) {
+	uint32_t count = light_vertex_count(light);
+	float u_min = 3.0e38f, v_min = 3.0e38f, u_max = -3.0e38f, v_max = -3.0e38f;
+	for (uint32_t i = 0; i < count; ++i) {
+		float u = load_f(light.base, 160 + 16 * i), v = load_f(light.base, 164 + 16 * i);
+		u_min = fminf(u_min, u); u_max = fmaxf(u_max, u);
+		v_min = fminf(v_min, v); v_max = fmaxf(v_max, v);
+	}
+	float grow_u = room * (kShaftDilation * (u_max - u_min) + 8.0f * margin * fabsf(load_f(light.base, 44)));
+	float grow_v = room * (kShaftDilation * (v_max - v_min) + 8.0f * margin * fabsf(load_f(light.base, 60)));
+	return make_float4(u_min - grow_u, v_min - grow_v, u_max + grow_u, v_max + grow_v);
+}
+// corner 0 ... 3 (counter-clockwise in plane space) of such a rectangle in world space: T + R (u s_x, v s_y, 0)
+VKR_DEV f3 shaft_rectangle_corner(const light_ref& light, float4 rectangle, uint32_t corner) {
+	float u = (corner == 0u || corner == 3u) ? rectangle.x : rectangle.z;
+	float v = (corner < 2u) ? rectangle.y : rectangle.w;
+	u *= load_f(light.base, 12);
+	v *= load_f(light.base, 28);
+	return light_translation(light) + light_rotation_column(light, 0) * u + light_rotation_column(light, 1) * v;
+}
+
 // `b` numbers the workgroups like shade_pixels does (one 8x8 patch each); out_clear[b * light_count + i] = 1 when no
 // ray of that patch toward light i can be blocked.  extent: largest coordinate difference of the scene (margins).
 // work_counters (diagnostics, may be NULL): [0] steps of the walks, [1] batches of triangles, [2] walks
-__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float extent, unsigned long long* work_counters) {
+__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float4* __restrict__ out_rectangles, float extent, unsigned long long* work_counters) {
 	__shared__ shaft_patch patch;
 	__shared__ shaft_state shafts[kShaftLights];
 	__shared__ uint32_t frontier[kShaftFrontier];
@@ -201,15 +232,19 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 	bool shaded = primitive != 0xFFFFFFFFu;
 	uint32_t* clear = out_clear + (size_t) b * p.light_count;
 	const uint64_t valid = __ballot(shaded);
+	// What the tests below allow for: shading positions and triangle vertices are a few units in the last place of the
+	// scene's coordinates off the planes they lie on, and so is what the tracing kernels compute with them - 5e-7 of
+	// the extent is ten units in the last place of the largest coordinate.
+	const float margin = 5.0e-7f * extent;
+	if (b == 0) {
+		// the rectangles that the shading kernel tests its rays against (the same for every patch: one workgroup writes them)
+		for (uint32_t i = lane; i < p.light_count; i += 64u) out_rectangles[i] = shaft_rectangle(get_light(p, i), margin, 1.0f);
+	}
 	if (valid == 0) {
 		for (uint32_t i = lane; i < p.light_count; i += 64u) clear[i] = kShaftNoPixels;
 		return;
 	}
 	// ---- the patch: shading positions as the shading kernel computes them (get_shading_data) ---------------
-	// What the tests below allow for: shading positions and triangle vertices are a few units in the last place of the
-	// scene's coordinates off the planes they lie on, and so is what the tracing kernels compute with them - 5e-7 of
-	// the extent is ten units in the last place of the largest coordinate.
-	const float margin = 5.0e-7f * extent;
 	f3 position = mk3(0.0f, 0.0f, 0.0f), face_normal = position;
 	float face_d = 0.0f;
 	if (shaded) {
@@ -261,25 +296,20 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 		for (uint32_t k = 0; k != chunk_lights; ++k) {
 			shaft_state& s = shafts[k];
 			light_ref light = get_light(p, chunk + k);
-			const uint32_t vertex_count = light_vertex_count(light);
+			constexpr uint32_t vertex_count = 4;
 			// ---- the shaft of this light (lanes build one plane each) -------------------------------------------
-			bool possible = vertex_count >= 3u && vertex_count <= kShaftMaxVertices;
+			// the rectangle the shaft is built around: the one the rays are tested against, and half as much room again
+			const float4 rectangle = shaft_rectangle(light, margin, 1.5f);
+			bool possible = light_vertex_count(light) >= 3u && rectangle.z > rectangle.x && rectangle.w > rectangle.y;
 			// every position on the same side of the light's plane, away from it
 			float side = shaded ? plane_distance(light, position) : 0.0f;
 			float side_min = wave_min(shaded ? side : big), side_max = wave_max(shaded ? side : -big);
 			possible = possible && (side_min > 8.0f * margin || side_max < -8.0f * margin);
 			if (possible) {
-				f3 centroid = mk3(0.0f, 0.0f, 0.0f);
-				for (uint32_t i = 0; i != vertex_count; ++i) centroid = centroid + light_vertex(light, i);
-				centroid = centroid * (1.0f / (float) vertex_count);
-				// dilated vertex of this lane (lanes beyond the polygon repeat vertices; unused)
-				uint32_t v = lane % vertex_count, v_next = (v + 1u) % vertex_count;
-				f3 v0 = light_vertex(light, v), v1 = light_vertex(light, v_next);
-				float grow = 1.0f + kShaftDilation;
-				f3 pad_direction = v0 - centroid;
-				v0 = centroid + (v0 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
-				pad_direction = v1 - centroid;
-				v1 = centroid + (v1 - centroid) * grow + pad_direction * (4.0f * margin * __builtin_amdgcn_rsqf(fmaxf(dot(pad_direction, pad_direction), 1.0e-30f)));
+				// corner of this lane and the next one around the rectangle (lanes beyond the fourth repeat; unused)
+				uint32_t v = lane & 3u, v_next = (v + 1u) & 3u;
+				f3 v0 = shaft_rectangle_corner(light, rectangle, v), v1 = shaft_rectangle_corner(light, rectangle, v_next);
+				f3 centroid = (shaft_rectangle_corner(light, rectangle, 0u) + shaft_rectangle_corner(light, rectangle, 2u)) * 0.5f;
 				f3 axis = centroid - centre;
 				float axis_length = __builtin_sqrtf(dot(axis, axis));
 				axis = axis * (1.0f / fmaxf(axis_length, 1.0e-30f));

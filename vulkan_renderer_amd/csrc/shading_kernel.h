@@ -89,6 +89,9 @@ struct shade_params {
 	// light can be blocked - its terms are then written as final ones and no ray is queued (any other value: why the
 	// pair is not clear); NULL: every ray is traced
 	const uint32_t* shaft_clear;
+	// ... and per light the rectangle (u_min, v_min, u_max, v_max in the light's plane space) that the shafts were built
+	// around: only a ray that meets the light's plane inside it may skip the tracing (shaft_holds_ray)
+	const float4* shaft_rectangles;
 	// first 16x16 pixel block of this launch in the rank's schedule (a frame may be rendered as
 	// several launches, "bands", each with wavefront buffers of its own size)
 	uint32_t first_block, block_count;
@@ -733,8 +736,10 @@ struct pixel_context {
 	// deferred mode: this thread's slot in the term streams and its write cursors
 	uint32_t tid, code_cursor, term_cursor;
 	bool light_has_terms;
-	// nothing can block a ray toward the current light (shade_params::shaft_clear; wave-uniform)
+	// nothing can block a ray toward the current light that stays inside its shaft (shade_params::shaft_clear;
+	// wave-uniform), and the number of that light
 	bool light_clear;
+	uint32_t light_index;
 	uint32_t queue;
 	// this thread's column of the LDS tables of the prepared polygons (strategies with two
 	// techniques per light: 2 x kPsaTableSlots(V) slots, [slot][thread]), else NULL
@@ -823,6 +828,29 @@ VKR_DEV void close_ray_block(const shade_params& p, uint32_t queue) {
 	if (rank == 0 && rays) atomicAdd(p.ray_queue_size + kRayCountOffset + (queue >> 6) * kCursorStride, rays);
 }
 
+// Light shafts (light_shafts.h) are built around a rectangle in the light's plane that contains the polygon with room to
+// spare.  Samples aim at the polygon, but where the sampling breaks down numerically (a polygon that is a sliver in the
+// space it is sampled in) the reference shader's directions leave it - and the ray query toward the light's PLANE is
+// still part of the result.  So a ray only skips the tracing if it meets the plane inside that rectangle, in front of
+// the origin: u_min <= u <= u_max with u = col0 . (o + t d - T) / s_x, t = a / b, a = -(n . o + w), b = n . d, written
+// without the division (both sides times b).  NaNs fail every comparison: such a ray is queued as before.
+VKR_DEV bool shaft_holds_ray(const shade_params& p, uint32_t light_index, const light_ref& light, f3 origin, f3 dir) {
+	constant_float_pointer words = (constant_float_pointer) (uintptr_t) (p.shaft_rectangles + light_index);
+	float4 rectangle = make_float4(words[0], words[1], words[2], words[3]);
+	f3 n = plane_normal(light);
+	float a = -plane_distance(light, origin), b = dot(dir, n);
+	f3 relative = origin - light_translation(light);
+	f3 column_u = light_rotation_column(light, 0), column_v = light_rotation_column(light, 1);
+	// plane-space coordinates of the hit point, times b
+	float u = (dot(column_u, relative) * b + a * dot(column_u, dir)) * load_f(light.base, 44);
+	float v = (dot(column_v, relative) * b + a * dot(column_v, dir)) * load_f(light.base, 60);
+	bool forward = b > 0.0f;
+	float lo_u = forward ? rectangle.x * b : rectangle.z * b, hi_u = forward ? rectangle.z * b : rectangle.x * b;
+	float lo_v = forward ? rectangle.y * b : rectangle.w * b, hi_v = forward ? rectangle.w * b : rectangle.y * b;
+	// t > 0: a and b of one sign
+	return a * b > 0.0f && u >= lo_u && u <= hi_u && v >= lo_v && v <= hi_v;
+}
+
 // Adds one estimator term to the per-light sum.  `visible_term` is the value of the
 // term if the shadow ray reaches the light (or, without a candidate ray, simply the
 // value), `hidden_term` the value if it is blocked.
@@ -844,10 +872,12 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		// Adding +-0 never changes the running sum (it starts at +0), so such terms are
 		// dropped; everything else is written in program order.
 		const shade_params& p = ctx.p;
-		// (a ray toward a light whose shaft is clear would arrive: its term is the visible one, right away)
+		// (a ray inside a shaft that is clear would arrive: its term is the visible one, right away)
 		bool hidden_matters = !all_zero(hidden_term);
-		bool needs_ray = candidate && !ctx.light_clear && (hidden_matters || !all_zero(visible_term));
-		bool is_final = (!candidate || ctx.light_clear) && !all_zero(visible_term);
+		bool arrives = false;
+		if (ctx.light_clear && candidate) arrives = shaft_holds_ray(p, ctx.light_index, light, sd.position, dir);
+		bool needs_ray = candidate && !arrives && (hidden_matters || !all_zero(visible_term));
+		bool is_final = (!candidate || arrives) && !all_zero(visible_term);
 		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
 			if (ctx.noise) settle_noise(*ctx.noise);
 			size_t code_index = code_slot(p.thread_count, ctx.code_cursor, ctx.tid);
@@ -1488,7 +1518,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
-	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, queue, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, queue, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		lds_state_word* state = ray_block_state();
@@ -1529,7 +1559,10 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 			ctx.noise = &noise;
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
-				if constexpr (is_deferred(RAYS)) ctx.light_clear = p.shaft_clear != nullptr && *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) == 1u;
+				if constexpr (is_deferred(RAYS)) {
+					ctx.light_clear = p.shaft_clear != nullptr && *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) == 1u;
+					ctx.light_index = i;
+				}
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);
 			}
 		}

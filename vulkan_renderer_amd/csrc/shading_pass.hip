@@ -139,6 +139,9 @@ struct wavefront_buffers {
 	// light can be blocked; allocated when the feature first runs
 	uint32_t* shaft_clear;
 	size_t shaft_words;
+	// ... and per light the plane-space rectangle that the shading kernel tests its rays against
+	float4* shaft_rectangles;
+	uint32_t shaft_rectangle_count;
 };
 
 static void free_wavefront_buffers(wavefront_buffers* w) {
@@ -146,6 +149,7 @@ static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->base_color); (void) hipFree(w->ray_directions); (void) hipFree(w->ray_records); (void) hipFree(w->ray_origins); (void) hipFree(w->ray_queue_size);
 	(void) hipFree(w->spill);
 	(void) hipFree(w->shaft_clear);
+	(void) hipFree(w->shaft_rectangles);
 	memset(w, 0, sizeof(*w));
 }
 
@@ -263,7 +267,16 @@ static uint32_t ray_block_size(uint32_t max_terms) {
 	return max_terms >= 8 ? slots : 0u;
 }
 
-static int ensure_shaft_words(wavefront_buffers* w, size_t words) {
+static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light_count) {
+	if (light_count > w->shaft_rectangle_count) {
+		(void) hipFree(w->shaft_rectangles);
+		w->shaft_rectangles = NULL; w->shaft_rectangle_count = 0;
+		if (hipMalloc(&w->shaft_rectangles, sizeof(float4) * light_count) != hipSuccess) {
+			printf("Failed to allocate the rectangles of the light shafts.\n");
+			return 1;
+		}
+		w->shaft_rectangle_count = light_count;
+	}
 	if (words <= w->shaft_words) return 0;
 	(void) hipFree(w->shaft_clear);
 	w->shaft_clear = NULL; w->shaft_words = 0;
@@ -919,13 +932,14 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		// whose samples aim at the light polygon itself (every ray then lies inside the shaft); the walk uses the
 		// four-wide tree whatever tree the rays walk.
 		p.shaft_clear = NULL;
+		p.shaft_rectangles = NULL;
 		if (frame && frames->light_shafts && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
 			&& app->scene.acceleration_structure.node_count < (1u << kShaftLightShift)  // (a queue entry of the walk is a node or triangle index and a light)
 			&& (technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueSolidAngle || technique == kTechniqueClippedSolidAngle))
 		{
 			const acceleration_structure_t* structure = &app->scene.acceleration_structure;
 			uint32_t shaft_groups = shade_grid_size(p.block_count);
-			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8)) return 1;
+			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8, p.light_count)) return 1;
 			float extent = 0.0f;
 			for (int j = 0; j != 3; ++j) extent = fmaxf(extent, kGridMax / structure->grid_inverse_cell[j]);
 			// (VKR_SHAFT_COUNTERS=1: the walks count their steps into three words behind the table, for get_light_shaft_work())
@@ -935,9 +949,10 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				work = (unsigned long long*) (frame->buffers.shaft_clear + (((size_t) shaft_groups * p.light_count + 1u) & ~(size_t) 1u));
 				(void) hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream);
 			}
-			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, extent, work);
+			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, extent, work);
 			if (hip_failed(hipGetLastError(), "launching the light shaft kernel")) return 1;
 			p.shaft_clear = frame->buffers.shaft_clear;
+			p.shaft_rectangles = frame->buffers.shaft_rectangles;
 			pass->last_shaft_groups = shaft_groups;
 		}
 		else pass->last_shaft_groups = 0;
