@@ -71,12 +71,12 @@ typedef enum acceleration_structure_builder_e {
 /*! Replaces reference scene.h:161-175: a binary BVH over the de-quantised
 	triangle soup (same de-quantisation as scene.c:176-187). */
 typedef struct acceleration_structure_s {
-	/*! float4 per vertex, 3 per triangle, in leaf order */
+	/*! float4 per vertex, 3 per leaf, in leaf order */
 	void* triangle_vertices;
 	/*! unused (the original triangle index travels in w of the first vertex) */
 	void* triangle_indices;
-	/*! (2 * triangle_count - 1) nodes of 16 bytes in depth-first order with boxes
-		quantised to a 16-bit grid, see vulkan_renderer_amd/csrc/lbvh.h */
+	/*! (2 * leaf_count - 1) nodes of 16 bytes in depth-first order with boxes
+		quantised to a 15-bit grid, see vulkan_renderer_amd/csrc/lbvh.h */
 	void* nodes;
 	uint32_t node_count;
 	uint32_t root;
@@ -94,6 +94,11 @@ typedef struct acceleration_structure_s {
 		triangles on the device to the finished structures (HIP kernels, or host build + upload) */
 	uint32_t builder;
 	float build_milliseconds;
+	/*! Leaves of the tree: the triangle count, or more when the device SAH builder has split long thin triangles
+		that lie diagonally in their boxes into several leaves (each names the whole triangle; lbvh_build.hip
+		"fragments"; environment VKR_BVH_SPLIT_TRIANGLES=0 turns it off).  node_count = 2 leaf_count - 1. */
+	uint32_t leaf_count;
+	uint32_t reserved;
 } acceleration_structure_t;
 
 /*! reference scene.h:161-166 */

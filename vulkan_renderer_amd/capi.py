@@ -80,7 +80,7 @@ class AccelerationStructure(C.Structure):
                 ("node_count", C.c_uint32), ("root", C.c_uint32),
                 ("grid_origin", C.c_float * 3), ("grid_inverse_cell", C.c_float * 3),
                 ("wide_nodes", C.c_void_p), ("wide_node_count", C.c_uint32), ("wide_stack_need", C.c_uint32),
-                ("builder", C.c_uint32), ("build_milliseconds", C.c_float)]
+                ("builder", C.c_uint32), ("build_milliseconds", C.c_float), ("leaf_count", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Scene(C.Structure):

@@ -23,9 +23,14 @@ namespace {
 
 struct build_params {
 	const uint2* quantized_positions;
+	// primitives of the build: triangles, or - device SAH with split triangles - fragments of triangles
 	uint32_t triangle_count;
 	float factor[3], summand[3];
 	float pad;
+	// Split triangles (see "fragments" below): primitive t is the part of triangle fragment_triangle[t] inside the box
+	// fragment_boxes[6 t ... 6 t + 5] (lo.xyz, hi.xyz).  NULL: every primitive is a whole triangle.
+	const uint32_t* fragment_triangle;
+	const float* fragment_boxes;
 };
 
 // De-quantisation with two roundings (multiply, then add) like scene.c:176-187; the
@@ -258,8 +263,18 @@ __device__ __forceinline__ void grow_open_node(sah_open_node* node, f3 lo, f3 hi
 	}
 }
 
+// index in the mesh of the triangle that primitive t is (a fragment of)
+__device__ __forceinline__ uint32_t source_triangle(const build_params& p, uint32_t t) { return p.fragment_triangle ? p.fragment_triangle[t] : t; }
+
 __device__ __forceinline__ void triangle_bounds(const build_params& p, uint32_t t, f3 (&v)[3], f3& lo, f3& hi) {
-	for (int i = 0; i != 3; ++i) v[i] = dequantize(p.quantized_positions[3 * (size_t) t + i], p);
+	uint32_t triangle = source_triangle(p, t);
+	for (int i = 0; i != 3; ++i) v[i] = dequantize(p.quantized_positions[3 * (size_t) triangle + i], p);
+	if (p.fragment_boxes) {
+		const float* box = p.fragment_boxes + 6 * (size_t) t;
+		lo = mk3(box[0], box[1], box[2]);
+		hi = mk3(box[3], box[4], box[5]);
+		return;
+	}
 	lo = mk3(fminf(v[0].x, fminf(v[1].x, v[2].x)), fminf(v[0].y, fminf(v[1].y, v[2].y)), fminf(v[0].z, fminf(v[1].z, v[2].z)));
 	hi = mk3(fmaxf(v[0].x, fmaxf(v[1].x, v[2].x)), fmaxf(v[0].y, fmaxf(v[1].y, v[2].y)), fmaxf(v[0].z, fmaxf(v[1].z, v[2].z)));
 }
@@ -271,7 +286,8 @@ __device__ __forceinline__ void write_threaded_node(float4* threaded, uint32_t p
 
 __device__ __forceinline__ void write_leaf(const build_params& p, uint32_t t, const f3 (&v)[3], f3 lo, f3 hi, uint32_t position, uint32_t slot, float4* threaded, float4* triangles) {
 	write_threaded_node(threaded, position, lo, hi, p.pad, position + 1u, slot);
-	triangles[3 * (size_t) slot + 0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(t));
+	// (w of the first vertex: the triangle's index in the mesh - what primary visibility reports)
+	triangles[3 * (size_t) slot + 0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(source_triangle(p, t)));
 	triangles[3 * (size_t) slot + 1] = make_float4(v[1].x, v[1].y, v[1].z, 0.0f);
 	triangles[3 * (size_t) slot + 2] = make_float4(v[2].x, v[2].y, v[2].z, 0.0f);
 }
@@ -582,6 +598,102 @@ __global__ void __launch_bounds__(256) k_sah_assign(build_params p, uint32_t* tr
 	if (threadIdx.x < kSahGroupSlots * 12) {
 		uint32_t key = keys[threadIdx.x / 12];
 		if (key != kSahEmptyKey) flush_box_word(next_open + key, threadIdx.x % 12, words[threadIdx.x]);
+	}
+}
+
+// ---- fragments: long thin triangles that run diagonally through their boxes ---------------------
+// The box of a slat 3 m long and 6 cm wide that lies at 45 degrees to the axes measures 2.1 m x 2.1 m: a tree of
+// such boxes sends every ray through a neighbourhood of the slat into its triangle test (the large scene of
+// synthetic.py: 30 triangle tests per shadow ray).  The reference's scenes are full of such triangles (railings,
+// awnings, wires), and the drivers it relies on split them.  Here a triangle whose box has more than four times the
+// half-area it needs (twice the triangle's area is what a triangle in an axis plane takes) is cut into up to 16
+// slabs along the longest axis of its box, and every slab becomes a primitive of the build with the bounds of the
+// triangle INSIDE the slab - its box, exactly (the triangle clipped by the two planes), so every point of the
+// triangle lies in the box of some fragment, and a leaf per fragment names the whole triangle.  Ray queries
+// return what they returned (the same triangles are tested, some by more than one leaf); the tree is what changes.
+constexpr uint32_t kMostFragments = 16;
+
+__device__ __forceinline__ uint32_t fragments_wanted(const f3 (&v)[3], f3 lo, f3 hi, float least_extent, int& out_axis) {
+	f3 e = hi - lo;
+	out_axis = (e.x >= e.y && e.x >= e.z) ? 0 : (e.y >= e.z ? 1 : 2);
+	float longest = out_axis == 0 ? e.x : (out_axis == 1 ? e.y : e.z);
+	if (!(longest > least_extent)) return 1u;
+	f3 normal = cross(v[1] - v[0], v[2] - v[0]);
+	float twice_area = __builtin_sqrtf(dot(normal, normal));
+	float box_half_area = e.x * e.y + e.y * e.z + e.z * e.x;
+	float ratio = box_half_area / fmaxf(twice_area, 1.0e-30f);
+	if (!(ratio > 4.0f)) return 1u;
+	float wanted = ceilf(0.5f * ratio);
+	return wanted >= (float) kMostFragments ? kMostFragments : (uint32_t) wanted;
+}
+
+__global__ void __launch_bounds__(256) k_count_fragments(build_params p, float least_extent, uint32_t* counts) {
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= p.triangle_count) return;
+	f3 v[3], lo, hi;
+	triangle_bounds(p, t, v, lo, hi);
+	int axis;
+	counts[t] = fragments_wanted(v, lo, hi, least_extent, axis);
+}
+
+// bounds of the part of the triangle with s0 <= x_axis <= s1 (the triangle is cut by the two planes)
+__device__ __forceinline__ void slab_bounds(const f3 (&v)[3], int axis, float s0, float s1, f3& lo, f3& hi) {
+	float px[8], py[8], pz[8], qx[8], qy[8], qz[8];
+	int count = 3;
+	for (int i = 0; i != 3; ++i) { px[i] = v[i].x; py[i] = v[i].y; pz[i] = v[i].z; }
+	for (int side = 0; side != 2; ++side) {
+		// keep x_axis >= s0 (side 0), x_axis <= s1 (side 1)
+		float plane = side ? s1 : s0, sign = side ? -1.0f : 1.0f;
+		int kept = 0;
+		for (int i = 0; i != count; ++i) {
+			int j = (i + 1 == count) ? 0 : i + 1;
+			float ci = axis == 0 ? px[i] : (axis == 1 ? py[i] : pz[i]), cj = axis == 0 ? px[j] : (axis == 1 ? py[j] : pz[j]);
+			float di = sign * (ci - plane), dj = sign * (cj - plane);
+			if (di >= 0.0f) { qx[kept] = px[i]; qy[kept] = py[i]; qz[kept] = pz[i]; ++kept; }
+			if ((di >= 0.0f) != (dj >= 0.0f)) {
+				float w = di / (di - dj);
+				qx[kept] = fmaf(w, px[j] - px[i], px[i]); qy[kept] = fmaf(w, py[j] - py[i], py[i]); qz[kept] = fmaf(w, pz[j] - pz[i], pz[i]);
+				// (the point lies on the plane: say so exactly, whatever the interpolation rounded to)
+				if (axis == 0) qx[kept] = plane; else if (axis == 1) qy[kept] = plane; else qz[kept] = plane;
+				++kept;
+			}
+		}
+		count = kept;
+		for (int i = 0; i != count; ++i) { px[i] = qx[i]; py[i] = qy[i]; pz[i] = qz[i]; }
+	}
+	lo = mk3(3.0e38f, 3.0e38f, 3.0e38f); hi = mk3(-3.0e38f, -3.0e38f, -3.0e38f);
+	for (int i = 0; i != count; ++i) {
+		lo = mk3(fminf(lo.x, px[i]), fminf(lo.y, py[i]), fminf(lo.z, pz[i]));
+		hi = mk3(fmaxf(hi.x, px[i]), fmaxf(hi.y, py[i]), fmaxf(hi.z, pz[i]));
+	}
+}
+
+// first[t]: exclusive prefix sum of the counts
+__global__ void __launch_bounds__(256) k_write_fragments(build_params p, float least_extent, const uint32_t* first, uint32_t* fragment_triangle, float* fragment_boxes) {
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= p.triangle_count) return;
+	f3 v[3], lo, hi;
+	triangle_bounds(p, t, v, lo, hi);
+	int axis;
+	uint32_t count = fragments_wanted(v, lo, hi, least_extent, axis);
+	uint32_t base = first[t];
+	float a0 = axis == 0 ? lo.x : (axis == 1 ? lo.y : lo.z), a1 = axis == 0 ? hi.x : (axis == 1 ? hi.y : hi.z);
+	for (uint32_t j = 0; j != count; ++j) {
+		f3 flo = lo, fhi = hi;
+		if (count > 1u) {
+			// (the planes between the slabs are shared: slab j ends where slab j + 1 begins, bit for bit)
+			float s0 = j == 0u ? a0 : fmaf((float) j / (float) count, a1 - a0, a0);
+			float s1 = j + 1u == count ? a1 : fmaf((float) (j + 1u) / (float) count, a1 - a0, a0);
+			slab_bounds(v, axis, s0, s1, flo, fhi);
+			// a slab that the clipping left empty (rounding at the ends) keeps a point of the triangle's box
+			if (!(flo.x <= fhi.x)) { flo = lo; fhi = lo; }
+			// never beyond the triangle's own box
+			flo = mk3(fmaxf(flo.x, lo.x), fmaxf(flo.y, lo.y), fmaxf(flo.z, lo.z));
+			fhi = mk3(fminf(fhi.x, hi.x), fminf(fhi.y, hi.y), fminf(fhi.z, hi.z));
+		}
+		fragment_triangle[base + j] = t;
+		float* box = fragment_boxes + 6 * (size_t) (base + j);
+		box[0] = flo.x; box[1] = flo.y; box[2] = flo.z; box[3] = fhi.x; box[4] = fhi.y; box[5] = fhi.z;
 	}
 }
 
@@ -905,6 +1017,8 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	build_params p;
 	p.quantized_positions = (const uint2*) mesh->positions;
 	p.triangle_count = n;
+	p.fragment_triangle = NULL;
+	p.fragment_boxes = NULL;
 	float extent = 0.0f;
 	for (int j = 0; j != 3; ++j) {
 		p.factor[j] = mesh->dequantization_factor[j];
@@ -932,8 +1046,59 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 		printf("Failed to allocate pinned host memory for the BVH build.\n");
 		return 1;
 	}
+	// device SAH: long thin triangles that lie diagonally in their boxes become several primitives ("fragments" above;
+	// VKR_BVH_SPLIT_TRIANGLES=0 builds over whole triangles as until round 3)
+	void* fragment_memory = NULL;
+	const char* split_knob = getenv("VKR_BVH_SPLIT_TRIANGLES");
+	if (builder == (int) acceleration_structure_sah_device && n > 1 && !(split_knob && split_knob[0] == '0')) {
+		uint32_t* counts = NULL;
+		void* scan_storage = NULL;
+		size_t scan_bytes = 0;
+		const float least_extent = extent * (1.0f / 512.0f);
+		uint32_t blocks = (n + 255) / 256, total = n;
+		bool ok = hipMalloc(&counts, sizeof(uint32_t) * 2 * (size_t) n) == hipSuccess;
+		uint32_t* first = counts ? counts + n : NULL;
+		if (ok) {
+			k_count_fragments<<<blocks, 256, 0, stream>>>(p, least_extent, counts);
+			ok = hipcub::DeviceScan::ExclusiveSum(NULL, scan_bytes, counts, first, (int) n, stream) == hipSuccess
+				&& hipMalloc(&scan_storage, scan_bytes ? scan_bytes : 1) == hipSuccess
+				&& hipcub::DeviceScan::ExclusiveSum(scan_storage, scan_bytes, counts, first, (int) n, stream) == hipSuccess;
+		}
+		if (ok) {
+			uint32_t last[2] = {0, 0};
+			ok = hipMemcpyAsync(&last[0], counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess
+				&& hipMemcpyAsync(&last[1], first + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess
+				&& hipStreamSynchronize(stream) == hipSuccess;
+			total = last[0] + last[1];
+		}
+		if (ok && total > n && total < 0x7FFFFFFFu) {
+			// fragment_triangle[total], then fragment_boxes[6 total]
+			ok = hipMalloc(&fragment_memory, sizeof(uint32_t) * (size_t) total + sizeof(float) * 6 * (size_t) total + 16) == hipSuccess;
+			if (ok) {
+				uint32_t* fragment_triangle = (uint32_t*) fragment_memory;
+				float* fragment_boxes = (float*) (fragment_triangle + total);
+				k_write_fragments<<<blocks, 256, 0, stream>>>(p, least_extent, first, fragment_triangle, fragment_boxes);
+				ok = hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
+				if (ok) {
+					p.fragment_triangle = fragment_triangle;
+					p.fragment_boxes = fragment_boxes;
+					p.triangle_count = total;
+				}
+			}
+		}
+		(void) hipFree(scan_storage);
+		(void) hipFree(counts);
+		if (!ok) {
+			printf("Splitting the long thin triangles of the mesh failed; the BVH is built over whole triangles.\n");
+			(void) hipFree(fragment_memory);
+			fragment_memory = NULL;
+			p.fragment_triangle = NULL; p.fragment_boxes = NULL; p.triangle_count = n;
+			(void) hipGetLastError();
+		}
+	}
 	int failed = builder == (int) acceleration_structure_sah_host ? build_sah_on_host(structure, device, mesh, p.pad)
 		: (builder == (int) acceleration_structure_lbvh_device ? build_lbvh_on_device(structure, device, p) : build_sah_on_device(structure, device, p, host_words));
+	(void) hipFree(fragment_memory);
 	if (trace) clock_gettime(CLOCK_MONOTONIC, &phase[0]);
 	if (!failed) {
 		failed = quantize_nodes(structure, device);
@@ -954,6 +1119,7 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	}
 	clock_gettime(CLOCK_MONOTONIC, &end);
 	structure->builder = (uint32_t) builder;
+	structure->leaf_count = (structure->node_count + 1u) / 2u;
 	structure->build_milliseconds = (float) ((double) (end.tv_sec - start.tv_sec) * 1.0e3 + (double) (end.tv_nsec - start.tv_nsec) * 1.0e-6);
 	return 0;
 }
