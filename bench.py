@@ -494,6 +494,7 @@ def run_workload(job, config, role, scene=None):
         r.render(target)
     r.sync()
     kernel_alone_ms = r.shading_kernel_ms(alone_frames)
+    shaft_alone_ms = r.light_shaft_ms(alone_frames)
     pass_alone_ms = r.dispatch_ms(alone_frames)
     kernel_ms = float(np.mean(kernel_alone_ms)) if kernel_alone_ms else float("nan")
     traversal = None
@@ -552,6 +553,7 @@ def run_workload(job, config, role, scene=None):
                 "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms_source": "HIP events around the kernel on its stream, %d frames with one frame at a time (nothing else on the GPU), run right after the timed region" % alone_frames,
                 "pass_alone_ms": round(float(np.mean(pass_alone_ms)), 4) if pass_alone_ms else None,
+                "light_shaft_kernel_ms": round(float(np.mean(shaft_alone_ms)), 4) if (shaft_alone_ms and shafts["pairs"]) else None,
                 "overlapped": {"frames_in_flight": frames_in_flight, "frame_period_ms": round(pass_ms, 4),
                                "kernel_bracket_ms": round(float(np.mean(overlapped_kernel_ms)), 4) if overlapped_kernel_ms else None,
                                "note": "inside the timed region %d frames share the GPU: the bracket of one frame's shade_pixels then spans time in which the other frames' trace and resolve kernels run too, so it can exceed ms_per_step; it is not used for `achieved`" % frames_in_flight},

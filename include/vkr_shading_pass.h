@@ -372,6 +372,9 @@ VKR_API uint32_t get_dispatch_milliseconds(application_t* app, float* out_millis
 /*! Durations of the shading kernel alone (the dominant kernel of the pass) in the most
 	recent `count` timed launches, HIP events on the stream it ran on */
 VKR_API uint32_t get_shading_kernel_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
+/*! Milliseconds a timed frame spends BEFORE its shading kernel starts: the light shaft kernel (and, for a textured
+	scene, the material resolve).  Most recent `count` timed frames, oldest first; returns how many were written. */
+VKR_API uint32_t get_light_shaft_milliseconds(application_t* app, float* out_milliseconds, uint32_t count);
 /*! Time from the end of one timed launch to the end of the next, divided by the number of
 	frames in between (timing_stride): the frame period when frames are submitted back to
 	back, which is what matters with frames in flight, where a launch's own duration

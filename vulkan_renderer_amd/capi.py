@@ -244,6 +244,7 @@ SIGNATURES = {
     "assemble_rgb8_frame_from_slabs": (C.c_int, [P(Application), C.c_void_p, C.c_void_p]),
     "get_traversal_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
     "get_light_shaft_statistics": (C.c_int, [P(Application), P(C.c_uint64)]),
+    "get_light_shaft_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),
     "read_back_light_shafts": (C.c_uint64, [P(Application), C.c_void_p, C.c_uint64]),
     "get_light_shaft_work": (C.c_int, [P(Application), P(C.c_uint64)]),
     "get_dispatch_milliseconds": (C.c_uint32, [P(Application), P(C.c_float), C.c_uint32]),

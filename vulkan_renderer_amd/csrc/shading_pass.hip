@@ -113,6 +113,9 @@ extern "C" int create_render_targets(render_targets_t* targets, const device_t* 
 
 // ---- shading pass ----------------------------------------------------------------
 
+// events of a timed frame: its start, the start and the end of the (last band's) shading kernel, its end
+constexpr uint32_t kTimingEvents = 4;
+
 // device counter of traced shadow rays, shared by all passes of the process
 
 // Buffers of the wavefront ray path, sized for the worst case (every sample of every
@@ -520,7 +523,7 @@ extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* devic
 	destroy_wavefront(pass);
 	if (pass->timing_ring) {
 		hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
-		for (uint32_t i = 0; i != 3 * pass->timing_ring_size; ++i) if (ring[i]) (void) hipEventDestroy(ring[i]);
+		for (uint32_t i = 0; i != kTimingEvents * pass->timing_ring_size; ++i) if (ring[i]) (void) hipEventDestroy(ring[i]);
 		free(ring);
 	}
 	memset(pass, 0, sizeof(*pass));
@@ -595,9 +598,9 @@ static int validate_settings(const application_t* app) {
 static int create_timing_ring(shading_pass_t* pass) {
 	pass->timing_ring_size = 256;
 	// per timed frame: start, end of the shading kernel, end of the frame
-	hipEvent_t* ring = (hipEvent_t*) calloc(3 * pass->timing_ring_size, sizeof(hipEvent_t));
+	hipEvent_t* ring = (hipEvent_t*) calloc(kTimingEvents * pass->timing_ring_size, sizeof(hipEvent_t));
 	pass->timing_ring = ring;
-	for (uint32_t i = 0; i != 3 * pass->timing_ring_size; ++i)
+	for (uint32_t i = 0; i != kTimingEvents * pass->timing_ring_size; ++i)
 		if (hip_failed(hipEventCreateWithFlags(&ring[i], hipEventReleaseToDevice), "creating timing events")) return 1;
 	return 0;
 }
@@ -920,6 +923,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		if (band == 0 && p.ray_counter && hip_failed(hipMemsetAsync(p.ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 		if (upload_constants(app, stream)) return 1;
 		p.constants = (const uint8_t*) pass->constants_device;
+		// (the first event of a timed frame: everything the frame launches lies behind it)
+		if (timed && band == 0) (void) hipEventRecord(ring[kTimingEvents * slot], stream);
 		if (textured && band == 0) {
 			if (g_resolve_launchers[pass->arithmetic_mode](&p, (float*) pass->pixel_materials, stream)) {
 				printf("Launching the material resolve kernel failed.\n");
@@ -927,7 +932,6 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			}
 			p.pixel_materials = (const float*) pass->pixel_materials;
 		}
-		if (timed && band == 0) (void) hipEventRecord(ring[3 * slot], stream);
 		// light shafts: which patches need no shadow rays toward which lights (light_shafts.h).  For the techniques
 		// whose samples aim at the light polygon itself (every ray then lies inside the shaft); the walk uses the
 		// four-wide tree whatever tree the rays walk.
@@ -956,10 +960,12 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			pass->last_shaft_groups = shaft_groups;
 		}
 		else pass->last_shaft_groups = 0;
+		// (the second event of a timed frame: the shading kernel itself begins here, behind the shaft kernel)
+		if (timed && band == 0) (void) hipEventRecord(ring[kTimingEvents * slot + 1], stream);
 		status = error_mode != kErrorNone
 			? g_error_launchers[pass->arithmetic_mode](strategy >= (int) sampling_strategies_diffuse_specular_separately, technique, capacity, error_mode, &p, p.block_count, stream)
 			: g_launchers[pass->arithmetic_mode + (p.light_texture_descriptors ? 3 : 0)][strategy](technique, capacity, ray_mode, &p, p.block_count, stream);
-		if (timed && band + 1 == band_count) (void) hipEventRecord(ring[3 * slot + 1], stream);
+		if (timed && band + 1 == band_count) (void) hipEventRecord(ring[kTimingEvents * slot + 2], stream);
 		if (status == 0 && is_deferred(ray_mode)) {
 			if (pipelined && frame->trace_stream) {
 				// the rest of the launch moves to the high-priority stream; the next launch that reuses this context's
@@ -1018,7 +1024,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		}
 	}
 	if (timed) {
-		(void) hipEventRecord(ring[3 * slot + 2], stream);
+		(void) hipEventRecord(ring[kTimingEvents * slot + 3], stream);
 		++pass->timing_cursor;
 	}
 	if (status < 0) {
@@ -1043,7 +1049,23 @@ extern "C" uint32_t get_dispatch_milliseconds(application_t* app, float* out, ui
 	for (uint32_t i = 0; i != count; ++i) {
 		uint32_t slot = (pass->timing_cursor - count + i) % pass->timing_ring_size;
 		float ms = 0.0f;
-		if (hipEventSynchronize(ring[3 * slot + 2]) != hipSuccess || hipEventElapsedTime(&ms, ring[3 * slot], ring[3 * slot + 2]) != hipSuccess) ms = 0.0f;
+		if (hipEventSynchronize(ring[kTimingEvents * slot + 3]) != hipSuccess || hipEventElapsedTime(&ms, ring[kTimingEvents * slot], ring[kTimingEvents * slot + 3]) != hipSuccess) ms = 0.0f;
+		out[i] = ms;
+	}
+	return count;
+}
+
+// what a timed frame spends before its shading kernel starts: the shaft kernel (and, for textured scenes, the material resolve)
+extern "C" uint32_t get_light_shaft_milliseconds(application_t* app, float* out, uint32_t count) {
+	shading_pass_t* pass = &app->shading_pass;
+	if (!pass->timing_ring) return 0;
+	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
+	uint32_t available = pass->timing_cursor < pass->timing_ring_size ? pass->timing_cursor : pass->timing_ring_size;
+	if (count > available) count = available;
+	for (uint32_t i = 0; i != count; ++i) {
+		uint32_t slot = (pass->timing_cursor - count + i) % pass->timing_ring_size;
+		float ms = 0.0f;
+		if (hipEventSynchronize(ring[kTimingEvents * slot + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[kTimingEvents * slot], ring[kTimingEvents * slot + 1]) != hipSuccess) ms = 0.0f;
 		out[i] = ms;
 	}
 	return count;
@@ -1058,7 +1080,7 @@ extern "C" uint32_t get_shading_kernel_milliseconds(application_t* app, float* o
 	for (uint32_t i = 0; i != count; ++i) {
 		uint32_t slot = (pass->timing_cursor - count + i) % pass->timing_ring_size;
 		float ms = 0.0f;
-		if (hipEventSynchronize(ring[3 * slot + 1]) != hipSuccess || hipEventElapsedTime(&ms, ring[3 * slot], ring[3 * slot + 1]) != hipSuccess) ms = 0.0f;
+		if (hipEventSynchronize(ring[kTimingEvents * slot + 2]) != hipSuccess || hipEventElapsedTime(&ms, ring[kTimingEvents * slot + 1], ring[kTimingEvents * slot + 2]) != hipSuccess) ms = 0.0f;
 		out[i] = ms;
 	}
 	return count;
@@ -1075,7 +1097,7 @@ extern "C" uint32_t get_frame_period_milliseconds(application_t* app, float* out
 		uint32_t later = (pass->timing_cursor - count + i) % pass->timing_ring_size;
 		uint32_t earlier = (later + pass->timing_ring_size - 1) % pass->timing_ring_size;
 		float ms = 0.0f;
-		if (hipEventSynchronize(ring[3 * later + 2]) != hipSuccess || hipEventElapsedTime(&ms, ring[3 * earlier + 2], ring[3 * later + 2]) != hipSuccess) ms = 0.0f;
+		if (hipEventSynchronize(ring[kTimingEvents * later + 3]) != hipSuccess || hipEventElapsedTime(&ms, ring[kTimingEvents * earlier + 3], ring[kTimingEvents * later + 3]) != hipSuccess) ms = 0.0f;
 		out[i] = ms / (float) stride;
 	}
 	return count;

@@ -303,6 +303,11 @@ class Renderer(HostScene):
         n = self.lib.get_shading_kernel_milliseconds(C.byref(self.app), out, count)
         return [float(out[i]) for i in range(n)]
 
+    def light_shaft_ms(self, count):
+        out = (C.c_float * count)()
+        n = self.lib.get_light_shaft_milliseconds(C.byref(self.app), out, count)
+        return [float(out[i]) for i in range(n)]
+
     def frame_period_ms(self, count):
         out = (C.c_float * count)()
         n = self.lib.get_frame_period_milliseconds(C.byref(self.app), out, count)
