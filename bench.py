@@ -62,7 +62,7 @@ def kernel_source_hash():
     # (what the shading, tracing and resolve kernels are compiled from, and the flags; host code - host/*.c,
     # shading_pass.hip around the kernels it instantiates - and the BVH builder do not change what they execute)
     for name in ("shading_kernel.h", "polygon_sampling.h", "related_work.h", "device_math.h", "glibc_math.h", "lbvh.h", "clip_cases.inc",
-                 "wavefront_kernels.h", "shading_variants.hip", "Makefile"):
+                 "wavefront_kernels.h", "light_shafts.h", "shading_variants.hip", "Makefile"):
         h.update(name.encode())
         h.update(open(os.path.join(base, name), "rb").read())
     return h.hexdigest()[:16]

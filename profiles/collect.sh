@@ -14,14 +14,14 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-FILTER="--kernel-include-regex shade_pixels|trace_shadow_rays|resolve_shadow --output-format csv"
+FILTER="--kernel-include-regex shade_pixels|trace_shadow_rays|resolve_shadow|light_shafts --output-format csv"
 for CFG in 2 3; do
 	# the bench command itself (default steps / warm-up, two frames in flight) ...
-	B="python $R/bench.py --config $CFG --mode $MODE --no-cpu-baseline --no-secondary --no-fast-mode"
+	B="python $R/bench.py --config $CFG --mode $MODE --no-cpu-baseline --no-secondary --no-other-modes --no-extra"
 	timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg${CFG}_trace -o trace -- $B > $O/cfg${CFG}_trace.log 2>&1
 	# ... and with one frame at a time: every kernel alone on the GPU
 	timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg${CFG}_serial -o trace -- $B --frames-in-flight 1 --steps 200 --warmup 50 > $O/cfg${CFG}_serial.log 2>&1
-	B="python $R/bench.py --config $CFG --mode $MODE --steps 6 --warmup 2 --prewarm-frames 8 --no-cpu-baseline --no-secondary --no-fast-mode"
+	B="python $R/bench.py --config $CFG --mode $MODE --steps 6 --warmup 2 --prewarm-frames 8 --no-cpu-baseline --no-secondary --no-other-modes --no-extra"
 	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU -d $O/cfg${CFG}_pmc1 -o pmc -- $B > $O/cfg${CFG}_pmc1.log 2>&1
 	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_FLAT SQ_INSTS_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE -d $O/cfg${CFG}_pmc2 -o pmc -- $B > $O/cfg${CFG}_pmc2.log 2>&1
 	timeout 150 rocprofv3 --kernel-trace $FILTER --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/cfg${CFG}_pmc3 -o pmc -- $B > $O/cfg${CFG}_pmc3.log 2>&1

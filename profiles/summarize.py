@@ -140,7 +140,7 @@ def main():
                 else:
                     floor_us = 4 * c.get("SQ_ACTIVE_INST_VALU", total) / 1024.0 / 2400.0
                     lines.append("- VALU issue floor at 4 clocks per instruction: %.1f us" % floor_us)
-                if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel:
+                if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel or "light_shafts" in kernel:
                     valu_floor = traffic.setdefault("config%d_%s_valu_floor_us" % (cfg, kernel_mode(kernel) or run_mode), {})
                     valu_floor[kernel.split("::")[-1].split("<")[0]] = round(floor_us, 2)
                 if "shade_pixels" in kernel and "SQ_INSTS_VALU_FMA_F32" in c:
