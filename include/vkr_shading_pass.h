@@ -232,7 +232,8 @@ typedef struct shading_pass_s {
 	/*! Light shafts (csrc/light_shafts.h): before a launch with wavefront shadow rays one conservative walk of the
 		BVH per 8x8 pixel patch and light finds the pairs whose shadow rays cannot be blocked by anything; their
 		terms are final at once and their rays are never queued.  Results of ray queries - and frames - are
-		unchanged.  Environment VKR_LIGHT_SHAFTS=0 turns it off.  last_shaft_groups: patches of the most recent
+		unchanged.  Environment VKR_LIGHT_SHAFTS: 0 off, 1 on, default automatic - on when a pixel may queue 16 rays
+		or more (samples x techniques x lights), where the walks repay themselves.  last_shaft_groups: patches of the most recent
 		launch that were tested (0: the launch ran without the test); get_light_shaft_statistics() counts. */
 	uint32_t last_shaft_groups, reserved;
 } shading_pass_t;

@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The light shafts of the shading pass (csrc/light_shafts.h) decide by a conservative test which shadow rays need not be
+# traced.  The pass switches them on by itself only where they pay (many rays per pixel); the test-suite forces them on
+# everywhere, so that every parity test against the oracle also checks that no ray was skipped wrongly.
+# (tests/test_gpu_light_shafts.py compares on / off / automatic explicitly.)
+os.environ.setdefault("VKR_LIGHT_SHAFTS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 

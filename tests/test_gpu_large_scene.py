@@ -105,8 +105,11 @@ def test_builders_and_trees_agree_on_the_large_scene(large_dataset, large_oracle
     same_visibility = np.array_equal(r.read_visibility(), large_oracle["visibility"])
     r.close()
     assert same_visibility
-    assert stats["rays"] == large_oracle["rays"] and stats["blocked_rays"] == large_oracle["wide"]["blocked_rays"]
     assert np.array_equal(image.view(np.uint32), large_oracle["image"].view(np.uint32)), int((image != large_oracle["image"]).any(axis=-1).sum())
+    # (how many rays are TRACED depends on the tree since round 4: the light shafts are decided by a conservative walk of
+    # it - csrc/light_shafts.h.  The rays that are blocked are the same whatever tree finds them.)
+    assert stats["blocked_rays"] == large_oracle["wide"]["blocked_rays"]
+    assert abs(stats["rays"] - large_oracle["rays"]) < 0.02 * large_oracle["rays"]
 
 
 def test_primary_visibility_of_the_large_scene_equals_the_oracle_at_full_size(large_oracle):

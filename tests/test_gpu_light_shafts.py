@@ -94,6 +94,22 @@ def test_lights_that_touch_graze_or_surround_the_geometry(monkeypatch, tmp_path)
         assert rays_on <= rays_off
 
 
+def test_shafts_are_automatic_where_they_pay(big_dataset, monkeypatch):
+    """without VKR_LIGHT_SHAFTS in the environment the pass decides: on for config 3 (32 rays per pixel at most), off
+    for config 2 (2 rays per pixel: a walk per patch costs more than its rays)"""
+    monkeypatch.delenv("VKR_LIGHT_SHAFTS", raising=False)
+    for config, expected in ((3, True), (2, False), ("target", False)):
+        r = renderer.Renderer()
+        renderer.setup_config(r, config, big_dataset, width=640, height=360, acceleration_structure="sah_device")
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        r.render()
+        stats = r.light_shaft_statistics()
+        r.close()
+        assert (stats["pairs"] > 0) == expected, (config, stats)
+
+
 def test_techniques_whose_samples_may_miss_the_polygon_are_left_alone(big_dataset, monkeypatch):
     """the shaft holds the rays of techniques that aim at the light polygon; the related-work samplers are not on the list"""
     monkeypatch.setenv("VKR_LIGHT_SHAFTS", "1")

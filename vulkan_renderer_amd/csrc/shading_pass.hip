@@ -195,7 +195,11 @@ struct frame_pipeline {
 	// (default 36864 - config 4 then runs as three bands of 12 GB, the fastest of 1 ... 12 bands, profiles/r04c/: a
 	// frame whose worst case needs more is rendered in bands); VKR_BAND_COUNT forces
 	// the number of bands per frame (0: automatic)
-	// VKR_LIGHT_SHAFTS: 0 turns the shaft test off (every shadow ray is traced, as until round 3); default 1
+	// VKR_LIGHT_SHAFTS: 0 turns the shaft test off (every shadow ray is traced, as until round 3), 1 on; default 2:
+	// on when a pixel may queue 16 rays or more (samples x techniques x lights) - the walk of a patch costs about as
+	// much as tracing 2.5 rays per pixel and light, and it is the patches with many rays per light and several lights
+	// that repay it (measured, profiles/r05m: config 3, 32 rays per pixel, 1.553 -> 1.443 ms; config 4, 128, 25.9 -> 23.0;
+	// the target shape, 8, 0.488 -> 0.500; config 2, 2 rays per pixel, 0.127 -> 0.192)
 	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts;
 };
 
@@ -235,7 +239,7 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 		return NULL;
 	}
 	frames->wide_stack_lds = environment_knob("VKR_WIDE_STACK_LDS", kWideStackLds, 4u, kWideStackLds);
-	frames->light_shafts = environment_knob("VKR_LIGHT_SHAFTS", 1u, 0u, 1u);
+	frames->light_shafts = environment_knob("VKR_LIGHT_SHAFTS", 2u, 0u, 2u);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
@@ -937,7 +941,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		// four-wide tree whatever tree the rays walk.
 		p.shaft_clear = NULL;
 		p.shaft_rectangles = NULL;
-		if (frame && frames->light_shafts && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
+		const uint32_t rays_per_pixel = app->render_settings.sample_count * p.light_count * ((int) app->render_settings.sampling_strategies == (int) sampling_strategies_diffuse_only ? 1u : 2u);
+		if (frame && (frames->light_shafts == 1u || (frames->light_shafts == 2u && rays_per_pixel >= 16u)) && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
 			&& app->scene.acceleration_structure.node_count < (1u << kShaftLightShift)  // (a queue entry of the walk is a node or triangle index and a light)
 			&& (technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueSolidAngle || technique == kTechniqueClippedSolidAngle))
 		{
