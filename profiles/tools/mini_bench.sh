@@ -15,7 +15,7 @@ import json
 try:
     d = json.loads([l for l in open("$O/${LIB}_cfg$CFG.json") if l.startswith("{")][-1])
     s = d["light_shafts"]
-    print("$LIB config $CFG: %.1f Msamples/s, %.4f ms/step, alone %.4f ms (kernel %.4f), rays %d, clear %.3f of %d pairs, not clear %s, work %s, parity %s" % (d["value"], d["ms_per_step"], d["latency_ms"], d["roofline"]["kernel_ms"], d["shadow_rays_per_frame"], s["clear_fraction"], s["patch_light_pairs"], s["not_clear"], s.get("work"), (d.get("parity") or {}).get("vs_libm_oracle", {}).get("pixels_differing_in_bits")))
+    print("$LIB config $CFG: %.1f Msamples/s, %.4f ms/step, alone %.4f ms (shade %.4f, shafts %s), rays %d, clear %.3f of %d pairs, not clear %s, work %s, parity %s" % (d["value"], d["ms_per_step"], d["latency_ms"], d["roofline"]["kernel_ms"], d["roofline"].get("light_shaft_kernel_ms"), d["shadow_rays_per_frame"], s["clear_fraction"], s["patch_light_pairs"], s["not_clear"], s.get("work"), (d.get("parity") or {}).get("vs_libm_oracle", {}).get("pixels_differing_in_bits")))
 except Exception as error:
     print("$LIB config $CFG failed:", error)
 PY

@@ -46,6 +46,19 @@ constexpr uint32_t kShaftLights = 8;                          // lights whose sh
 constexpr uint32_t kShaftLightShift = 27;                     // an entry of the queues: node or triangle | light << 27
 constexpr uint32_t kShaftFrontier = 640;                      // inner nodes waiting (LDS); more -> not clear
 constexpr uint32_t kShaftLeaves = 320;                        // triangles waiting
+// Measured (profiles/r05n, r05o, r05p; config 3 / config 4, shaft kernel alone): test (iii) with all 64 shading positions
+// instead of the corners of their bounding box finds 0.2 % more clear pairs and costs 0.288 instead of 0.173 ms / 0.90
+// instead of 0.80 ms (VKR_SHAFT_ORIGIN_LOOP=1); batches of 16 or 8 triangles instead of 32 cost 0.35 / 0.39 ms, 64 the
+// same as 32; the whole per-light set-up computed by every lane alike instead of four lanes and a dozen wave-wide
+// reductions saves 4 % of the kernel alone but takes 126 instead of 79 registers, and the frame with three of them in
+// flight gets slower (1.441 vs 1.428 ms).
+#ifndef VKR_SHAFT_ORIGIN_LOOP
+#define VKR_SHAFT_ORIGIN_LOOP 0
+#endif
+#ifndef VKR_SHAFT_LEAF_BATCH
+#define VKR_SHAFT_LEAF_BATCH 32
+#endif
+constexpr uint32_t kShaftLeafBatch = VKR_SHAFT_LEAF_BATCH;         // triangles that must wait before a batch of them is tested
 constexpr uint32_t kShaftMaxSteps = 40;                       // steps of 16 nodes (plus 8 per light); more -> not clear
 constexpr float kShaftDilation = 1.0f / 32.0f;
 // Measured and not adopted (profiles/r05h/): cutting every candidate triangle by all planes of the shaft (test (iii) below)
@@ -174,6 +187,7 @@ VKR_DEV bool shaft_triangle_harmless(const shaft_state& s, const shaft_patch& pa
 	if (h_max < 0.0f) { n = -n; float t = h_min; h_min = -h_max; h_max = -t; }
 	if (!(h_min > 4.0f * margin)) return false;
 	// lowest origin above the plane
+#if VKR_SHAFT_ORIGIN_LOOP
 	float g_min = 3.0e38f;
 	uint64_t lanes = patch.valid;
 	while (lanes) {
@@ -183,6 +197,11 @@ VKR_DEV bool shaft_triangle_harmless(const shaft_state& s, const shaft_patch& pa
 		g_min = fminf(g_min, g);
 	}
 	g_min -= margin;
+#else
+	// (the lowest corner of the positions' bounding box: never higher than the lowest position)
+	float g_min = n.x * (patch.centre[0] - a.x) + n.y * (patch.centre[1] - a.y) + n.z * (patch.centre[2] - a.z)
+		- (fabsf(n.x) * patch.half[0] + fabsf(n.y) * patch.half[1] + fabsf(n.z) * patch.half[2]) - margin;
+#endif
 	// the first point of a ray from height g: g + t_min n . u with n . u >= (h_min - g) / reach; grows with g
 	float first = g_min + 1.0e-3f * (h_min - g_min) / s.reach;
 	return g_min <= h_min && first > 2.0f * margin;
@@ -435,7 +454,7 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 				__syncthreads();
 			}
 			// triangles: as soon as a good part of the wave has one, or nothing else is left
-			if (leaf_count >= 32u || (waiting == 0 && leaf_count != 0)) {
+			if (leaf_count >= kShaftLeafBatch || (waiting == 0 && leaf_count != 0)) {
 				uint32_t take = leaf_count < 64u ? leaf_count : 64u;
 				++batches;
 				if (lane < take) {
