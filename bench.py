@@ -782,7 +782,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="do not also measure BASELINE config 4 (3840x2160, 8 spp, 8 lights)")
     ap.add_argument("--mode", default="libm", choices=["libm", "exact", "fast"],
                     help="libm: IEEE arithmetic with glibc's transcendentals, bit-identical to the CPU oracle in the mode that is pinned against the reference shader (default); "
-                         "exact: IEEE arithmetic with polynomial transcendentals, bit-identical to the oracle's polynomial mode; fast: approximate reciprocals + contraction")
+                         "exact: the libm mode with a polynomial arctangent, bit-identical to the oracle's math mode 1 (arithmetic_mode_polynomial of the C-ABI); fast: approximate reciprocals + contraction")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed frame is cut into tiles (default); weak = the frame height grows with N")
     ap.add_argument("--exchange", choices=("rgba32f", "rgb8", "none"), default="rgba32f",
                     help="N > 1: all-gather of the tile slabs per frame as float radiance (default) or as packed RGB8 of the encoded output, then the scatter into the frame on every rank; none leaves every rank's slab in its HBM")
@@ -802,7 +802,7 @@ def main():
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=(1, 2, 3, 4),
                     help="n >= 2: n consecutive frames overlap on the device's frame streams, like the frames of the reference's frame queue, which is as deep as "
-                         "its swapchain (main.c:1498: typically 3).  Default: 3 (config 4 renders its frames in eight bands, whose buffers are what is in flight)")
+                         "its swapchain (main.c:1498: typically 3).  Default: 3 (config 4 renders its frames in three bands, whose buffers are what is in flight)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")
     ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")

@@ -135,3 +135,31 @@ def test_primary_visibility_of_the_benchmark_scene_equals_the_oracle_at_baseline
     cpu = oracle.primary_visibility(inputs["constants"], bvh, width, height, near, far)
     assert (gpu != 0xFFFFFFFF).mean() > 0.3
     assert np.array_equal(gpu, cpu), "%d pixels differ" % int((gpu != cpu).sum())
+
+
+def test_long_thin_triangles_are_split_into_several_leaves_and_nothing_else_changes(large_dataset, large_oracle, big_dataset, monkeypatch):
+    """The device SAH builder cuts triangles that lie diagonally in their boxes (the slats and bars of this scene) into
+    up to 16 leaves with the exact bounds of the triangle inside each slab (csrc/lbvh_build.hip "fragments"): more leaves
+    than triangles here, none on the benchmark scene, the same frame and the same visibility buffer either way, and far
+    fewer triangle tests per ray."""
+    def build(dataset, split):
+        monkeypatch.setenv("VKR_BVH_SPLIT_TRIANGLES", "1" if split else "0")
+        r, image = render(dataset, 3, 1920, 1080)
+        structure = r.app.scene.acceleration_structure
+        out = {"image": image, "visibility": r.read_visibility(), "leaves": int(structure.leaf_count), "triangles": int(r.app.scene.mesh.triangle_count),
+               "nodes": int(structure.node_count), "stats": r.traversal_statistics(True)}
+        r.close()
+        return out
+    split, whole = build(large_dataset, True), build(large_dataset, False)
+    monkeypatch.delenv("VKR_BVH_SPLIT_TRIANGLES")
+    print({k: split[k] for k in ("leaves", "triangles", "nodes")}, split["stats"], whole["stats"])
+    assert whole["leaves"] == whole["triangles"] and whole["nodes"] == 2 * whole["triangles"] - 1
+    assert split["leaves"] > split["triangles"] and split["nodes"] == 2 * split["leaves"] - 1
+    assert split["leaves"] < 1.2 * split["triangles"]  # a few thousand slats and bars, not the whole mesh
+    for frame in (split, whole):
+        assert np.array_equal(frame["image"].view(np.uint32), large_oracle["image"].view(np.uint32))
+        assert np.array_equal(frame["visibility"], large_oracle["visibility"])
+    assert split["stats"]["blocked_rays"] == whole["stats"]["blocked_rays"]
+    assert split["stats"]["triangle_tests"] < 0.5 * whole["stats"]["triangle_tests"]
+    bench = build(big_dataset, True)
+    assert bench["leaves"] == bench["triangles"]
