@@ -15,4 +15,4 @@ print("default", d["value"], d["ms_per_step"], d["latency_ms"], d["shadow_rays_p
 PY
 bash profiles/collect.sh $TAG > $O/collect.log 2>&1; echo "collect rc $?"
 cd $R
-timeout 600 python profiles/tools/predict_scaling.py --tiles 32 --out gpurun_out/$TAG/predicted_scaling > $O/predict.log 2>&1; echo "predict rc $?"; tail -12 $O/predict.log
+timeout 600 python profiles/tools/predict_scaling.py --tiles 32 --configs 4 --out gpurun_out/$TAG/predicted_scaling > $O/predict.log 2>&1; echo "predict rc $?"; tail -12 $O/predict.log
