@@ -56,6 +56,35 @@ def test_large_scene_same_frame(monkeypatch, tmp_path):
     assert stats["pairs"] > 0 and rays_on <= rays_off
 
 
+@pytest.fixture(scope="module")
+def large_dataset(tmp_path_factory):
+    return synthetic.write_dataset(str(tmp_path_factory.mktemp("shafts_large")), seed=4321, ltc_resolution=32, fresnel_count=16, large={})
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_large_scene_from_random_cameras_under_random_lights(large_dataset, monkeypatch, seed):
+    """the scene where a wrong "clear" would show (towers, fences, slats between the floor and the lights; 70 % of the
+    rays blocked), seen from other places than the benchmark's and lit by other polygons than its four quads"""
+    rng = np.random.default_rng(77 + seed)
+    lights = [test_gpu_sweep.random_light(rng, int(rng.integers(3, 8))) for _ in range(int(rng.integers(1, 6)))]
+    while True:
+        position = (float(rng.uniform(-8.0, 8.0)), float(rng.uniform(-8.0, 8.0)), float(rng.uniform(0.3, 4.0)))
+        if math.hypot(position[0] - synthetic.DEFAULT_CAMERA["position"][0], position[1] - synthetic.DEFAULT_CAMERA["position"][1]) > 0.5:
+            break
+    rotation_x, rotation_z, fov = float(rng.uniform(0.25, 0.45) * math.pi), float(rng.uniform(0.0, 2.0) * math.pi), float(rng.uniform(0.2, 0.45) * math.pi)
+
+    def setup(r):
+        renderer.setup_config(r, 3, large_dataset, width=960, height=544, acceleration_structure="sah_device")
+        r.set_camera(position, rotation_x, rotation_z, fov, synthetic.DEFAULT_CAMERA["near"], synthetic.DEFAULT_CAMERA["far"])
+        r.set_lights(lights)
+        r.set_settings(sample_count=1 + seed % 3)
+    on, off, rays_on, rays_off, stats, _ = frames_with_and_without(monkeypatch, setup, frames_in_flight=1 + seed % 2)
+    print(seed, position, stats, rays_on, rays_off)
+    assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), (seed, int((on != off).any(axis=-1).sum()), stats)
+    # (a camera that looks down always sees the floor: a case without rays would test nothing)
+    assert rays_on <= rays_off and rays_off > 0 and stats["pairs"] > stats["not_clear"]["no_shaded_pixel"]
+
+
 @pytest.mark.parametrize("seed", [s for s in range(60) if test_gpu_sweep.random_case(s)["rays"]][:24])
 def test_random_configurations_same_frame(seed, monkeypatch, tmp_path_factory):
     dataset = synthetic.write_dataset(str(tmp_path_factory.mktemp("shafts_sweep")), **golden_cases.DATASET)

@@ -126,6 +126,9 @@ constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == k
 // (kCodePendingHiddenNaN: the value of the blocked term is not stored because it can only be NaN - every
 // estimator but the plain optimal MIS heuristic computes it as 0 x something, i.e. +-0 or NaN, and a NaN
 // in any channel sends the whole pixel to the shader's NaN guard, shading_pass.frag.glsl:861-864)
+#ifndef VKR_SUM_FINAL_TERMS
+#define VKR_SUM_FINAL_TERMS 1
+#endif
 enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5, kCodePendingHiddenNaN = 6 };
 // Byte index of code `cursor` of thread `tid`: four consecutive codes of a thread share one 32-bit
 // word ([cursor / 4][thread] words), so that the resolve kernel fetches four codes per load and can
@@ -741,6 +744,14 @@ struct pixel_context {
 	bool light_clear;
 	uint32_t light_index;
 	uint32_t queue;
+	// deferred mode, clear lights: as long as no term of the light is in the stream (`leading`), the terms that need no
+	// ray are added up as they come - the resolve kernel would add them one after the other to its sum of the light, which
+	// is still +0, and 0 + ((0 + t1) + t2) is the same bits as (0 + t1) + t2 - and go to the stream as ONE final term when
+	// a term with a ray comes up or the light ends: a light whose shaft is clear sends one term per pixel to the resolve
+	// kernel instead of 2 S.  (After the first term with a ray the sum is no longer +0, and (s + t1) + t2 is not
+	// s + (t1 + t2): later final terms are written one by one.)
+	f3 final_sum;
+	uint32_t final_state;  // bit 0: final_sum holds terms, bit 1: leading (one word: two bools ended up in scratch memory)
 	// this thread's column of the LDS tables of the prepared polygons (strategies with two
 	// techniques per light: 2 x kPsaTableSlots(V) slots, [slot][thread]), else NULL
 	float2* psa_tables;
@@ -854,6 +865,22 @@ VKR_DEV bool shaft_holds_ray(const shade_params& p, uint32_t light_index, const 
 // Adds one estimator term to the per-light sum.  `visible_term` is the value of the
 // term if the shadow ray reaches the light (or, without a candidate ray, simply the
 // value), `hidden_term` the value if it is blocked.
+// writes the sum of the final terms seen so far as one term of the stream
+VKR_DEV void flush_final_sum(pixel_context& ctx) {
+	const shade_params& p = ctx.p;
+	if (ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
+		if (ctx.noise) settle_noise(*ctx.noise);
+		size_t term_index = ((size_t) ctx.term_cursor * p.thread_count + ctx.tid) * 3;
+		p.codes[code_slot(p.thread_count, ctx.code_cursor, ctx.tid)] = (uint8_t) kCodeFinal;
+		p.terms_visible[term_index] = ctx.final_sum.x; p.terms_visible[term_index + 1] = ctx.final_sum.y; p.terms_visible[term_index + 2] = ctx.final_sum.z;
+		++ctx.code_cursor;
+		++ctx.term_cursor;
+		ctx.light_has_terms = true;
+	}
+	ctx.final_sum = mk3(0.0f, 0.0f, 0.0f);
+	ctx.final_state &= ~1u;
+}
+
 template <int RAYS>
 VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visible_term, f3 hidden_term, f3 dir, const shading_data& sd, const light_ref& light) {
 	if constexpr (RAYS == kRaysNone) {
@@ -878,6 +905,19 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		if (ctx.light_clear && candidate) arrives = shaft_holds_ray(p, ctx.light_index, light, sd.position, dir);
 		bool needs_ray = candidate && !arrives && (hidden_matters || !all_zero(visible_term));
 		bool is_final = (!candidate || arrives) && !all_zero(visible_term);
+#if VKR_SUM_FINAL_TERMS
+		if (ctx.light_clear && (ctx.final_state & 2u)) {
+			if (is_final) {
+				ctx.final_sum = ctx.final_sum + visible_term;
+				ctx.final_state |= 1u;
+				return;
+			}
+			if (needs_ray) {
+				if (ctx.final_state & 1u) flush_final_sum(ctx);
+				ctx.final_state = 0u;
+			}
+		}
+#endif
 		if ((needs_ray || is_final) && ctx.term_cursor < p.max_terms && ctx.code_cursor + 2 < p.max_codes) {
 			if (ctx.noise) settle_noise(*ctx.noise);
 			size_t code_index = code_slot(p.thread_count, ctx.code_cursor, ctx.tid);
@@ -1422,6 +1462,10 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 	}
 	if constexpr (is_deferred(RAYS)) {
 		// close this light's run of terms; the resolve kernel scales by 1 / S and adds it
+#if VKR_SUM_FINAL_TERMS
+		if (ctx.light_clear && (ctx.final_state & 1u)) flush_final_sum(ctx);
+		ctx.final_state = 2u;
+#endif
 		if (ctx.light_has_terms && ctx.code_cursor + 1 < p.max_codes) {
 			if (ctx.noise) settle_noise(*ctx.noise);
 			p.codes[code_slot(p.thread_count, ctx.code_cursor, ctx.tid)] = (uint8_t) kCodeEndOfLight;
@@ -1518,7 +1562,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
-	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, queue, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, queue, mk3(0.0f, 0.0f, 0.0f), 2u, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		lds_state_word* state = ray_block_state();
