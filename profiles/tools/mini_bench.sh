@@ -6,7 +6,7 @@ set -u
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 for LIB in "$@"; do
-	for CFG in 3 4; do
+	for CFG in ${CFGS:-3 4}; do
 		EXTRA="--no-secondary --no-extra --no-other-modes"
 		[ $CFG = 4 ] && EXTRA="$EXTRA --no-cpu-baseline --steps 40 --warmup 5"
 		VKR_SHADING_LIBRARY=$(pwd)/vulkan_renderer_amd/libvkr_mini_$LIB.so timeout 300 python bench.py --config $CFG $EXTRA > $O/${LIB}_cfg$CFG.json 2> $O/${LIB}_cfg$CFG.err
