@@ -597,8 +597,9 @@ def run_workload(job, config, role, scene=None):
                    "arithmetic": args.mode, "bands_per_frame": bands_per_frame, "frames_in_flight": frames_in_flight},
         "prewarm_frames": prewarm, "host_issue_ms_per_step": round(issue_seconds / steps * 1e3, 4),
         "shadow_rays_per_frame": rays, "Mrays_per_s": round(rays / (ms_per_step * 1e-3) / 1e6, 2) if rays else 0.0,
-        "light_shafts": {"patch_light_pairs": shafts["pairs"], "clear_pairs": shafts["clear_pairs"], "clear_fraction": round(shafts["clear_pairs"] / max(shafts["pairs"], 1), 4), "not_clear": shafts["not_clear"], "work": shafts["work"],
-                         "note": "csrc/light_shafts.h: (8x8 pixel patch, light) pairs of the last launch whose shadow rays cannot be blocked (one conservative BVH walk per pair); their rays are not queued - shadow_rays_per_frame counts the rays that were traced; VKR_LIGHT_SHAFTS=0 traces them all; frames are bit-identical either way (tests/test_gpu_light_shafts.py)"},
+        "light_shafts": {"patch_light_pairs": shafts["pairs"], "clear_pairs": shafts["clear_pairs"], "clear_fraction": round(shafts["clear_pairs"] / max(shafts["pairs"], 1), 4), "occluder_list_pairs": shafts["list_pairs"], "triangles_per_occluder_list": round(shafts["listed_triangles"] / max(shafts["list_pairs"], 1), 2),
+                         "not_clear": shafts["not_clear"], "work": shafts["work"],
+                         "note": "csrc/light_shafts.h: one conservative BVH walk per (8x8 pixel patch, light) pair of the last launch; clear_pairs: no shadow ray of the pair can be blocked, none is queued; occluder_list_pairs: its rays can only meet the (at most 12) triangles of a list, and the shading kernel decides them against that list with the tracing kernel's triangle test; not_clear: the rays are queued and traced - shadow_rays_per_frame counts those; VKR_LIGHT_SHAFTS=0 traces all rays, VKR_SHAFT_LISTS=0 all but the clear pairs'; frames are bit-identical either way (tests/test_gpu_light_shafts.py)"},
         "setup": {"load_and_upload_ms": round(load_ms - structure.build_milliseconds, 2), "bvh_build_ms": round(float(structure.build_milliseconds), 3),
                   "bvh_builder": renderer.BVH_BUILDER_NAME[int(structure.builder)], "bvh_node_bytes": 16 * int(structure.node_count) + 64 * int(structure.wide_node_count),
                   "bvh_wide_nodes": int(structure.wide_node_count), "bvh_stack_need": int(structure.wide_stack_need), "visibility_pass_ms": round(visibility_ms, 3), "first_visibility_pass_ms": round(first_visibility_ms, 3),

@@ -230,10 +230,12 @@ typedef struct shading_pass_s {
 		arithmetic_mode.  last_band_count: what the most recent frame used. */
 	uint32_t band_count, last_band_count;
 	/*! Light shafts (csrc/light_shafts.h): before a launch with wavefront shadow rays one conservative walk of the
-		BVH per 8x8 pixel patch and light finds the pairs whose shadow rays cannot be blocked by anything; their
-		terms are final at once and their rays are never queued.  Results of ray queries - and frames - are
-		unchanged.  Environment VKR_LIGHT_SHAFTS: 0 off, 1 on, default automatic - on when a pixel may queue 16 rays
-		or more (samples x techniques x lights), where the walks repay themselves.  last_shaft_groups: patches of the most recent
+		BVH per 8x8 pixel patch and light finds the pairs whose shadow rays cannot be blocked by anything - their
+		terms are final at once and their rays are never queued - and the pairs whose rays can only meet a handful of
+		triangles (an occluder list, at most 12): the shading kernel decides those rays itself, with the tracing kernel's
+		triangle test.  Results of ray queries - and frames - are unchanged.  Environment VKR_LIGHT_SHAFTS: 0 off, 1 on,
+		default automatic - on when a pixel may queue 8 rays or more (samples x techniques x lights), where the walks
+		repay themselves; VKR_SHAFT_LISTS=0: no occluder lists.  last_shaft_groups: patches of the most recent
 		launch that were tested (0: the launch ran without the test); get_light_shaft_statistics() counts. */
 	uint32_t last_shaft_groups, reserved;
 } shading_pass_t;
@@ -391,13 +393,15 @@ VKR_API uint64_t get_last_ray_count(const application_t* app);
 	groups of 64 rays of the longest ray's visits), longest ray's visits}.  0 on success. */
 VKR_API int get_traversal_statistics(application_t* app, uint64_t out_statistics[6]);
 /*! Light shafts of the most recent launch: {(patch, light) pairs tested, pairs found clear - no shadow ray queued
-	for them -, patches, lights, then the pairs that are not clear by reason: patch without a shaded pixel, light and
-	patch do not form a shaft (light behind the patch, seen edge-on, too close), walk too long, queue full, a triangle
-	in the way, other}; all zero when the launch ran without the shaft test.  0 on success. */
-VKR_API int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[10]);
+	for them -, patches, lights, then the pairs whose rays are traced by reason: patch without a shaded pixel, light and
+	patch do not form a shaft (light behind the patch, seen edge-on, too close), walk too long, queue full, too many
+	triangles in the way, other; then the pairs with an occluder list - their rays are decided by the shading kernel -
+	and the triangles on those lists}; all zero when the launch ran without the shaft test.  0 on success. */
+VKR_API int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[12]);
 /*! (diagnostics) The verdicts themselves, one word per patch and light ([patch][light]; patches in the order of the
-	shading workgroups): the low byte is 1 = clear or 16 ... 20 = the reasons above; with 20 (a triangle in the way) bits
-	8 ... 31 name one such triangle (its index in the mesh, if below 2^24).  Returns the number of words written. */
+	shading workgroups): the low byte is 1 = clear, 2 = occluder list (bits 8 ... 12: its length) or 16 ... 20 = the
+	reasons above; with 20 (triangles in the way) bits 8 ... 31 name one such triangle (its index in the mesh, if below
+	2^24).  Returns the number of words written. */
 VKR_API uint64_t read_back_light_shafts(application_t* app, uint32_t* out_words, uint64_t capacity);
 /*! (diagnostics, only with VKR_SHAFT_COUNTERS=1 in the environment) work of the shaft kernel of the most recent
 	launch: {steps of its walks (16 nodes each), batches of triangles, walks}.  0 on success. */

@@ -57,10 +57,9 @@ struct bvh_view {
 // and all comparisons are mirrored for det < 0.  No face culling unless CULL_BACK
 // (then triangles whose normal (v1-v0)x(v2-v0) points along the ray are rejected).
 // `dist` (only needed by the closest-hit query) is T / det.
+// (the test proper, on a vertex and the two edges that leave it - what an occluder list of light_shafts.h stores)
 template <bool CULL_BACK>
-VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_min, float t_max, float& dist) {
-	f3 e1 = mk3(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
-	f3 e2 = mk3(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z);
+VKR_DEV bool ray_triangle_edges(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float t_max, float& dist) {
 	f3 p = cross(d, e2);
 	float det = dot(e1, p);
 	if (CULL_BACK ? !(det > 0.0f) : !(det != 0.0f)) return false;
@@ -76,6 +75,12 @@ VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_m
 	if (!(T >= t_min * adet && T <= t_max * adet)) return false;
 	if (CULL_BACK) dist = T / adet;
 	return true;
+}
+template <bool CULL_BACK>
+VKR_DEV bool ray_triangle(float4 p0, float4 p1, float4 p2, f3 o, f3 d, float t_min, float t_max, float& dist) {
+	f3 e1 = mk3(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
+	f3 e2 = mk3(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z);
+	return ray_triangle_edges<CULL_BACK>(mk3(p0.x, p0.y, p0.z), e1, e2, o, d, t_min, t_max, dist);
 }
 
 // A ray in the grid space of the quantised boxes: t = plane * inv + shift

@@ -10,8 +10,8 @@
 // instead of queueing their rays (accumulate(), shading_kernel.h).  The result of every ray query is unchanged:
 // "clear" is only ever claimed when no triangle can be hit, with margins that cover the rounding of the kernels
 // that would have traced the rays, so frames stay bit-identical (tests/test_gpu_light_shafts.py renders them
-// with and without).  What it buys depends on the scene: 83 % of the lit (patch, light) pairs of the benchmark
-// scene at config 3 are clear, 7 % of the large scene's (profiles/).
+// with and without).  What it buys depends on the scene: at config 3 the benchmark scene is left with 1.6 M of its
+// 28.8 M rays to trace, the large scene - slats and fences between every patch and every light - with 21.8 of 22.2 M.
 //
 // Which rays a shaft holds.  Samples aim at the polygon, but where the sampling breaks down numerically (a polygon that
 // is a sliver in the space it is sampled in: seed 6 of the random sweep has a specular sample 2.5 degrees off a light
@@ -35,6 +35,16 @@
 //        every ray's first point o + t_min u (t_min = 1e-3, the ray query's) does too - which is what lets a
 //        patch see past the very surface it lies on.
 // Anything else - also a walk that gets long or a queue that fills up - means "trace the rays".
+//
+// Occluder lists.  A walk that meets a triangle it cannot rule out goes on and collects such triangles, up to kShaftListMax.
+// If it reaches its end, the list is complete: every triangle of the scene is either on it or cannot be hit by a ray that
+// the shaft holds.  The shading kernel then decides each such ray itself - ray_triangle_edges() of lbvh.h, the function
+// the tracing kernels call at their leaves, with the same origin, direction and interval, on the vertex and the two
+// edges that the list stores (computed here as ray_triangle computes them) - and the ray query's answer "some triangle is
+// hit" is the OR over the list.  (Both directions rest on margins that cover rounding: the walk must not drop a triangle that
+// the tracing kernel would report - the margins of the tests above -, and the tracing kernel must not cull a triangle
+// that its own triangle test accepts - its boxes are rounded outwards, lbvh.h kGridMargin.)  Around occluders most pairs
+// end this way: config 3 of the benchmark scene 85 % of the pairs that are not clear, 4.3 triangles on average.
 #pragma once
 #include "shading_kernel.h"
 
@@ -67,6 +77,10 @@ constexpr float kShaftDilation = 1.0f / 32.0f;
 #ifndef VKR_SHAFT_CLIPPING
 #define VKR_SHAFT_CLIPPING 0
 #endif
+// Occluder lists (above).  Measured (profiles/r05zg, frame period of config 3 / config 4 with kShaftListMax = 4, 6, 8, 12,
+// 16; none: 1.400 / 22.6 ms): 1.304 / 21.06, 1.240 / 20.15, 1.217 / 19.41, 1.187 / 19.01, 1.192 / 18.87 ms - a triangle
+// test costs a twelfth of what tracing the ray costs, and the walks that give up do so a little later.
+// (kShaftListMax, VKR_SHAFT_LIST: shading_kernel.h)
 
 // what the walk needs to know about one (patch, light), wave-uniform, in LDS
 struct shaft_state {
@@ -83,7 +97,8 @@ struct shaft_state {
 };
 
 // why a pair is not clear (the word that the shading kernel reads is 1 for clear pairs and one of these otherwise)
-enum { kShaftClear = 1, kShaftNoPixels = 16, kShaftGeometry = 17, kShaftTooLong = 18, kShaftQueueFull = 19, kShaftTriangle = 20 };
+// (kShaftList: bits 8 ... 12 hold the number of triangles on the pair's list)
+enum { kShaftClear = 1, kShaftList = 2, kShaftNoPixels = 16, kShaftGeometry = 17, kShaftTooLong = 18, kShaftQueueFull = 19, kShaftTriangle = 20 };
 
 struct shaft_patch {
 	float origin[64][3];
@@ -234,12 +249,17 @@ VKR_DEV f3 shaft_rectangle_corner(const light_ref& light, float4 rectangle, uint
 // `b` numbers the workgroups like shade_pixels does (one 8x8 patch each); out_clear[b * light_count + i] = 1 when no
 // ray of that patch toward light i can be blocked.  extent: largest coordinate difference of the scene (margins).
 // work_counters (diagnostics, may be NULL): [0] steps of the walks, [1] batches of triangles, [2] walks
-__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float4* __restrict__ out_rectangles, float extent, unsigned long long* work_counters) {
+// out_lists (may be NULL: then a walk ends at the first triangle in the way): kShaftListMax entries of kShaftListEntry
+// floats per (patch, light), in the order of out_clear - a vertex of the triangle and the two edges that leave it.
+__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float4* __restrict__ out_rectangles, float* __restrict__ out_lists, float extent, unsigned long long* work_counters) {
 	__shared__ shaft_patch patch;
 	__shared__ shaft_state shafts[kShaftLights];
 	__shared__ uint32_t frontier[kShaftFrontier];
 	__shared__ uint32_t leaves[kShaftLeaves];
 	__shared__ uint32_t failed_lights, failed_triangle[kShaftLights];
+	__shared__ uint32_t listed_count[kShaftLights];
+	__shared__ uint32_t list_count[kShaftLights], list_slot[kShaftLights][kShaftListMax ? kShaftListMax : 1], list_triangle[kShaftLights][kShaftListMax ? kShaftListMax : 1];
+	const uint32_t list_capacity = out_lists ? kShaftListMax : 0u;
 	const uint32_t lane = threadIdx.x;
 	const uint32_t b = blockIdx.x;
 	const uint32_t local_block = ((b >> 5) << 3) | (b & 7u);
@@ -409,6 +429,7 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 			}
 			failed_lights = 0u;
 		}
+		if (lane < kShaftLights) list_count[lane] = 0u;
 		waiting = (uint32_t) __popc(alive);
 		__syncthreads();
 		// ---- the walk ----------------------------------------------------------------------------------------------
@@ -464,10 +485,19 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 						const float4* t = p.bvh.triangles + 3 * (size_t) (entry & ((1u << kShaftLightShift) - 1u));
 						float4 a = t[0], bq = t[1], cq = t[2];
 						if (!shaft_triangle_harmless(shafts[k], patch, mk3(a.x, a.y, a.z), mk3(bq.x, bq.y, bq.z), mk3(cq.x, cq.y, cq.z), margin)) {
-							atomicOr(&failed_lights, 1u << k);
-							// (diagnostics: bits 8 ... 31 of the verdict name one triangle that is in the way, if its index fits)
 							uint32_t which = __float_as_uint(a.w);
-							failed_triangle[k] = which < (1u << 24) ? which << 8 : 0u;
+							// onto the pair's list, if there is room left (a triangle cut into several leaves comes up several times:
+							// sorted out at the end)
+							uint32_t position = list_capacity ? atomicAdd(&list_count[k], 1u) : 0u;
+							if (position < list_capacity) {
+								list_slot[k][position] = entry & ((1u << kShaftLightShift) - 1u);
+								list_triangle[k][position] = which;
+							}
+							else {
+								atomicOr(&failed_lights, 1u << k);
+								// (diagnostics: bits 8 ... 31 of the verdict name one triangle that is in the way, if its index fits)
+								failed_triangle[k] = which < (1u << 24) ? which << 8 : 0u;
+							}
 						}
 					}
 				}
@@ -477,11 +507,45 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 			}
 		}
 		__syncthreads();
+		// ---- the lists, one lane per entry (a triangle that was cut into several leaves came up
+		// several times: the first one counts) -------------------------------------------------------------------------
+		static_assert(kShaftListMax <= 16, "the verdict has five bits for the length of a list");
+		if (list_capacity) {
+			const uint32_t given_up = failed_lights | too_long | queue_full;
+			if (lane < kShaftLights) listed_count[lane] = 0u;
+			__syncthreads();
+			for (uint32_t entry = lane; entry < kShaftLights * kShaftListMax; entry += 64u) {
+				const uint32_t k = entry / (kShaftListMax ? kShaftListMax : 1u), j = entry % (kShaftListMax ? kShaftListMax : 1u);
+				bool mine = k < chunk_lights && ((walked >> k) & 1u) && !((given_up >> k) & 1u) && j < list_count[k];
+				uint32_t before = 0;
+				if (mine) {
+					for (uint32_t i = 0; i < j; ++i) {
+						bool first = true;
+						for (uint32_t h = 0; h < i; ++h) first = first && list_triangle[k][h] != list_triangle[k][i];
+						before += first ? 1u : 0u;
+						mine = mine && list_triangle[k][i] != list_triangle[k][j];
+					}
+				}
+				if (mine) {
+					const float4* t = p.bvh.triangles + 3 * (size_t) list_slot[k][j];
+					float4 a = t[0], bq = t[1], cq = t[2];
+					float4* out = (float4*) (out_lists + (((size_t) b * p.light_count + chunk + k) * kShaftListMax + before) * kShaftListEntry);
+					// (the edges as ray_triangle computes them, lbvh.h)
+					out[0] = make_float4(a.x, a.y, a.z, a.w);
+					out[1] = make_float4(bq.x - a.x, bq.y - a.y, bq.z - a.z, 0.0f);
+					out[2] = make_float4(cq.x - a.x, cq.y - a.y, cq.z - a.z, 0.0f);
+					atomicAdd(&listed_count[k], 1u);
+				}
+			}
+			__syncthreads();
+		}
 		if (lane < chunk_lights && ((walked >> lane) & 1u)) {
 			uint32_t verdict = kShaftClear;
+			uint32_t listed = list_capacity ? listed_count[lane] : 0u;
 			if ((failed_lights >> lane) & 1u) verdict = kShaftTriangle | failed_triangle[lane];
 			else if ((too_long >> lane) & 1u) verdict = kShaftTooLong;
 			else if ((queue_full >> lane) & 1u) verdict = kShaftQueueFull;
+			else if (listed != 0u) verdict = kShaftList | (listed << 8);
 			clear[chunk + lane] = verdict;
 		}
 		if (lane == 0 && work_counters && walked) {

@@ -92,6 +92,9 @@ struct shade_params {
 	// ... and per light the rectangle (u_min, v_min, u_max, v_max in the light's plane space) that the shafts were built
 	// around: only a ray that meets the light's plane inside it may skip the tracing (shaft_holds_ray)
 	const float4* shaft_rectangles;
+	// ... and per pair whose verdict is kShaftList the triangles that its rays may meet: kShaftListMax entries of
+	// kShaftListEntry floats each (a vertex and the two edges that leave it, as ray_triangle computes them); NULL: no lists
+	const float* shaft_lists;
 	// first 16x16 pixel block of this launch in the rank's schedule (a frame may be rendered as
 	// several launches, "bands", each with wavefront buffers of its own size)
 	uint32_t first_block, block_count;
@@ -126,6 +129,19 @@ constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == k
 // (kCodePendingHiddenNaN: the value of the blocked term is not stored because it can only be NaN - every
 // estimator but the plain optimal MIS heuristic computes it as 0 x something, i.e. +-0 or NaN, and a NaN
 // in any channel sends the whole pixel to the shader's NaN guard, shading_pass.frag.glsl:861-864)
+// triangles on the occluder list of a (patch, light) pair (light_shafts.h); 0: no lists
+#ifndef VKR_SHAFT_LIST
+#define VKR_SHAFT_LIST 12
+#endif
+constexpr uint32_t kShaftListMax = VKR_SHAFT_LIST;
+constexpr uint32_t kShaftListEntry = 12;  // floats of a list entry: p0, e1, e2, each padded to four
+// (not in the fast mode: its translation units contract a b + c into fused operations, the tracing kernel's do not, and
+// the list test must be the tracing kernel's test to the bit)
+#if VKR_FAST_MATH
+constexpr bool kUseShaftLists = false;
+#else
+constexpr bool kUseShaftLists = kShaftListMax != 0u;
+#endif
 #ifndef VKR_SUM_FINAL_TERMS
 #define VKR_SUM_FINAL_TERMS 1
 #endif
@@ -743,6 +759,9 @@ struct pixel_context {
 	// wave-uniform), and the number of that light
 	bool light_clear;
 	uint32_t light_index;
+	// ... or only this pair's list of triangles can (list_count of them, wave-uniform; 0: nothing can)
+	uint32_t list_count;
+	const float* list;
 	uint32_t queue;
 	// deferred mode, clear lights: as long as no term of the light is in the stream (`leading`), the terms that need no
 	// ray are added up as they come - the resolve kernel would add them one after the other to its sum of the light, which
@@ -899,16 +918,31 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 		// Adding +-0 never changes the running sum (it starts at +0), so such terms are
 		// dropped; everything else is written in program order.
 		const shade_params& p = ctx.p;
-		// (a ray inside a shaft that is clear would arrive: its term is the visible one, right away)
+		// (a ray inside a shaft that is clear would arrive: its term is the visible one, right away; a ray inside a shaft
+		// with an occluder list meets those triangles or none: decided here, by the tracing kernel's own triangle test)
 		bool hidden_matters = !all_zero(hidden_term);
-		bool arrives = false;
-		if (ctx.light_clear && candidate) arrives = shaft_holds_ray(p, ctx.light_index, light, sd.position, dir);
-		bool needs_ray = candidate && !arrives && (hidden_matters || !all_zero(visible_term));
-		bool is_final = (!candidate || arrives) && !all_zero(visible_term);
+		bool arrives = false, blocked = false;
+		if (ctx.light_clear && candidate && shaft_holds_ray(p, ctx.light_index, light, sd.position, dir)) {
+			if (ctx.list_count != 0u) {
+				float max_t = divide(-plane_distance(light, sd.position), dot(dir, plane_normal(light)));
+				for (uint32_t j = 0; j != ctx.list_count; ++j) {
+					constant_float_pointer t = (constant_float_pointer) (uintptr_t) (ctx.list + kShaftListEntry * j);
+					float dist;
+					blocked = blocked || ray_triangle_edges<false>(mk3(t[0], t[1], t[2]), mk3(t[4], t[5], t[6]), mk3(t[8], t[9], t[10]), sd.position, dir, 1.0e-3f, max_t, dist);
+				}
+			}
+			arrives = !blocked;
+		}
+		// what a blocked ray leaves of its term: nothing, the hidden value, or - without a buffer for hidden values - NaN
+		// (kCodePendingHiddenNaN above)
+		f3 value = visible_term;
+		if (blocked) value = !hidden_matters ? mk3(0.0f, 0.0f, 0.0f) : (p.terms_hidden ? hidden_term : mk3(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")));
+		bool needs_ray = candidate && !arrives && !blocked && (hidden_matters || !all_zero(visible_term));
+		bool is_final = (!candidate || arrives || blocked) && !all_zero(value);
 #if VKR_SUM_FINAL_TERMS
 		if (ctx.light_clear && (ctx.final_state & 2u)) {
 			if (is_final) {
-				ctx.final_sum = ctx.final_sum + visible_term;
+				ctx.final_sum = ctx.final_sum + value;
 				ctx.final_state |= 1u;
 				return;
 			}
@@ -924,7 +958,7 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 			size_t term_index = ((size_t) ctx.term_cursor * p.thread_count + ctx.tid) * 3;
 			// (terms_hidden exists for the one estimator whose blocked terms have values, the optimal heuristic)
 			p.codes[code_index] = (uint8_t) (is_final ? kCodeFinal : (hidden_matters ? (p.terms_hidden ? kCodePendingWithHidden : kCodePendingHiddenNaN) : kCodePending));
-			p.terms_visible[term_index] = visible_term.x; p.terms_visible[term_index + 1] = visible_term.y; p.terms_visible[term_index + 2] = visible_term.z;
+			p.terms_visible[term_index] = value.x; p.terms_visible[term_index + 1] = value.y; p.terms_visible[term_index + 2] = value.z;
 			if (needs_ray && hidden_matters && p.terms_hidden) {
 				p.terms_hidden[term_index] = hidden_term.x; p.terms_hidden[term_index + 1] = hidden_term.y; p.terms_hidden[term_index + 2] = hidden_term.z;
 			}
@@ -1562,7 +1596,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
-	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, queue, mk3(0.0f, 0.0f, 0.0f), 2u, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, 0u, nullptr, queue, mk3(0.0f, 0.0f, 0.0f), 2u, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		lds_state_word* state = ray_block_state();
@@ -1604,7 +1638,12 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 			for (uint32_t i = 0; i != p.light_count; ++i) {
 				light_ref light = get_light(p, i);
 				if constexpr (is_deferred(RAYS)) {
-					ctx.light_clear = p.shaft_clear != nullptr && *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) == 1u;
+					// the verdict of the shaft walk (light_shafts.h): 1 clear, 2 | n << 8 a list of n triangles, else trace
+					uint32_t verdict = p.shaft_clear != nullptr ? *(constant_uint_pointer) (uintptr_t) (p.shaft_clear + ((size_t) b * p.light_count + i)) : 0u;
+					bool listed = kUseShaftLists && (verdict & 0xFFu) == 2u && p.shaft_lists != nullptr;
+					ctx.light_clear = verdict == 1u || listed;
+					ctx.list_count = listed ? ((verdict >> 8) & 0x1Fu) : 0u;
+					ctx.list = p.shaft_lists + ((size_t) b * p.light_count + i) * (kShaftListMax * kShaftListEntry);
 					ctx.light_index = i;
 				}
 				color = color + evaluate_light<STRATEGY, TECHNIQUE, V, RAYS, ERROR>(ctx, sd, ltc, light, noise);

@@ -145,6 +145,9 @@ struct wavefront_buffers {
 	// ... and per light the plane-space rectangle that the shading kernel tests its rays against
 	float4* shaft_rectangles;
 	uint32_t shaft_rectangle_count;
+	// ... and per pair kShaftListMax triangle slots: the occluder lists (VKR_SHAFT_LISTS)
+	float* shaft_lists;
+	size_t shaft_list_words;
 };
 
 static void free_wavefront_buffers(wavefront_buffers* w) {
@@ -153,6 +156,7 @@ static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->spill);
 	(void) hipFree(w->shaft_clear);
 	(void) hipFree(w->shaft_rectangles);
+	(void) hipFree(w->shaft_lists);
 	memset(w, 0, sizeof(*w));
 }
 
@@ -200,7 +204,7 @@ struct frame_pipeline {
 	// much as tracing 2.5 rays per pixel and light, and it is the patches with many rays per light and several lights
 	// that repay it (measured, profiles/r05m: config 3, 32 rays per pixel, 1.553 -> 1.443 ms; config 4, 128, 25.9 -> 23.0;
 	// the target shape, 8, 0.488 -> 0.500; config 2, 2 rays per pixel, 0.127 -> 0.192)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts;
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts, shaft_lists;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -240,6 +244,8 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	}
 	frames->wide_stack_lds = environment_knob("VKR_WIDE_STACK_LDS", kWideStackLds, 4u, kWideStackLds);
 	frames->light_shafts = environment_knob("VKR_LIGHT_SHAFTS", 2u, 0u, 2u);
+	// VKR_SHAFT_LISTS=0: a shaft walk ends at the first triangle in the way (no occluder lists, light_shafts.h)
+	frames->shaft_lists = environment_knob("VKR_SHAFT_LISTS", 1u, 0u, 1u);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
@@ -274,7 +280,17 @@ static uint32_t ray_block_size(uint32_t max_terms) {
 	return max_terms >= 8 ? slots : 0u;
 }
 
-static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light_count) {
+static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light_count, bool lists) {
+	size_t list_words = lists ? words * kShaftListMax * kShaftListEntry : 0;
+	if (list_words > w->shaft_list_words) {
+		(void) hipFree(w->shaft_lists);
+		w->shaft_lists = NULL; w->shaft_list_words = 0;
+		if (hipMalloc(&w->shaft_lists, list_words * sizeof(float)) != hipSuccess) {
+			printf("Failed to allocate %.1f MiB for the occluder lists of the light shafts.\n", list_words * 4.0 / 1048576.0);
+			return 1;
+		}
+		w->shaft_list_words = list_words;
+	}
 	if (light_count > w->shaft_rectangle_count) {
 		(void) hipFree(w->shaft_rectangles);
 		w->shaft_rectangles = NULL; w->shaft_rectangle_count = 0;
@@ -941,14 +957,16 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		// four-wide tree whatever tree the rays walk.
 		p.shaft_clear = NULL;
 		p.shaft_rectangles = NULL;
+		p.shaft_lists = NULL;
 		const uint32_t rays_per_pixel = app->render_settings.sample_count * p.light_count * ((int) app->render_settings.sampling_strategies == (int) sampling_strategies_diffuse_only ? 1u : 2u);
-		if (frame && (frames->light_shafts == 1u || (frames->light_shafts == 2u && rays_per_pixel >= 16u)) && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
+		if (frame && (frames->light_shafts == 1u || (frames->light_shafts == 2u && rays_per_pixel >= 8u)) && is_deferred(ray_mode) && error_mode == kErrorNone && app->scene.acceleration_structure.wide_nodes && p.light_count
 			&& app->scene.acceleration_structure.node_count < (1u << kShaftLightShift)  // (a queue entry of the walk is a node or triangle index and a light)
 			&& (technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueSolidAngle || technique == kTechniqueClippedSolidAngle))
 		{
 			const acceleration_structure_t* structure = &app->scene.acceleration_structure;
 			uint32_t shaft_groups = shade_grid_size(p.block_count);
-			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8, p.light_count)) return 1;
+			const bool lists = frames->shaft_lists != 0u && kShaftListMax != 0u;
+			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8, p.light_count, lists)) return 1;
 			float extent = 0.0f;
 			for (int j = 0; j != 3; ++j) extent = fmaxf(extent, kGridMax / structure->grid_inverse_cell[j]);
 			// (VKR_SHAFT_COUNTERS=1: the walks count their steps into three words behind the table, for get_light_shaft_work())
@@ -958,10 +976,11 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				work = (unsigned long long*) (frame->buffers.shaft_clear + (((size_t) shaft_groups * p.light_count + 1u) & ~(size_t) 1u));
 				(void) hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream);
 			}
-			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, extent, work);
+			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, lists ? frame->buffers.shaft_lists : NULL, extent, work);
 			if (hip_failed(hipGetLastError(), "launching the light shaft kernel")) return 1;
 			p.shaft_clear = frame->buffers.shaft_clear;
 			p.shaft_rectangles = frame->buffers.shaft_rectangles;
+			p.shaft_lists = lists ? frame->buffers.shaft_lists : NULL;
 			pass->last_shaft_groups = shaft_groups;
 		}
 		else pass->last_shaft_groups = 0;
@@ -1389,17 +1408,19 @@ extern "C" int get_traversal_statistics_of_tree(application_t* app, VkBool32 wid
 }
 
 // sums the words of the most recent launch's shaft table
-// out[0]: clear pairs, out[1 ... 5]: pairs that are not, by reason (kShaftNoPixels ... kShaftTriangle, light_shafts.h)
+// out[0]: clear pairs, out[1 ... 5]: pairs that are traced, by reason (kShaftNoPixels ... kShaftTriangle, light_shafts.h),
+// out[6]: anything else, out[7]: pairs with an occluder list, out[8]: triangles on those lists
 __global__ void __launch_bounds__(256) k_count_clear_shafts(const uint32_t* words, size_t count, unsigned long long* out) {
 	for (size_t i = (size_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (size_t) gridDim.x * 256u) {
 		uint32_t verdict = words[i] & 0xFFu;
-		uint32_t slot = verdict == kShaftClear ? 0u : (verdict >= kShaftNoPixels && verdict <= kShaftTriangle ? 1u + (verdict - kShaftNoPixels) : 6u);
+		uint32_t slot = verdict == kShaftClear ? 0u : (verdict == kShaftList ? 7u : (verdict >= kShaftNoPixels && verdict <= kShaftTriangle ? 1u + (verdict - kShaftNoPixels) : 6u));
 		atomicAdd(out + slot, 1ull);
+		if (verdict == kShaftList) atomicAdd(out + 8, (unsigned long long) ((words[i] >> 8) & 0x1Fu));
 	}
 }
 
-extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[10]) {
-	memset(out_statistics, 0, sizeof(uint64_t) * 10);
+extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_statistics[12]) {
+	memset(out_statistics, 0, sizeof(uint64_t) * 12);
 	const shading_pass_t* pass = &app->shading_pass;
 	const frame_pipeline* frames = (const frame_pipeline*) pass->wavefront;
 	const wavefront_buffers* w = frames ? &frames->contexts[frames->last].buffers : NULL;
@@ -1407,11 +1428,11 @@ extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_stati
 	if (finish_frames(app)) return 1;
 	size_t words = (size_t) pass->last_shaft_groups * app->scene_specification.polygonal_light_count;
 	unsigned long long* counter = NULL;
-	if (hip_failed(hipMalloc(&counter, sizeof(unsigned long long) * 8), "allocating counters")) return 1;
+	if (hip_failed(hipMalloc(&counter, sizeof(unsigned long long) * 16), "allocating counters")) return 1;
 	hipStream_t stream = (hipStream_t) app->device.stream;
-	(void) hipMemsetAsync(counter, 0, sizeof(unsigned long long) * 8, stream);
+	(void) hipMemsetAsync(counter, 0, sizeof(unsigned long long) * 16, stream);
 	k_count_clear_shafts<<<256, 256, 0, stream>>>(w->shaft_clear, words, counter);
-	unsigned long long counts[8] = {0};
+	unsigned long long counts[16] = {0};
 	int failed = vkr_copy_to_host(counts, counter, sizeof(counts), &app->device);
 	(void) hipFree(counter);
 	out_statistics[0] = words;
@@ -1419,6 +1440,8 @@ extern "C" int get_light_shaft_statistics(application_t* app, uint64_t out_stati
 	out_statistics[2] = pass->last_shaft_groups;
 	out_statistics[3] = app->scene_specification.polygonal_light_count;
 	for (int i = 0; i != 6; ++i) out_statistics[4 + i] = counts[1 + i];
+	out_statistics[10] = counts[7];
+	out_statistics[11] = counts[8];
 	return failed;
 }
 

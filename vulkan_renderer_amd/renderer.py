@@ -339,13 +339,15 @@ class Renderer(HostScene):
 
     def light_shaft_statistics(self):
         """(patch, light) pairs of the last launch and how many of them needed no shadow rays (csrc/light_shafts.h)"""
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 12)()
         if self.lib.get_light_shaft_statistics(C.byref(self.app), out):
             raise RuntimeError("get_light_shaft_statistics failed")
         work = (C.c_uint64 * 3)()
         self.lib.get_light_shaft_work(C.byref(self.app), work)
         return {"pairs": int(out[0]), "clear_pairs": int(out[1]), "patches": int(out[2]), "lights": int(out[3]), "work": {"steps": int(work[0]), "triangle_batches": int(work[1]), "walks": int(work[2])},
-                "not_clear": {"no_shaded_pixel": int(out[4]), "no_shaft": int(out[5]), "walk_too_long": int(out[6]), "queue_full": int(out[7]), "triangle_in_the_way": int(out[8]), "other": int(out[9])}}
+                "not_clear": {"no_shaded_pixel": int(out[4]), "no_shaft": int(out[5]), "walk_too_long": int(out[6]), "queue_full": int(out[7]), "triangle_in_the_way": int(out[8]), "other": int(out[9])},
+                # pairs whose rays the shading kernel decides against a handful of triangles, and those triangles
+                "list_pairs": int(out[10]), "listed_triangles": int(out[11])}
 
     # -- multi-GPU exchange (include/vkr_slab_exchange.h) ---------------------------------
     def exchange_id(self):
