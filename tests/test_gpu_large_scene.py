@@ -106,9 +106,10 @@ def test_builders_and_trees_agree_on_the_large_scene(large_dataset, large_oracle
     r.close()
     assert same_visibility
     assert np.array_equal(image.view(np.uint32), large_oracle["image"].view(np.uint32)), int((image != large_oracle["image"]).any(axis=-1).sum())
-    # (how many rays are TRACED depends on the tree since round 4: the light shafts are decided by a conservative walk of
-    # it - csrc/light_shafts.h.  The rays that are blocked are the same whatever tree finds them.)
-    assert stats["blocked_rays"] == large_oracle["wide"]["blocked_rays"]
+    # (which rays are TRACED depends on the tree since round 4: the light shafts and their occluder lists are decided by a
+    # conservative walk of it - csrc/light_shafts.h - and a ray that the shading kernel decides against a list is not in
+    # the queues that these statistics replay.  The frame above is what must not depend on the tree.)
+    assert abs(stats["blocked_rays"] - large_oracle["wide"]["blocked_rays"]) < 0.02 * large_oracle["rays"]
     assert abs(stats["rays"] - large_oracle["rays"]) < 0.02 * large_oracle["rays"]
 
 
@@ -159,7 +160,8 @@ def test_long_thin_triangles_are_split_into_several_leaves_and_nothing_else_chan
     for frame in (split, whole):
         assert np.array_equal(frame["image"].view(np.uint32), large_oracle["image"].view(np.uint32))
         assert np.array_equal(frame["visibility"], large_oracle["visibility"])
-    assert split["stats"]["blocked_rays"] == whole["stats"]["blocked_rays"]
+    # (of the rays that were traced; a few hundred of 22 M are decided against occluder lists with one tree and traced with the other)
+    assert abs(split["stats"]["blocked_rays"] - whole["stats"]["blocked_rays"]) < 0.02 * whole["stats"]["rays"]
     assert split["stats"]["triangle_tests"] < 0.5 * whole["stats"]["triangle_tests"]
     bench = build(big_dataset, True)
     assert bench["leaves"] == bench["triangles"]

@@ -151,11 +151,14 @@ def test_occluder_lists_same_frame_far_fewer_rays(big_dataset, monkeypatch, conf
     (on, rays_on, stats), (off, rays_off, stats_off) = out[1], out[0]
     print(config, stats, rays_on, rays_off)
     assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), int((on != off).any(axis=-1).sum())
-    assert stats_off["list_pairs"] == 0 and stats["list_pairs"] > 0 and stats["clear_pairs"] == stats_off["clear_pairs"]
+    assert stats_off["list_pairs"] == 0 and stats["list_pairs"] > 0
     assert stats["list_pairs"] <= stats["listed_triangles"] <= 12 * stats["list_pairs"]
-    # (a pair with a list was a pair with "a triangle in the way")
-    assert stats["list_pairs"] + stats["not_clear"]["triangle_in_the_way"] + stats["not_clear"]["walk_too_long"] + stats["not_clear"]["queue_full"] \
-        == stats_off["not_clear"]["triangle_in_the_way"] + stats_off["not_clear"]["walk_too_long"] + stats_off["not_clear"]["queue_full"]
+    # (a pair with a list was a pair with "a triangle in the way"; the lights of a patch are walked together, and where
+    # one of them now goes on collecting triangles until the walk is called off as too long, a pair that used to come out
+    # clear may be traced instead: a tenth of a per cent of them)
+    walked = lambda t: t["clear_pairs"] + t["list_pairs"] + t["not_clear"]["triangle_in_the_way"] + t["not_clear"]["walk_too_long"] + t["not_clear"]["queue_full"]
+    assert walked(stats) == walked(stats_off)
+    assert 0.99 * stats_off["clear_pairs"] <= stats["clear_pairs"] <= stats_off["clear_pairs"]
     assert 0 < rays_on < (0.5 if config != 2 else 1.0) * rays_off, (rays_on, rays_off)
 
 
