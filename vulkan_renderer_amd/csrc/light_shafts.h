@@ -61,12 +61,14 @@ constexpr uint32_t kShaftLeaves = 320;                        // triangles waiti
 // instead of 0.80 ms (VKR_SHAFT_ORIGIN_LOOP=1); batches of 16 or 8 triangles instead of 32 cost 0.35 / 0.39 ms, 64 the
 // same as 32; the whole per-light set-up computed by every lane alike instead of four lanes and a dozen wave-wide
 // reductions saves 4 % of the kernel alone but takes 126 instead of 79 registers, and the frame with three of them in
-// flight gets slower (1.441 vs 1.428 ms).
+// flight gets slower (1.441 vs 1.428 ms).  With the occluder lists (walks go on where they used to end; profiles/r06d):
+// the reductions over the rectangle's corners within a quad instead of the wave 0.241 -> 0.224 ms, and batches of 48 /
+// 64 triangles 0.212 / 0.210 ms.
 #ifndef VKR_SHAFT_ORIGIN_LOOP
 #define VKR_SHAFT_ORIGIN_LOOP 0
 #endif
 #ifndef VKR_SHAFT_LEAF_BATCH
-#define VKR_SHAFT_LEAF_BATCH 32
+#define VKR_SHAFT_LEAF_BATCH 64
 #endif
 constexpr uint32_t kShaftLeafBatch = VKR_SHAFT_LEAF_BATCH;         // triangles that must wait before a batch of them is tested
 constexpr uint32_t kShaftMaxSteps = 40;                       // steps of 16 nodes (plus 8 per light); more -> not clear
@@ -101,7 +103,9 @@ struct shaft_state {
 enum { kShaftClear = 1, kShaftList = 2, kShaftNoPixels = 16, kShaftGeometry = 17, kShaftTooLong = 18, kShaftQueueFull = 19, kShaftTriangle = 20 };
 
 struct shaft_patch {
+#if VKR_SHAFT_ORIGIN_LOOP
 	float origin[64][3];
+#endif
 	uint64_t valid;                     // lanes with a shading position
 	float centre[3], half[3], radius;   // bounding box of the positions (with margin), length of its half diagonal
 	// the patch's own plane if all its positions lie on one (within flat_tolerance): n unit, n . x = d
@@ -118,6 +122,16 @@ VKR_DEV float wave_max(float v) {
 #pragma unroll
 	for (int offset = 32; offset > 0; offset >>= 1) v = fmaxf(v, __shfl_xor(v, offset));
 	return v;
+}
+
+// (over the four lanes of a quad: every quad of the wave holds the four corners of the light's rectangle)
+VKR_DEV float quad_min(float v) {
+	v = fminf(v, __shfl_xor(v, 1));
+	return fminf(v, __shfl_xor(v, 2));
+}
+VKR_DEV float quad_max(float v) {
+	v = fmaxf(v, __shfl_xor(v, 1));
+	return fmaxf(v, __shfl_xor(v, 2));
 }
 
 // One box or triangle per lane against the planes of the shaft.  true: the box may reach into the shaft.
@@ -298,7 +312,9 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 		face_normal = cross(t.e0, t.e1);
 		face_normal = face_normal * __builtin_amdgcn_rsqf(fmaxf(dot(face_normal, face_normal), 1.0e-38f));
 		face_d = dot(face_normal, t.pos[0]);
+#if VKR_SHAFT_ORIGIN_LOOP
 		patch.origin[lane][0] = position.x; patch.origin[lane][1] = position.y; patch.origin[lane][2] = position.z;
+#endif
 	}
 	const float big = 3.0e38f;
 	f3 lo = mk3(wave_min(shaded ? position.x : big), wave_min(shaded ? position.y : big), wave_min(shaded ? position.z : big));
@@ -354,11 +370,11 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 				axis = axis * (1.0f / fmaxf(axis_length, 1.0e-30f));
 				float along = dot(v0 - centre, axis);
 				float reach = __builtin_sqrtf(dot(v0 - centre, v0 - centre));
-				float along_min = wave_min(lane < vertex_count ? along : big);
-				float reach_max = wave_max(lane < vertex_count ? reach : 0.0f);
+				float along_min = quad_min(along);
+				float reach_max = quad_max(reach);
 				// heights of the light above the patch's own plane (flat patches)
 				float above = dot(plane_n, v0) - plane_d;
-				float above_min = wave_min(lane < vertex_count ? above : big), above_max = wave_max(lane < vertex_count ? above : -big);
+				float above_min = quad_min(above), above_max = quad_max(above);
 				float above_sign = 1.0f;
 				// (a flat patch is seen from the front of its plane: a light that lies behind that plane altogether sends it no
 				// light - whatever rays rounding or a bent shading normal may still produce are traced as before, without a walk)
@@ -379,8 +395,8 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 					s.light[lane][0] = v0.x; s.light[lane][1] = v0.y; s.light[lane][2] = v0.z;
 				}
 				// bounding box of patch and polygon
-				f3 box_lo = mk3(wave_min(lane < vertex_count ? v0.x : big), wave_min(lane < vertex_count ? v0.y : big), wave_min(lane < vertex_count ? v0.z : big));
-				f3 box_hi = mk3(wave_max(lane < vertex_count ? v0.x : -big), wave_max(lane < vertex_count ? v0.y : -big), wave_max(lane < vertex_count ? v0.z : -big));
+				f3 box_lo = mk3(quad_min(v0.x), quad_min(v0.y), quad_min(v0.z));
+				f3 box_hi = mk3(quad_max(v0.x), quad_max(v0.y), quad_max(v0.z));
 				if (lane == 0) {
 					// far cap: nothing behind the light's plane matters
 					f3 nl = plane_normal(light);
