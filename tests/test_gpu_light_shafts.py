@@ -1,8 +1,10 @@
 """Light shafts (csrc/light_shafts.h): (8x8 pixel patch, light) pairs whose shadow rays cannot be blocked by anything are
-found by one conservative walk of the BVH per pair, and their rays are never queued.  Every ray query keeps its
-result, so every frame keeps every bit: rendered with the test (the default) and without it (VKR_LIGHT_SHAFTS=0)
-on both scenes, on a slice of the random sweep and on lights that graze, touch or surround the geometry.
-(The whole GPU suite runs with the test on: every bit-parity test against the oracle checks it as well.)"""
+found by one conservative walk of the BVH per pair, and their rays are never queued; pairs whose rays can only meet a
+handful of triangles get those triangles as an occluder list, and the shading kernel decides their rays itself.  Every
+ray query keeps its result, so every frame keeps every bit: rendered with the test (the default) and without it
+(VKR_LIGHT_SHAFTS=0), with the lists and without them (VKR_SHAFT_LISTS=0), on both scenes, from random cameras under
+random lights, on a slice of the random sweep and on lights that graze, touch or surround the geometry.
+(The whole GPU suite runs with shafts and lists on: every bit-parity test against the oracle checks them as well.)"""
 import math
 
 import numpy as np
