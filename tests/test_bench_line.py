@@ -1,0 +1,117 @@
+"""The one line bench.py prints must stay machine-readable: round 4's line had grown to 25 KB of copied dicts and prose
+notes, the driver keeps 8 KB of stdout, and BENCH_r04.json came back with `parsed: null` - a round without an accepted
+measurement.  The line is now built by bench.short_line() from the full record (which goes to a details file); these
+tests hold it under 4 KB with the contract's keys present, on the real record of round 4's closing run and on a
+record inflated the way an 8-rank run inflates it."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORD = os.path.join(ROOT, "profiles", "r06i", "bench_default.json")  # the 25 KB line the driver could not parse
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                 "roofline", "cpu_baseline")
+
+
+def _record():
+    lines = [line for line in open(RECORD).read().splitlines() if line.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _check(line_text):
+    assert "\n" not in line_text
+    assert len(line_text) < 4096, len(line_text)
+    line = json.loads(line_text)
+    for key in CONTRACT_KEYS:
+        assert key in line, key
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-5
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    # numbers and identifiers, no lab notes
+    def strings(node):
+        if isinstance(node, dict):
+            for value in node.values():
+                yield from strings(value)
+        elif isinstance(node, list):
+            for value in node:
+                yield from strings(value)
+        elif isinstance(node, str):
+            yield node
+    assert max(len(s) for s in strings(line)) <= 256
+    assert not any(key == "note" or key.endswith("_note") or key.endswith("_source") for key in _keys(line))
+    return line
+
+
+def _keys(node):
+    if isinstance(node, dict):
+        for key, value in node.items():
+            yield key
+            yield from _keys(value)
+
+
+def test_the_line_of_the_record_that_did_not_parse_is_short_now():
+    bench = _bench()
+    record = _record()
+    assert len(json.dumps(record)) > 20000  # what was printed in round 4
+    line = _check(json.dumps(bench.short_line(record, "gpurun_out/bench_details.json"), separators=(",", ":")))
+    assert line["value"] == record["value"] and line["ms_per_step"] == record["ms_per_step"]
+    assert line["parity"]["pixels_differing"] == 0 and line["parity"]["within_tolerance"] is True
+    assert line["north_star_target"]["met"] is True and line["north_star_target"]["value"] == record["north_star_target"]["value"]
+    assert line["secondary"]["value"] == record["secondary"]["value"] and "frac" in line["secondary"]["roofline"]
+    assert line["value_shaded_only"] == record["value_shaded_only"]
+    assert line["details"] == "gpurun_out/bench_details.json"
+
+
+def test_an_eight_rank_record_still_fits():
+    """N = 8: per-rank stage times, scaling parity for both workloads, long parallelism strings"""
+    bench = _bench()
+    record = copy.deepcopy(_record())
+    record["n_gpus"] = 8
+    record["stages"] = {key: [1.23456789] * 8 for key in ("shade_ms", "all_gather_ms", "scatter_ms")}
+    record["stages"]["note"] = "x" * 400
+    record["scaling_parity"] = {"pixels_differing_from_single_gpu_frame": 0, "pixels": 2073600, "format": "rgba32f"}
+    record["secondary"]["scaling_parity"] = {"pixels_differing_from_single_gpu_frame": 0, "pixels": 8294400, "format": "rgba32f"}
+    record["secondary"]["stages"] = copy.deepcopy(record["stages"])
+    record["config"]["parallelism"] = "tiles 32x32 round-robin over 8 rank(s), RCCL all-gather of rgba32f slabs (ncclAllGather from C) + scatter per frame inside the timed region, overlapped with the next frame"
+    record["config"]["workload"] += " " + "y" * 600
+    line = _check(json.dumps(bench.short_line(record, "gpurun_out/bench_details.json"), separators=(",", ":")))
+    assert line["scaling_parity"]["pixels_differing_from_single_gpu_frame"] == 0
+    assert line["secondary"]["scaling_parity"]["pixels"] == 8294400
+
+
+def test_a_record_without_the_optional_parts_still_gives_the_contract_keys():
+    bench = _bench()
+    record = _record()
+    for key in ("extra_workloads", "north_star_target", "secondary", "other_modes", "parity", "traversal", "light_shafts"):
+        record.pop(key, None)
+    record["roofline"]["traffic"] = None
+    record["roofline"].pop("flops"), record["roofline"].pop("valu_issue")
+    line = _check(json.dumps(bench.short_line(record), separators=(",", ":")))
+    assert line["roofline"]["traffic"] is None and line["details"] is None
+
+
+def test_dry_line_prints_exactly_that_line():
+    """`python bench.py --dry-line <record>`: the printing path of a real run (no GPU, no torch import)"""
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-line", RECORD], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert done.returncode == 0, done.stderr[-1000:]
+    out = done.stdout.splitlines()
+    assert len(out) == 1
+    _check(out[0])
+
+
+def test_details_file_holds_the_whole_record(tmp_path):
+    bench = _bench()
+    record = _record()
+    path = bench.write_details(record, str(tmp_path / "sub" / "bench_details.json"))
+    assert path is not None
+    assert json.load(open(tmp_path / "sub" / "bench_details.json")) == record
