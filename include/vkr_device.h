@@ -30,7 +30,7 @@ typedef struct VkExtent3D { uint32_t width, height, depth; } VkExtent3D;
 
 /*! Replaces device_t of the reference (src/vulkan_basics.h:30-75). */
 /*! Deepest frame pipeline of a shading pass (shading_pass_t.frames_in_flight) */
-#define VKR_MAX_FRAMES_IN_FLIGHT 4
+#define VKR_MAX_FRAMES_IN_FLIGHT 8
 
 typedef struct device_s {
 	/*! HIP device ordinal (LOCAL_RANK in multi-process runs) */

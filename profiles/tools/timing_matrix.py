@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--frames", type=int, default=110)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--only", default=None, help="substring of the screenshot path, to run part of the matrix")
+    ap.add_argument("--mode", default="libm", choices=["libm", "exact", "fast"], help="arithmetic mode of the kernels (libm: the default of the pass, bit-identical to the pinned oracle)")
     args = ap.parse_args()
     lib = capi.load()
     table = capi.ExperimentList()
@@ -65,7 +66,8 @@ def main():
     names = (C.c_char_p * 13).in_dll(lib, "g_sample_polygon_name") if hasattr(lib, "g_sample_polygon_name") else None
     tmp = tempfile.TemporaryDirectory(prefix="vkr_timings_")
     dataset = synthetic.write_dataset(tmp.name, grid=256, box_count=64, seed=1234, ltc_resolution=64, fresnel_count=51)
-    r = renderer.Renderer(frames_in_flight=1, timing_stride=1)
+    # (the matrix renders without shadow rays: nothing to pipeline, every frame is one kernel on one stream)
+    r = renderer.Renderer(frames_in_flight=1, timing_stride=1, arithmetic=args.mode)
     r.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=True)  # primary visibility walks the BVH
     r.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
     r.load_noise_table("white")
@@ -119,12 +121,12 @@ def main():
     r.close()
     lib.destroy_experiment_list(C.byref(table))
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-    json.dump({"frames": args.frames, "seconds": round(elapsed, 1), "results": results}, open(args.out + ".json", "w"), indent=1)
+    json.dump({"frames": args.frames, "seconds": round(elapsed, 1), "arithmetic": args.mode, "results": results}, open(args.out + ".json", "w"), indent=1)
     # two tables like the paper's: rows = technique, columns = geometric case x vertex count
     lines = ["# Timing matrix of the reference (src/experiment_list.c:366-409) on one MI355X", "",
              "`python profiles/tools/timing_matrix.py` - see its docstring for what is the reference's (the experiment table: 1920x1080, diffuse only,",
              "no shadow rays, settings per technique) and what is a stand-in (scene, noise, lights).  Median frame time over %d frames in ms," % args.frames,
-             "exact arithmetic, one frame at a time.  %d experiments in %.0f s." % (len(results), elapsed), ""]
+             "%s arithmetic, one frame at a time (no shadow rays in these experiments: a frame is one kernel, there is nothing to overlap).  %d experiments in %.0f s." % (args.mode, len(results), elapsed), ""]
     techniques = []
     for entry in results:
         if entry["technique"] not in techniques:

@@ -8,6 +8,7 @@ result in profiles/r03a/glibc_math_exhaustive.txt).
 GPU: the same functions evaluated on the device through the C-ABI (evaluate_device_arithmetic)
 against the C library of the host, bit for bit."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -124,17 +125,20 @@ def test_frames_of_the_oracle_do_not_depend_on_where_its_libm_comes_from(dataset
     from vulkan_renderer_amd import renderer
     flags = open("/proc/cpuinfo").read() if platform.system() == "Linux" else ""
     if platform.libc_ver() != ("glibc", "2.35") or platform.machine() != "x86_64" or " fma" not in flags or " avx2" not in flags:
+        # where the reference checkout is - the container in which the fixtures are generated and oracle/_ref is built - the
+        # tie MUST be checkable: a silent skip there would leave GPU-vs-oracle parity resting on one header compared with itself
+        assert not os.path.isdir("/root/reference"), "this is the image the oracle is pinned in, but its C library is not glibc 2.35 / x86-64 / FMA + AVX2: %r" % (platform.libc_ver(),)
         pytest.skip("the C library of this machine is not the one csrc/glibc_math.h restates")
     frames = {}
     for source in ("port", "system"):
         oracle.set_libm_source(source)
         try:
-            for config in (2, 3):
+            for config in (2, 3, "target", 4):
                 hs = renderer.HostScene()
                 renderer.setup_config(hs, config, dataset, width=96, height=64, sample_count=2)
                 frames[(source, config)] = oracle_render(hs, math_mode=0)[0]
                 hs.close()
         finally:
             oracle.set_libm_source("port")
-    for config in (2, 3):
+    for config in (2, 3, "target", 4):
         assert np.array_equal(frames[("port", config)].view(np.uint32), frames[("system", config)].view(np.uint32)), config

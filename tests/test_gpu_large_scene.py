@@ -93,6 +93,23 @@ def test_rays_leave_the_lds_stack_on_the_large_scene(large_dataset, large_oracle
     assert np.array_equal(spilled.view(np.uint32), s["image"].view(np.uint32))
 
 
+@pytest.mark.parametrize("refill, lds_stack", [(0, 16), (1, 16), (24, 16), (64, 16), (16, 6), (0, 6)])
+def test_handing_rays_to_idle_lanes_changes_no_frame(large_dataset, large_oracle, monkeypatch, refill, lds_stack):
+    """Round 5: a lane of a tracing wave whose ray is done takes the next ray of the pending batch as soon as
+    VKR_WIDE_REFILL lanes are idle (16 by default, what every other test of the suite runs with), instead of waiting
+    for the longest ray of its batch of 64 (0: the kernel of rounds 3 - 4).  A ray query's answer does not depend on
+    which lane walks it or when: the same frame and the same number of traced rays whatever the threshold - one lane
+    (a hand-out after every finished ray), a third of the wave, the whole wave (a batch at a time, through the new
+    loop) - and also when most rays leave the LDS part of their stack while other lanes are handed new rays."""
+    monkeypatch.setenv("VKR_WIDE_REFILL", str(refill))
+    monkeypatch.setenv("VKR_WIDE_STACK_LDS", str(lds_stack))
+    r, image = render(large_dataset, 3, 1920, 1080)
+    rays = r.last_ray_count()
+    r.close()
+    assert rays == large_oracle["rays"]
+    assert np.array_equal(image.view(np.uint32), large_oracle["image"].view(np.uint32)), int((image != large_oracle["image"]).any(axis=-1).sum())
+
+
 @pytest.mark.parametrize("builder, binary_traversal", [("sah_device", True), ("lbvh_device", False), ("lbvh_device", True), ("sah_host", False)])
 def test_builders_and_trees_agree_on_the_large_scene(large_dataset, large_oracle, builder, binary_traversal):
     """any-hit results do not depend on the tree: every builder and both layouts give the frame of the default

@@ -63,6 +63,81 @@ def large_dataset(tmp_path_factory):
     return synthetic.write_dataset(str(tmp_path_factory.mktemp("shafts_large")), seed=4321, ltc_resolution=32, fresnel_count=16, large={})
 
 
+@pytest.mark.parametrize("frames_in_flight", [1, 3])
+def test_pairs_whose_walk_met_too_many_triangles_rest_for_a_few_frames(large_dataset, monkeypatch, frames_in_flight):
+    """Round 5 (light_shafts.h, kShaftResting): behind fences and louvres most walks end at "more triangles in the way
+    than a list holds".  A verdict is a hint - without one the rays are traced - so the table of a frame context keeps the
+    verdicts of its previous frame, and such a pair is not walked again for seven of that context's frames.  Every frame
+    must be the same frame, with the same number of traced rays; the failed pairs of the first frame are exactly the
+    resting pairs of the following ones, and after seven rests they are walked (and fail) again.  VKR_SHAFT_REST=0
+    walks every pair in every frame."""
+    def frames(rest, count):
+        if rest is None:
+            monkeypatch.delenv("VKR_SHAFT_REST", raising=False)
+        else:
+            monkeypatch.setenv("VKR_SHAFT_REST", str(rest))
+        r = renderer.Renderer(frames_in_flight=frames_in_flight)
+        renderer.setup_config(r, 3, large_dataset, width=960, height=544, acceleration_structure="sah_device")
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        out = []
+        for _ in range(count):
+            r.render()
+            out.append((r.read_radiance(), r.last_ray_count(), r.light_shaft_statistics()))
+        r.close()
+        return out
+    contexts = frames_in_flight
+    resting = frames(None, 10 * contexts)
+    walking = frames(0, 2 * contexts)
+    first_image, first_rays, first = resting[0]
+    failed = first["not_clear"]["triangle_in_the_way"]
+    print(first)
+    assert failed > 0.2 * first["pairs"] and first["not_clear"]["other"] == 0
+    for index, (image, rays, stats) in enumerate(resting):
+        assert np.array_equal(image.view(np.uint32), first_image.view(np.uint32)), index
+        assert rays == first_rays, (index, rays, first_rays)
+        assert stats["clear_pairs"] == first["clear_pairs"] and stats["list_pairs"] == first["list_pairs"], index
+        use = index // contexts  # how often this frame's context has rendered before
+        walked = use % 8 == 0
+        assert stats["not_clear"]["triangle_in_the_way"] == (failed if walked else 0), (index, stats)
+        assert stats["not_clear"]["other"] == (0 if walked else failed), (index, stats)
+    for image, rays, stats in walking:
+        assert np.array_equal(image.view(np.uint32), first_image.view(np.uint32))
+        assert rays == first_rays and stats["not_clear"]["triangle_in_the_way"] == failed and stats["not_clear"]["other"] == 0
+    monkeypatch.delenv("VKR_SHAFT_REST", raising=False)
+
+
+def test_a_moved_light_does_not_lean_on_old_verdicts_for_long(large_dataset, monkeypatch):
+    """the hint may be stale - lights and camera move - but never wrong: after the lights have changed, frames with resting
+    pairs equal the frames of a renderer that walks every pair"""
+    rng = np.random.default_rng(5)
+    # (four quads like the configuration's own lights: the same kernel variant and constant buffer)
+    sets = [[test_gpu_sweep.random_light(rng, 4) for _ in range(4)] for _ in range(3)]
+
+    def frames(rest):
+        monkeypatch.setenv("VKR_SHAFT_REST", str(rest))
+        r = renderer.Renderer(frames_in_flight=2)
+        renderer.setup_config(r, 3, large_dataset, width=640, height=368, acceleration_structure="sah_device")
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        out = []
+        for lights in sets:
+            r.set_lights(lights)
+            for _ in range(3):
+                r.render()
+                out.append((r.read_radiance(), r.last_ray_count()))
+        r.close()
+        return out
+    with_rests, without = frames(7), frames(0)
+    monkeypatch.delenv("VKR_SHAFT_REST", raising=False)
+    for index, ((a, rays_a), (b, rays_b)) in enumerate(zip(with_rests, without)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), index
+        # (a pair that rests while its new shaft would have been clear has its rays traced: more rays, never fewer)
+        assert rays_a >= rays_b, (index, rays_a, rays_b)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_large_scene_from_random_cameras_under_random_lights(large_dataset, monkeypatch, seed):
     """the scene where a wrong "clear" would show (towers, fences, slats between the floor and the lights; 70 % of the

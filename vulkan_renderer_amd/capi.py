@@ -15,7 +15,7 @@ c_float_p = C.POINTER(C.c_float)
 
 class Device(C.Structure):
     _fields_ = [("hip_device", C.c_int32), ("stream", C.c_void_p), ("ray_tracing_supported", C.c_uint32),
-                ("compute_unit_count", C.c_int32), ("architecture", C.c_char * 64), ("frame_streams", C.c_void_p * 4)]
+                ("compute_unit_count", C.c_int32), ("architecture", C.c_char * 64), ("frame_streams", C.c_void_p * 8)]  # VKR_MAX_FRAMES_IN_FLIGHT
 
 
 class PolygonalLight(C.Structure):
@@ -163,7 +163,7 @@ class ExperimentList(C.Structure):
 
 # stack entries per lane that trace_shadow_rays_wide keeps in LDS (csrc/lbvh.h kWideStackLds)
 WIDE_STACK_LDS = 16
-MAX_FRAMES_IN_FLIGHT = 4  # VKR_MAX_FRAMES_IN_FLIGHT
+MAX_FRAMES_IN_FLIGHT = 8  # VKR_MAX_FRAMES_IN_FLIGHT
 
 
 class SlabExchangeId(C.Structure):

@@ -26,7 +26,15 @@
  * point exception flags do not exist here.
  *
  * Plain C99 and HIP device code at the same time: the including translation unit must be compiled
- * with -ffp-contract=off. */
+ * with -ffp-contract=off.
+ *
+ * Licence note.  This file restates THIRD-PARTY algorithms, not the reference renderer's: the GNU C Library 2.35
+ * (LGPL-2.1-or-later), whose float routines named above come from Sun's fdlibm ("Copyright (C) 1993 by Sun Microsystems,
+ * Inc.  Permission to use, copy, modify, and distribute this software is freely granted, provided that this notice is
+ * preserved.") and from the Arm Optimized Routines (MIT / Apache-2.0 with LLVM exception).  The polynomial coefficients
+ * and the log2 / exp2 tables are necessarily those publications' numbers - bit-equality with the library is the point -
+ * while the code around them is written for this file (branch-free range selection, the row table of gm_atanf_rows, FMA
+ * placement read off the shipped binary).  NOTICE.md at the repository root repeats this. */
 #ifndef VKR_GLIBC_MATH_H
 #define VKR_GLIBC_MATH_H
 

@@ -1050,7 +1050,9 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 	// VKR_BVH_SPLIT_TRIANGLES=0 builds over whole triangles as until round 3)
 	void* fragment_memory = NULL;
 	const char* split_knob = getenv("VKR_BVH_SPLIT_TRIANGLES");
-	if (builder == (int) acceleration_structure_sah_device && n > 1 && !(split_knob && split_knob[0] == '0')) {
+	// (a triangle becomes at most 16 fragments: up to 2^31 / 16 triangles the 32-bit prefix sum of the counts cannot wrap;
+	// beyond that the mesh is built unsplit)
+	if (builder == (int) acceleration_structure_sah_device && n > 1 && n <= 0x7FFFFFFFu / 16u && !(split_knob && split_knob[0] == '0')) {
 		uint32_t* counts = NULL;
 		void* scan_storage = NULL;
 		size_t scan_bytes = 0;
@@ -1071,7 +1073,11 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 				&& hipStreamSynchronize(stream) == hipSuccess;
 			total = last[0] + last[1];
 		}
-		if (ok && total > n && total < 0x7FFFFFFFu) {
+		// a mesh of nothing but slivers would grow leaves, nodes and triangle_vertices sixteenfold: beyond four leaves per
+		// triangle on average the split is not worth its memory, and the tree is built over whole triangles
+		if (ok && total > n && (uint64_t) total > 4ull * n)
+			printf("Splitting long thin triangles would turn %u triangles into %u leaves; the BVH is built over whole triangles.\n", n, total);
+		if (ok && total > n && (uint64_t) total <= 4ull * n) {
 			// fragment_triangle[total], then fragment_boxes[6 total]
 			ok = hipMalloc(&fragment_memory, sizeof(uint32_t) * (size_t) total + sizeof(float) * 6 * (size_t) total + 16) == hipSuccess;
 			if (ok) {

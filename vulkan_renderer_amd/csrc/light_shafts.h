@@ -71,7 +71,7 @@ constexpr uint32_t kShaftLeaves = 320;                        // triangles waiti
 #define VKR_SHAFT_LEAF_BATCH 64
 #endif
 constexpr uint32_t kShaftLeafBatch = VKR_SHAFT_LEAF_BATCH;         // triangles that must wait before a batch of them is tested
-constexpr uint32_t kShaftMaxSteps = 40;                       // steps of 16 nodes (plus 8 per light); more -> not clear
+constexpr uint32_t kShaftMaxSteps = 40;                       // steps of 16 nodes (plus a fifth of it per light); more -> not clear (run-time knob VKR_SHAFT_MAX_STEPS)
 constexpr float kShaftDilation = 1.0f / 32.0f;
 // Measured and not adopted (profiles/r05h/): cutting every candidate triangle by all planes of the shaft (test (iii) below)
 // finds 7 % more clear pairs at config 3 (25.0 instead of 23.3 % of all pairs) but costs the kernel 17 registers and 300
@@ -100,7 +100,18 @@ struct shaft_state {
 
 // why a pair is not clear (the word that the shading kernel reads is 1 for clear pairs and one of these otherwise)
 // (kShaftList: bits 8 ... 12 hold the number of triangles on the pair's list)
-enum { kShaftClear = 1, kShaftList = 2, kShaftNoPixels = 16, kShaftGeometry = 17, kShaftTooLong = 18, kShaftQueueFull = 19, kShaftTriangle = 20 };
+// kShaftResting: the pair's last walk ended at a triangle too many and this frame did not repeat it (below); bits 8 ... 15
+// count the frames since that walk
+enum { kShaftClear = 1, kShaftList = 2, kShaftNoPixels = 16, kShaftGeometry = 17, kShaftTooLong = 18, kShaftQueueFull = 19, kShaftTriangle = 20, kShaftResting = 21 };
+// Walks that find nothing (round 5).  Behind fences and louvres - the large scene - 64 % of the walks end with "more
+// triangles in the way than a list holds": they cost what a successful walk costs and their rays are traced all the same
+// (5 % of that scene's frame).  A verdict is only ever a HINT - a pair without one has its rays traced, and every term
+// comes out the same either way - so it may lean on the past: the table of a frame context keeps the verdicts of the
+// frame it rendered before (three frames back with three frames in flight), and a pair whose walk failed that way then
+// is not walked again for `rest_frames` of its context's frames.  After that the walk is repeated, so a pair that a moving
+// camera or light has freed gets its shaft back a few frames late, nothing more.  What the table holds before the first
+// frame is zeros (the host clears it), i.e. "walk".  VKR_SHAFT_REST=0 walks every pair in every frame.
+constexpr uint32_t kShaftRestFrames = 7;
 
 struct shaft_patch {
 #if VKR_SHAFT_ORIGIN_LOOP
@@ -265,7 +276,8 @@ VKR_DEV f3 shaft_rectangle_corner(const light_ref& light, float4 rectangle, uint
 // work_counters (diagnostics, may be NULL): [0] steps of the walks, [1] batches of triangles, [2] walks
 // out_lists (may be NULL: then a walk ends at the first triangle in the way): kShaftListMax entries of kShaftListEntry
 // floats per (patch, light), in the order of out_clear - a vertex of the triangle and the two edges that leave it.
-__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* __restrict__ out_clear, float4* __restrict__ out_rectangles, float* __restrict__ out_lists, float extent, unsigned long long* work_counters) {
+// out_clear is read before it is written: the verdict that this patch and light got when the table was last used (see kShaftResting)
+__global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const uint4* __restrict__ wide_nodes, uint32_t* out_clear, float4* __restrict__ out_rectangles, float* __restrict__ out_lists, float extent, unsigned long long* work_counters, uint32_t rest_frames, uint32_t max_steps) {
 	__shared__ shaft_patch patch;
 	__shared__ shaft_state shafts[kShaftLights];
 	__shared__ uint32_t frontier[kShaftFrontier];
@@ -356,6 +368,14 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 			// the rectangle the shaft is built around: the one the rays are tested against, and half as much room again
 			const float4 rectangle = shaft_rectangle(light, margin, 1.5f);
 			bool possible = light_vertex_count(light) >= 3u && rectangle.z > rectangle.x && rectangle.w > rectangle.y;
+			// a pair whose last walk met too many triangles rests for a few frames (the same word for every lane)
+			uint32_t resting = 0u;
+			if (rest_frames != 0u) {
+				const uint32_t before = clear[chunk + k], kind = before & 0xFFu, age = (before >> 8) & 0xFFu;
+				if (kind == kShaftTriangle) resting = kShaftResting | (1u << 8);
+				else if (kind == kShaftResting && age < rest_frames) resting = kShaftResting | ((age + 1u) << 8);
+			}
+			possible = possible && resting == 0u;
 			// every position on the same side of the light's plane, away from it
 			float side = shaded ? plane_distance(light, position) : 0.0f;
 			float side_min = wave_min(shaded ? side : big), side_max = wave_max(shaded ? side : -big);
@@ -431,7 +451,7 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 				}
 			}
 			if (possible) alive |= 1u << k;
-			else if (lane == 0) clear[chunk + k] = kShaftGeometry;
+			else if (lane == 0) clear[chunk + k] = resting ? resting : kShaftGeometry;
 		}
 		uint32_t waiting = 0, leaf_count = 0, steps = 0, batches = 0;
 		const uint32_t walked = alive;
@@ -449,7 +469,7 @@ __global__ void __launch_bounds__(64) k_light_shafts(const shade_params p, const
 		waiting = (uint32_t) __popc(alive);
 		__syncthreads();
 		// ---- the walk ----------------------------------------------------------------------------------------------
-		const uint32_t step_limit = kShaftMaxSteps + 8u * waiting;
+		const uint32_t step_limit = max_steps + (max_steps / 5u) * waiting;
 		uint32_t too_long = 0, queue_full = 0;
 		while (alive != 0 && (waiting != 0 || leaf_count != 0)) {
 			if (++steps > step_limit) { too_long = alive; alive = 0; break; }

@@ -103,6 +103,11 @@ struct shade_params {
 	uint32_t ray_block;
 	// tuning knobs (host: environment, see shading_pass.hip)
 	uint32_t refill_threshold;
+	// wavefront mode: 1 for the first launch of a frame, whose resolve kernel STORES its ray count in ray_counter; those of
+	// the frame's later bands add to it (the resolves of consecutive launches are ordered).  Until round 4 a memset in
+	// front of every frame cleared the counter: one more (tiny) kernel in the chain of every frame, which the GPU schedules
+	// when it finds room - 4 to 800 us under load (profiles/r07b).
+	uint32_t first_launch_of_frame;
 	// error display (ERROR_INDEX of the reference; the two constants of error_to_color
 	// that the GLSL compiler folds: 10^4.99 and 20 / (5 log2 10), computed on the host)
 	uint32_t error_index;
@@ -142,8 +147,11 @@ constexpr bool kUseShaftLists = false;
 #else
 constexpr bool kUseShaftLists = kShaftListMax != 0u;
 #endif
+// The final terms of a light that needs no ray are added up here instead of by the resolve kernel.  Not in the fast mode:
+// its translation units contract (a b) + c into a fused operation, the resolve kernel's do not, so the sum formed here
+// could differ from the one formed there - and a frame would depend on whether the shaft test is on.
 #ifndef VKR_SUM_FINAL_TERMS
-#define VKR_SUM_FINAL_TERMS 1
+#define VKR_SUM_FINAL_TERMS (!VKR_FAST_MATH)
 #endif
 enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5, kCodePendingHiddenNaN = 6 };
 // Byte index of code `cursor` of thread `tid`: four consecutive codes of a thread share one 32-bit
@@ -800,8 +808,9 @@ VKR_DEV bool all_zero(f3 v) { return ((__float_as_uint(v.x) | __float_as_uint(v.
 // for the global stores of the term before it, a round trip to the L2 per ray.)
 typedef __attribute__((address_space(3))) volatile uint32_t lds_state_word;
 VKR_DEV lds_state_word* ray_block_state() {
-	__shared__ uint32_t state[4 * 4];
-	return (lds_state_word*) (state + 4 * (threadIdx.x >> 6));
+	// (a shading workgroup is one wave, kShadeThreads: one entry of four words)
+	__shared__ uint32_t state[4];
+	return (lds_state_word*) state;
 }
 
 // Appends one shadow ray to the queue of this wave.  Lanes of the wave that arrive here

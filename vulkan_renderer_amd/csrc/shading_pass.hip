@@ -141,6 +141,9 @@ struct wavefront_buffers {
 	// light shafts (light_shafts.h): one word per shading workgroup and light, 1 = no ray of that patch toward that
 	// light can be blocked; allocated when the feature first runs
 	uint32_t* shaft_clear;
+	// which launch the verdicts in shaft_clear belong to (blocks, frame size, tiling, lights): the shaft kernel only leans on
+	// them when the next launch with these buffers is the same one (a band of another part of the frame is not)
+	uint64_t shaft_tag;
 	size_t shaft_words;
 	// ... and per light the plane-space rectangle that the shading kernel tests its rays against
 	float4* shaft_rectangles;
@@ -204,7 +207,7 @@ struct frame_pipeline {
 	// much as tracing 2.5 rays per pixel and light, and it is the patches with many rays per light and several lights
 	// that repay it (measured, profiles/r05m: config 3, 32 rays per pixel, 1.553 -> 1.443 ms; config 4, 128, 25.9 -> 23.0;
 	// the target shape, 8, 0.488 -> 0.500; config 2, 2 rays per pixel, 0.127 -> 0.192)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts, shaft_lists;
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, wide_refill, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts, shaft_lists, shaft_rest, shaft_max_steps;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -246,8 +249,17 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->light_shafts = environment_knob("VKR_LIGHT_SHAFTS", 2u, 0u, 2u);
 	// VKR_SHAFT_LISTS=0: a shaft walk ends at the first triangle in the way (no occluder lists, light_shafts.h)
 	frames->shaft_lists = environment_knob("VKR_SHAFT_LISTS", 1u, 0u, 1u);
+	// VKR_SHAFT_REST: frames (of a frame context) for which a pair is not walked again after a walk that met more triangles
+	// than a list holds; 0: every pair is walked in every frame (light_shafts.h, kShaftResting)
+	frames->shaft_rest = environment_knob("VKR_SHAFT_REST", kShaftRestFrames, 0u, 200u);
+	// VKR_SHAFT_MAX_STEPS: steps after which a walk gives up (plus a fifth of it per light that is walked along).  The shaft
+	// kernel of a small launch - a rank's slab at N = 8 - lasts as long as its longest walk.
+	frames->shaft_max_steps = environment_knob("VKR_SHAFT_MAX_STEPS", kShaftMaxSteps, 5u, 1000u);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
+	// VKR_WIDE_REFILL: lanes of a tracing wave (four-wide tree) that have to be idle before they are handed the next
+	// rays; 0: a batch of 64 rays is walked to its end first (until round 4)
+	frames->wide_refill = environment_knob("VKR_WIDE_REFILL", kWideRefillLanes, 0u, 64u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
 	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
 	frames->wavefront_budget_mib = environment_knob("VKR_WAVEFRONT_BUDGET_MIB", 36864u, 64u, 262144u);
@@ -280,7 +292,7 @@ static uint32_t ray_block_size(uint32_t max_terms) {
 	return max_terms >= 8 ? slots : 0u;
 }
 
-static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light_count, bool lists) {
+static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light_count, bool lists, hipStream_t stream) {
 	size_t list_words = lists ? words * kShaftListMax * kShaftListEntry : 0;
 	if (list_words > w->shaft_list_words) {
 		(void) hipFree(w->shaft_lists);
@@ -302,11 +314,13 @@ static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light
 	}
 	if (words <= w->shaft_words) return 0;
 	(void) hipFree(w->shaft_clear);
-	w->shaft_clear = NULL; w->shaft_words = 0;
+	w->shaft_clear = NULL; w->shaft_words = 0; w->shaft_tag = 0;
 	if (hipMalloc(&w->shaft_clear, words * sizeof(uint32_t)) != hipSuccess) {
 		printf("Failed to allocate %.1f MiB for the light shafts.\n", words * 4.0 / 1048576.0);
 		return 1;
 	}
+	// (the shaft kernel reads the verdicts of the frame before: none yet)
+	if (hipMemsetAsync(w->shaft_clear, 0, words * sizeof(uint32_t), stream) != hipSuccess) return 1;
 	w->shaft_words = words;
 	return 0;
 }
@@ -333,10 +347,13 @@ static uint32_t queue_capacity_for(uint32_t thread_count, uint32_t max_terms) {
 }
 
 // bytes that ensure_wavefront() allocates for a launch of thread_count threads
+// (with the light shafts' table: a verdict word per 8x8 patch and light and, with occluder lists, kShaftListMax entries each)
 static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count, bool hidden_terms, bool base_color) {
 	double terms = (double) max_terms * thread_count;
+	double shaft_pairs = (double) (thread_count / 64u) * light_count;
 	return terms * (hidden_terms ? 24.0 : 12.0) + (double) ((max_terms + light_count + 2 + 3) & ~3u) * thread_count + (base_color ? 16.0 : 0.0) * thread_count
-		+ 16.0 * thread_count + (double) queue_capacity_for(thread_count, max_terms) * kRayQueueCount * 20.0;
+		+ 16.0 * thread_count + (double) queue_capacity_for(thread_count, max_terms) * kRayQueueCount * 20.0
+		+ shaft_pairs * (4.0 + 4.0 * kShaftListMax * kShaftListEntry);
 }
 
 // `stream`: the stream the frame that uses these buffers is about to run on.  The counters are cleared
@@ -789,8 +806,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		return 1;
 	}
 	if (pass->use_ray_tracing) {
-		// (eight counters, one per frame in turn: see the band loop)
-		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, 8 * sizeof(unsigned long long)), "allocating the ray counters")) return 1;
+		// (sixteen counters, one per frame in turn: see the band loop)
+		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, 16 * sizeof(unsigned long long)), "allocating the ray counters")) return 1;
 		p.ray_counter = (unsigned long long*) pass->ray_counter;
 	}
 	// Launches with wavefront rays may run n at a time: launch k on frame stream k mod n with
@@ -906,9 +923,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	hipEvent_t* ring = (hipEvent_t*) pass->timing_ring;
 	uint32_t slot = pass->timing_cursor % pass->timing_ring_size;
 	bool timed = pass->timing_stride <= 1 || pass->frame_counter % pass->timing_stride == 0;
-	// rays of this frame: one of eight counters, taken in turn, so that the bands of this frame never
-	// meet those of a frame that is still in flight (at most four launches are)
-	if (p.ray_counter) p.ray_counter += pass->frame_counter % 8u;
+	// rays of this frame: one of sixteen counters, taken in turn, so that the bands of this frame never
+	// meet those of a frame that is still in flight (at most eight launches are)
+	if (p.ray_counter) p.ray_counter += pass->frame_counter % 16u;
 	++pass->frame_counter;
 	hipEvent_t caller_event = (hipEvent_t) pass->wait_before_next_frame;
 	pass->wait_before_next_frame = NULL;
@@ -940,7 +957,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		pass->last_frame_stream = stream;
 		// (a target that earlier work of the caller still reads: every stream that writes it waits)
 		if (caller_event && hip_failed(hipStreamWaitEvent(stream, caller_event, 0), "waiting for the caller's event")) return 1;
-		if (band == 0 && p.ray_counter && hip_failed(hipMemsetAsync(p.ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
+		// (wavefront rays: the resolve kernel of the frame's first launch stores the count instead)
+		p.first_launch_of_frame = band == 0 ? 1u : 0u;
+		if (band == 0 && p.ray_counter && !is_deferred(ray_mode) && hip_failed(hipMemsetAsync(p.ray_counter, 0, sizeof(unsigned long long), stream), "clearing the ray counter")) return 1;
 		if (upload_constants(app, stream)) return 1;
 		p.constants = (const uint8_t*) pass->constants_device;
 		// (the first event of a timed frame: everything the frame launches lies behind it)
@@ -965,8 +984,10 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		{
 			const acceleration_structure_t* structure = &app->scene.acceleration_structure;
 			uint32_t shaft_groups = shade_grid_size(p.block_count);
-			const bool lists = frames->shaft_lists != 0u && kShaftListMax != 0u;
-			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8, p.light_count, lists)) return 1;
+			// (the fast-mode shading kernels do not use the lists - kUseShaftLists, shading_kernel.h - and would trace the rays
+			// of a listed pair anyway: their walks end at the first triangle in the way)
+			const bool lists = frames->shaft_lists != 0u && kShaftListMax != 0u && pass->arithmetic_mode != arithmetic_mode_fast;
+			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8, p.light_count, lists, stream)) return 1;
 			float extent = 0.0f;
 			for (int j = 0; j != 3; ++j) extent = fmaxf(extent, kGridMax / structure->grid_inverse_cell[j]);
 			// (VKR_SHAFT_COUNTERS=1: the walks count their steps into three words behind the table, for get_light_shaft_work())
@@ -976,7 +997,13 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				work = (unsigned long long*) (frame->buffers.shaft_clear + (((size_t) shaft_groups * p.light_count + 1u) & ~(size_t) 1u));
 				(void) hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream);
 			}
-			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, lists ? frame->buffers.shaft_lists : NULL, extent, work);
+			uint64_t tag = 0xcbf29ce484222325ull;
+			for (uint64_t word : {(uint64_t) p.first_block, (uint64_t) p.block_count, (uint64_t) p.width, (uint64_t) p.height, (uint64_t) p.tile_size, (uint64_t) p.rank, (uint64_t) p.rank_count,
+					(uint64_t) p.slab_layout, (uint64_t) p.light_count, (uint64_t) (uintptr_t) p.visibility, (uint64_t) lists})
+				tag = (tag ^ word) * 0x100000001b3ull;
+			const bool same_launch = frame->buffers.shaft_tag == tag;
+			frame->buffers.shaft_tag = tag;
+			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, lists ? frame->buffers.shaft_lists : NULL, extent, work, same_launch ? frames->shaft_rest : 0u, frames->shaft_max_steps);
 			if (hip_failed(hipGetLastError(), "launching the light shaft kernel")) return 1;
 			p.shaft_clear = frame->buffers.shaft_clear;
 			p.shaft_rectangles = frame->buffers.shaft_rectangles;
@@ -1006,10 +1033,14 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				// per SIMD (wavefront_kernels.h has the measurements)
 				bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 7;
 				if (frames->trace_single_waves != 2u) single_waves = frames->trace_single_waves != 0u;
-				if (single_waves)
-					trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
-				else
-					trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds);
+				if (single_waves) {
+					if (frames->wide_refill) trace_shadow_rays_wide<64, true><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
+					else trace_shadow_rays_wide<64, false><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
+				}
+				else {
+					if (frames->wide_refill) trace_shadow_rays_wide<256, true><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
+					else trace_shadow_rays_wide<256, false><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
+				}
 			}
 			else
 				trace_shadow_rays<<<trace_blocks, 256, 0, stream>>>(p.bvh, rays, p.ray_queue_size + kRayQueueCount, p.codes, p.refill_threshold);
@@ -1475,7 +1506,7 @@ extern "C" uint64_t get_last_ray_count(const application_t* app) {
 	// (the kernels of the frame - the shading kernel with inline rays, else the resolve kernel of every
 	// band - added their rays to the frame's counter)
 	if (finish_frames((application_t*) app)) return 0;
-	if (vkr_copy_to_host(&rays, (const unsigned long long*) pass->ray_counter + (pass->frame_counter - 1u) % 8u, sizeof(rays), &app->device)) return 0;
+	if (vkr_copy_to_host(&rays, (const unsigned long long*) pass->ray_counter + (pass->frame_counter - 1u) % 16u, sizeof(rays), &app->device)) return 0;
 	return rays;
 }
 

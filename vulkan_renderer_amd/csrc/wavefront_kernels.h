@@ -14,6 +14,12 @@ namespace vkr {
 #define VKR_WIDE_TRACE_WAVES 8
 #endif
 constexpr uint32_t kWideTraceWaves = VKR_WIDE_TRACE_WAVES;
+// Idle lanes of a tracing wave before the next rays are handed out (trace_shadow_rays_wide, `refill_lanes`; the
+// run-time knob is VKR_WIDE_REFILL, 0 = batch at a time)
+#ifndef VKR_WIDE_REFILL_LANES
+#define VKR_WIDE_REFILL_LANES 16
+#endif
+constexpr uint32_t kWideRefillLanes = VKR_WIDE_REFILL_LANES;
 
 // Experiment of round 3 (north_star: "LDS-staged BVH node packets"; profiles/r03_trace.md has the
 // measurement): the first VKR_LDS_TOP_NODES nodes of the four-wide tree - its top levels, breadth
@@ -183,8 +189,17 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, ray_strea
 // kernels and many rays (config 3) single waves overlap the neighbouring frame's shading better
 // (-2.6 %, config 4 -0.9 %); with few rays (config 2) or two-wave shading kernels launching four
 // times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
-template <uint32_t THREADS>
-__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, uint32_t wide_node_count, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries) {
+// REFILL (round 5; `refill_lanes` idle lanes): without it the kernel walks a batch of 64 rays until its last ray is done - the scheme above, as measured
+// until round 4.  n >= 1: a lane whose ray is done takes the next ray of the pending batch as soon as n lanes of
+// the wave are idle (or the whole wave is), wherever the other lanes are in their walks.  On the benchmark scene a
+// ray fetches 5.8 nodes and the longest one 16: 77 % of the lane-steps of a batch do work.  On the large scene
+// it is 22 fetches against 137 - 56 %: every batch waits for its longest ray with most lanes idle.  The pending batch
+// stays where the loads put it (lane i holds ray i); it is handed out in lane order, so the source of the r-th idle
+// lane is lane pending_next + r: five ds_bpermute_b32 per hand-out, no search.  The batch after it is requested when
+// the last ray of the pending one has been handed out, and is not looked at before the next hand-out: its cold read
+// still hides behind the walk.
+template <uint32_t THREADS, bool REFILL>
+__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, uint32_t wide_node_count, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries, uint32_t refill_lanes) {
 	__shared__ uint32_t stack[kWideStackLds * THREADS];
 #if VKR_LDS_TOP_NODES
 	__shared__ uint4 top_nodes[VKR_LDS_TOP_NODES * 4];
@@ -233,8 +248,114 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 		cursor.chunk_next += 64u;
 		return true;
 	};
+	// One step of every walk of the wave: lanes at a node fetch it, test its four boxes and push the children that were
+	// hit; lanes at a triangle test it once enough of them have gathered; then every lane that is through with its
+	// item takes the next one off its stack - or is done, its ray unblocked.
+	auto walk_step = [&](bool at_node, bool at_leaf, uint64_t node_lanes, uint64_t leaf_lanes) {
+		bool pop = false;
+		if (at_node) {
+			const uint4* n = (const uint4*) ((const uint8_t*) wide_nodes + ((size_t) item << 6));
+#if VKR_LDS_TOP_NODES
+			if (item < top_count) n = top_nodes + 4u * item;
+#endif
+			uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
+			bool h0 = wide_ray_box(qx.x, qy.x, qz.x, ray, 1.0e-3f, t_max);
+			bool h1 = wide_ray_box(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
+			bool h2 = wide_ray_box(qx.z, qy.z, qz.z, ray, 1.0e-3f, t_max);
+			bool h3 = wide_ray_box(qx.w, qy.w, qz.w, ray, 1.0e-3f, t_max);
+			if (top + 4u * kEntry <= lds_end) {
+				// (the last child first: the first one comes off the stack first, the order of
+				// the scheme with a register for the next item)
+				VKR_STACK_AT(top) = link.w; top += h3 ? kEntry : 0u;
+				VKR_STACK_AT(top) = link.z; top += h2 ? kEntry : 0u;
+				VKR_STACK_AT(top) = link.y; top += h1 ? kEntry : 0u;
+				VKR_STACK_AT(top) = link.x; top += h0 ? kEntry : 0u;
+			}
+			else {
+				const bool hits[4] = {h3, h2, h1, h0};
+				const uint32_t links[4] = {link.w, link.z, link.y, link.x};
+#pragma unroll
+				for (int c = 0; c != 4; ++c) {
+					// (an absent child cannot be hit - unless a NaN slab let it through: never push its link, which is kIdle)
+					if (!hits[c] || links[c] == kWideEmpty) continue;
+					if (top < lds_end) VKR_STACK_AT(top) = links[c];
+					else my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride] = links[c];
+					top += kEntry;
+				}
+			}
+			pop = true;
+		}
+		bool test_leaves = leaf_lanes != 0 && (node_lanes == 0 || (uint32_t) __popcll((unsigned long long) leaf_lanes) >= leaf_batch);
+		if (test_leaves && at_leaf) {
+			const float4* t = bvh.triangles + 3 * (size_t) (item & ~kLeafBit);
+			float dist;
+			bool blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
+			// a blocked ray is done: its term keeps the code the shading kernel gave it
+			if (blocked) { item = kIdle; top = my_stack; }
+			else pop = true;
+		}
+		if (pop) {
+			if (top == my_stack) {
+				codes[code_index] = (uint8_t) kCodeVisible;
+				item = kIdle;
+			}
+			else {
+				top -= kEntry;
+				item = top < lds_end ? VKR_STACK_AT(top) : my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride];
+			}
+		}
+	};
+	// the rays of the pending batch that have not been handed out are those of lanes [pending_next, pending_end)
+	uint32_t pending_next = 0, pending_end = 0;
 	bool batch_pending = fetch_batch();
-	while (batch_pending) {
+	if constexpr (REFILL) {
+		if (batch_pending) pending_end = min(64u, cursor.chunk_count + 64u - cursor.chunk_next);
+		while (true) {
+			// ---- rays of the pending batch for idle lanes ------------------------------------------
+			uint64_t idle_lanes = __ballot(item == kIdle);
+			uint32_t idle_count = (uint32_t) __popcll((unsigned long long) idle_lanes);
+			if (batch_pending && (idle_count >= refill_lanes || idle_count == 64u)) {
+				uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle_lanes, 0u));
+				uint32_t source = pending_next + rank;
+				// (every lane takes part in the exchange: a lane that is switched off would deliver nothing)
+				float4 a = make_float4(__shfl(next_direction.x, (int) (source & 63u)), __shfl(next_direction.y, (int) (source & 63u)),
+					__shfl(next_direction.z, (int) (source & 63u)), __shfl(next_direction.w, (int) (source & 63u)));
+				uint32_t record = (uint32_t) __shfl((int) next_record, (int) (source & 63u));
+				bool take = item == kIdle && source < pending_end;
+				pending_next += idle_count;
+				// (a slot that the shading wave reserved and did not need holds kNullRay)
+				if (take && record != kNullRay) {
+					uint32_t tid = ray_record_thread(rays.thread_bits, record);
+					float4 b = rays.origins[tid];
+					o = mk3(b.x, b.y, b.z); d = mk3(a.x, a.y, a.z); t_max = a.w;
+					code_index = (uint32_t) code_slot(rays.thread_count, ray_record_cursor(rays.thread_bits, record), tid);
+					ray = make_wide_ray(make_grid_ray(bvh, o, d));
+					item = 0;
+					top = my_stack;
+					if (!(t_max >= 1.0e-3f)) {
+						// empty interval: nothing can block the ray (same rule as any_hit)
+						codes[code_index] = (uint8_t) kCodeVisible;
+						item = kIdle;
+					}
+				}
+				if (pending_next >= pending_end) {
+					// the batch after it: requested now, looked at when lanes have run dry again
+					batch_pending = fetch_batch();
+					pending_next = 0;
+					pending_end = batch_pending ? min(64u, cursor.chunk_count + 64u - cursor.chunk_next) : 0u;
+				}
+			}
+			bool at_node = item != kIdle && !(item & kLeafBit);
+			bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
+			uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
+			if ((node_lanes | leaf_lanes) == 0) {
+				if (!batch_pending) break;
+				continue;
+			}
+			walk_step(at_node, at_leaf, node_lanes, leaf_lanes);
+		}
+	}
+	else while (batch_pending) {
 		// ---- the prefetched batch becomes the current one ---------------------------------------
 		{
 			float4 a = next_direction;
@@ -264,58 +385,7 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 			bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
 			uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
 			if ((node_lanes | leaf_lanes) == 0) break;
-			bool pop = false;
-			if (at_node) {
-				const uint4* n = (const uint4*) ((const uint8_t*) wide_nodes + ((size_t) item << 6));
-#if VKR_LDS_TOP_NODES
-				if (item < top_count) n = top_nodes + 4u * item;
-#endif
-				uint4 qx = n[0], qy = n[1], qz = n[2], link = n[3];
-				bool h0 = wide_ray_box(qx.x, qy.x, qz.x, ray, 1.0e-3f, t_max);
-				bool h1 = wide_ray_box(qx.y, qy.y, qz.y, ray, 1.0e-3f, t_max);
-				bool h2 = wide_ray_box(qx.z, qy.z, qz.z, ray, 1.0e-3f, t_max);
-				bool h3 = wide_ray_box(qx.w, qy.w, qz.w, ray, 1.0e-3f, t_max);
-				if (top + 4u * kEntry <= lds_end) {
-					// (the last child first: the first one comes off the stack first, the order of
-					// the scheme with a register for the next item)
-					VKR_STACK_AT(top) = link.w; top += h3 ? kEntry : 0u;
-					VKR_STACK_AT(top) = link.z; top += h2 ? kEntry : 0u;
-					VKR_STACK_AT(top) = link.y; top += h1 ? kEntry : 0u;
-					VKR_STACK_AT(top) = link.x; top += h0 ? kEntry : 0u;
-				}
-				else {
-					const bool hits[4] = {h3, h2, h1, h0};
-					const uint32_t links[4] = {link.w, link.z, link.y, link.x};
-#pragma unroll
-					for (int c = 0; c != 4; ++c) {
-						// (an absent child cannot be hit - unless a NaN slab let it through: never push its link, which is kIdle)
-						if (!hits[c] || links[c] == kWideEmpty) continue;
-						if (top < lds_end) VKR_STACK_AT(top) = links[c];
-						else my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride] = links[c];
-						top += kEntry;
-					}
-				}
-				pop = true;
-			}
-			bool test_leaves = leaf_lanes != 0 && (node_lanes == 0 || (uint32_t) __popcll((unsigned long long) leaf_lanes) >= leaf_batch);
-			if (test_leaves && at_leaf) {
-				const float4* t = bvh.triangles + 3 * (size_t) (item & ~kLeafBit);
-				float dist;
-				bool blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
-				// a blocked ray is done: its term keeps the code the shading kernel gave it
-				if (blocked) { item = kIdle; top = my_stack; }
-				else pop = true;
-			}
-			if (pop) {
-				if (top == my_stack) {
-					codes[code_index] = (uint8_t) kCodeVisible;
-					item = kIdle;
-				}
-				else {
-					top -= kEntry;
-					item = top < lds_end ? VKR_STACK_AT(top) : my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride];
-				}
-			}
+			walk_step(at_node, at_leaf, node_lanes, leaf_lanes);
 		}
 	}
 }
@@ -401,7 +471,10 @@ __global__ void __launch_bounds__(256) resolve_shadow_terms_and_reset(const shad
 		}
 		if (my_queued) atomicAdd(&queued, my_queued);
 		__syncthreads();
-		if (threadIdx.x == 0 && p.ray_counter) atomicAdd(p.ray_counter, (unsigned long long) (counted ? counted : queued));
+		if (threadIdx.x == 0 && p.ray_counter) {
+			if (p.first_launch_of_frame) *p.ray_counter = (unsigned long long) (counted ? counted : queued);
+			else atomicAdd(p.ray_counter, (unsigned long long) (counted ? counted : queued));
+		}
 	}
 }
 
