@@ -240,11 +240,20 @@ class Job:
         from vulkan_renderer_amd import synthetic
         if scene not in self.datasets:
             t = time.perf_counter()
-            directory = os.path.join(self.tmp.name, scene)
-            if scene == "large":
-                self.datasets[scene] = synthetic.write_dataset(directory, seed=4321, ltc_resolution=self.args.ltc_resolution, fresnel_count=51, large={})
+            # VKR_BENCH_DATASET_CACHE=<directory>: the generated files are kept there and found again by later runs of one
+            # profiling session (profiles/collect.sh starts bench.py dozens of times; the large scene takes 25 s to generate)
+            cache = os.environ.get("VKR_BENCH_DATASET_CACHE")
+            directory = os.path.join(cache, "%s_R%d_rank%d" % (scene, self.args.ltc_resolution, self.rank)) if cache else os.path.join(self.tmp.name, scene)
+            marker = os.path.join(directory, "dataset.json")
+            if cache and os.path.exists(marker):
+                self.datasets[scene] = json.load(open(marker))
             else:
-                self.datasets[scene] = synthetic.write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=self.args.ltc_resolution, fresnel_count=51)
+                if scene == "large":
+                    self.datasets[scene] = synthetic.write_dataset(directory, seed=4321, ltc_resolution=self.args.ltc_resolution, fresnel_count=51, large={})
+                else:
+                    self.datasets[scene] = synthetic.write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=self.args.ltc_resolution, fresnel_count=51)
+                if cache:
+                    json.dump(self.datasets[scene], open(marker, "w"))
             self.datasets[scene]["generate_seconds"] = round(time.perf_counter() - t, 2)
         return self.datasets[scene]
 
@@ -350,7 +359,7 @@ def run_workload(job, config, role, scene=None):
         # at least 100 timed frames, so that the reference's protocol (median of >= 100 frame times) applies
         steps, warmup = 200, 20
     timing_stride = 1 if steps < 4 * args.timing_stride else args.timing_stride
-    frames_in_flight_requested = args.frames_in_flight or 3
+    frames_in_flight_requested = args.frames_in_flight or renderer.frames_in_flight_for(world if (world > 1 or args.force_distributed) else 1)
 
     # ---- set-up (untimed, reported separately: BASELINE.md section 3) -------------------------
     r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=args.mode, inline_rays=args.inline_rays,
@@ -461,6 +470,10 @@ def run_workload(job, config, role, scene=None):
             step()
         fence()
         protocol_periods = r.frame_period_ms(max(1, 128 // max(timing_stride, 1) - 1))
+        if timing_stride == 1 and len(protocol_periods) >= 64:
+            # (frames in flight finish in bursts: a period between two consecutive frames says little; like the long runs,
+            # whose events bracket every eighth frame, periods are averaged over eight frames before the median is taken)
+            protocol_periods = [float(np.mean(protocol_periods[i:i + 8])) for i in range(0, len(protocol_periods) - 7, 8)]
     stages = None
     if exchange != "none":
         mine = r.exchange_ms() or [float("nan")] * 3
@@ -927,7 +940,7 @@ def main():
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=(1, 2, 3, 4, 5, 6, 7, 8),
                     help="n >= 2: n consecutive frames overlap on the device's frame streams, like the frames of the reference's frame queue, which is as deep as "
-                         "its swapchain (main.c:1498: typically 3).  Default: 3 (config 4 renders its frames in three bands, whose buffers are what is in flight)")
+                         "its swapchain (main.c:1498: typically 3).  Default: 3, and 4 from eight ranks on (renderer.frames_in_flight_for)")
     ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")
     ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")

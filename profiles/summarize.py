@@ -60,32 +60,44 @@ def main():
     traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_path):
         traffic = json.load(open(traffic_path))
-    for cfg in (2, 3):
-        lines += ["## BASELINE config %d" % cfg, ""]
-        bench = os.path.join(base, "cfg%d_bench.json" % cfg)
-        if os.path.exists(bench):
+    # workloads of profiles/collect.sh: BASELINE configs, the north_star target shape, config 3 on the large scene; the
+    # entries of pmc_traffic.json are keyed the way bench.py looks them up ("config3_libm", "config3_libm_large")
+    workloads = [w for w in ("2", "3", "4", "target", "3_large") if glob.glob(os.path.join(base, "cfg%s_*" % w))]
+    sizes = {"4": (3840, 2160)}
+    for workload in workloads:
+        cfg, _, scene = workload.partition("_")
+        scene = scene or "bench"
+        suffix = "" if scene == "bench" else "_" + scene
+        lines += ["## BASELINE config %s%s" % (cfg, "" if scene == "bench" else " on the %s scene" % scene), ""]
+        details = os.path.join(base, "cfg%s_bench_details.json" % workload)
+        bench = os.path.join(base, "cfg%s_bench.json" % workload)
+        d = None
+        if os.path.exists(details):
+            d = json.load(open(details))
+        elif os.path.exists(bench):
             text = [l for l in open(bench).read().splitlines() if l.startswith("{")]
-            if text:
-                d = json.loads(text[-1])
-                lines += ["bench.py (un-profiled): **%.1f %s**, %.4f ms/step, shade_pixels %.4f ms (HIP events), %.0f Mrays/s, parity %s" % (
-                    d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d.get("Mrays_per_s", 0), json.dumps(d.get("parity"))), ""]
-        stats = kernel_stats(os.path.join(base, "cfg%d_trace" % cfg))
+            d = json.loads(text[-1]) if text else None
+        if d:
+            parity = d.get("parity") or {}
+            lines += ["bench.py (un-profiled): **%.1f %s**, %.4f ms/step, shade_pixels %.4f ms (HIP events), %.0f Mrays/s, parity: %s pixels of %s differ from the oracle" % (
+                d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d.get("Mrays_per_s", 0), parity.get("pixels_differing", "-"), parity.get("sample_pixels", "-")), ""]
+        stats = kernel_stats(os.path.join(base, "cfg%s_trace" % workload))
         if stats:
             lines += ["`rocprofv3 --kernel-trace --stats` (top kernels):", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
             for row in stats[:8]:
                 lines.append("| `%s` | %s | %.1f | %.1f | %.1f | %s |" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3, row["Percentage"]))
             lines.append("")
-        serial = kernel_stats(os.path.join(base, "cfg%d_serial" % cfg))
+        serial = kernel_stats(os.path.join(base, "cfg%s_serial" % workload))
         serial_us = {}
         if serial:
             lines += ["The same with `--frames-in-flight 1` (every kernel alone on the GPU):", "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
-            for row in serial[:3]:
+            for row in [r for r in serial if any(k in r["Name"] for k in ("shade_pixels", "trace_shadow_rays", "resolve_shadow", "light_shafts"))][:4]:
                 lines.append("| `%s` | %s | %.1f | %.1f | %.1f |" % (row["Name"][:80], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
                 serial_us[row["Name"].split("(")[0]] = float(row["AverageNs"]) / 1e3
             lines.append("")
         merged, meta = {}, {}
         for p in (1, 2, 3, 4, 5, 6, 7):
-            c, m = counters(os.path.join(base, "cfg%d_pmc%d" % (cfg, p)))
+            c, m = counters(os.path.join(base, "cfg%s_pmc%d" % (workload, p)))
             for k, v in c.items():
                 merged.setdefault(k, {}).update(v)
             meta.update(m)
@@ -141,13 +153,13 @@ def main():
                     floor_us = 4 * c.get("SQ_ACTIVE_INST_VALU", total) / 1024.0 / 2400.0
                     lines.append("- VALU issue floor at 4 clocks per instruction: %.1f us" % floor_us)
                 if "shade_pixels" in kernel or "trace_shadow_rays" in kernel or "resolve_shadow" in kernel or "light_shafts" in kernel:
-                    valu_floor = traffic.setdefault("config%d_%s_valu_floor_us" % (cfg, kernel_mode(kernel) or run_mode), {})
+                    valu_floor = traffic.setdefault("config%s_%s%s_valu_floor_us" % (cfg, kernel_mode(kernel) or run_mode, suffix), {})
                     valu_floor[kernel.split("::")[-1].split("<")[0]] = round(floor_us, 2)
                 if "shade_pixels" in kernel and "SQ_INSTS_VALU_FMA_F32" in c:
                     flop = 64.0 * (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 2.0 * c["SQ_INSTS_VALU_FMA_F32"])
                     lines.append("- FP32 arithmetic: %.4g FLOP per dispatch (ADD + MUL + 2 FMA wave instructions x 64 lanes)%s" % (
                         flop, (" = %.1f TFLOP/s over the %.1f us alone = %.1f %% of the 157.3 TFLOP/s FP32 vector peak" % (flop / alone / 1e6, alone, 100 * flop / alone / 1e6 / 157.3)) if alone else ""))
-                    traffic.setdefault("config%d_%s" % (cfg, kernel_mode(kernel) or run_mode), {})["fp32_flop_per_launch"] = flop
+                    traffic.setdefault("config%s_%s%s" % (cfg, kernel_mode(kernel) or run_mode, suffix), {})["fp32_flop_per_launch"] = flop
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
                 lines += ["- HBM traffic per dispatch: FETCH_SIZE %.1f MiB (x2 correction: %.1f MiB) + WRITE_SIZE %.1f MiB = %.1f MB raw" % (
@@ -155,10 +167,10 @@ def main():
                 if "TCC_HIT_sum" in c:
                     lines.append("- L2 hit rate %.1f %%" % (100 * c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)))
                 if "shade_pixels" in kernel:
-                    w, h = (1920, 1080)
-                    entry = traffic.setdefault("config%d_%s" % (cfg, kernel_mode(kernel) or run_mode), {})
+                    w, h = sizes.get(cfg, (1920, 1080))
+                    entry = traffic.setdefault("config%s_%s%s" % (cfg, kernel_mode(kernel) or run_mode, suffix), {})
                     # (FETCH_SIZE with the guide's x2 correction for wide coalesced reads on gfx950)
-                    entry.update({"width": w, "height": h, "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "hbm_bytes_per_launch_uncorrected": int(raw),
+                    entry.update({"width": w, "height": h, "scene": scene, "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "hbm_bytes_per_launch_uncorrected": int(raw),
                                   "source": "profiles/%s_summary.md" % tag, "csrc_hash": csrc_hash})
             lines.append("")
     open(os.path.join(ROOT, "profiles", "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")

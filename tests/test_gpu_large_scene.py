@@ -93,15 +93,18 @@ def test_rays_leave_the_lds_stack_on_the_large_scene(large_dataset, large_oracle
     assert np.array_equal(spilled.view(np.uint32), s["image"].view(np.uint32))
 
 
-@pytest.mark.parametrize("refill, lds_stack", [(0, 16), (1, 16), (24, 16), (64, 16), (16, 6), (0, 6)])
-def test_handing_rays_to_idle_lanes_changes_no_frame(large_dataset, large_oracle, monkeypatch, refill, lds_stack):
-    """Round 5: a lane of a tracing wave whose ray is done takes the next ray of the pending batch as soon as
-    VKR_WIDE_REFILL lanes are idle (16 by default, what every other test of the suite runs with), instead of waiting
-    for the longest ray of its batch of 64 (0: the kernel of rounds 3 - 4).  A ray query's answer does not depend on
-    which lane walks it or when: the same frame and the same number of traced rays whatever the threshold - one lane
-    (a hand-out after every finished ray), a third of the wave, the whole wave (a batch at a time, through the new
-    loop) - and also when most rays leave the LDS part of their stack while other lanes are handed new rays."""
+@pytest.mark.parametrize("refill, below, lds_stack", [(0, 166, 16), (16, 256, 16), (1, 256, 16), (24, 256, 16), (64, 256, 16), (16, 256, 6), (16, 200, 6), (16, 40, 16)])
+def test_handing_rays_to_idle_lanes_changes_no_frame(large_dataset, large_oracle, monkeypatch, refill, below, lds_stack):
+    """Round 5: a tracing wave that finds its batches of 64 rays less than VKR_WIDE_REFILL_BELOW / 256 busy (default 166:
+    this scene's waves switch, the benchmark scene's do not) hands the next rays to lanes whose ray is done as soon as
+    VKR_WIDE_REFILL lanes are idle (default 16), instead of waiting for the longest ray of every batch (VKR_WIDE_REFILL=0:
+    the kernel of rounds 3 - 4; every other test of the suite runs with the defaults).  A ray query's answer does not
+    depend on which lane walks it or when: the same frame and the same number of traced rays whether waves never switch,
+    switch after their first batches or hand out from the start, whatever the threshold - one lane (a hand-out after
+    every finished ray), a third of the wave, the whole wave - and also when most rays leave the LDS part of their stack
+    while other lanes are handed new rays."""
     monkeypatch.setenv("VKR_WIDE_REFILL", str(refill))
+    monkeypatch.setenv("VKR_WIDE_REFILL_BELOW", str(below))
     monkeypatch.setenv("VKR_WIDE_STACK_LDS", str(lds_stack))
     r, image = render(large_dataset, 3, 1920, 1080)
     rays = r.last_ray_count()

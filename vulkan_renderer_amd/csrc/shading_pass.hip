@@ -207,7 +207,7 @@ struct frame_pipeline {
 	// much as tracing 2.5 rays per pixel and light, and it is the patches with many rays per light and several lights
 	// that repay it (measured, profiles/r05m: config 3, 32 rays per pixel, 1.553 -> 1.443 ms; config 4, 128, 25.9 -> 23.0;
 	// the target shape, 8, 0.488 -> 0.500; config 2, 2 rays per pixel, 0.127 -> 0.192)
-	uint32_t wide_stack_lds, leaf_batch, refill_threshold, wide_refill, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts, shaft_lists, shaft_rest, shaft_max_steps;
+	uint32_t wide_stack_lds, leaf_batch, refill_threshold, wide_refill, wide_refill_below, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts, shaft_lists, shaft_rest, shaft_max_steps;
 };
 
 static uint32_t environment_knob(const char* name, uint32_t fallback, uint32_t low, uint32_t high) {
@@ -257,9 +257,11 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->shaft_max_steps = environment_knob("VKR_SHAFT_MAX_STEPS", kShaftMaxSteps, 5u, 1000u);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
-	// VKR_WIDE_REFILL: lanes of a tracing wave (four-wide tree) that have to be idle before they are handed the next
-	// rays; 0: a batch of 64 rays is walked to its end first (until round 4)
+	// VKR_WIDE_REFILL: lanes of a tracing wave (four-wide tree) that have to be idle before they are handed the next rays,
+	// once the wave has found its batches less than VKR_WIDE_REFILL_BELOW / 256 busy (wavefront_kernels.h; 256: from the
+	// first batch on); 0: a batch of 64 rays is always walked to its end first (until round 4)
 	frames->wide_refill = environment_knob("VKR_WIDE_REFILL", kWideRefillLanes, 0u, 64u);
+	frames->wide_refill_below = environment_knob("VKR_WIDE_REFILL_BELOW", kWideRefillBelow, 0u, 256u);
 	frames->trace_waves = environment_knob("VKR_TRACE_WAVES", 0u, 0u, 8u);
 	frames->trace_single_waves = environment_knob("VKR_TRACE_SINGLE_WAVES", 2u, 0u, 2u);
 	frames->wavefront_budget_mib = environment_knob("VKR_WAVEFRONT_BUDGET_MIB", 36864u, 64u, 262144u);
@@ -1034,12 +1036,10 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				bool single_waves = ray_mode == kRaysDeferredBlocks && capacity <= 7;
 				if (frames->trace_single_waves != 2u) single_waves = frames->trace_single_waves != 0u;
 				if (single_waves) {
-					if (frames->wide_refill) trace_shadow_rays_wide<64, true><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
-					else trace_shadow_rays_wide<64, false><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
+					trace_shadow_rays_wide<64><<<trace_blocks * 4u, 64, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill, frames->wide_refill_below);
 				}
 				else {
-					if (frames->wide_refill) trace_shadow_rays_wide<256, true><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
-					else trace_shadow_rays_wide<256, false><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill);
+					trace_shadow_rays_wide<256><<<trace_blocks, 256, 0, stream>>>(p.bvh, wide_nodes, app->scene.acceleration_structure.wide_node_count, rays, p.ray_queue_size + kRayQueueCount, p.codes, frame->buffers.spill, frames->leaf_batch, frames->wide_stack_lds, frames->wide_refill, frames->wide_refill_below);
 				}
 			}
 			else

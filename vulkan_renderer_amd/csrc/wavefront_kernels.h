@@ -15,11 +15,13 @@ namespace vkr {
 #endif
 constexpr uint32_t kWideTraceWaves = VKR_WIDE_TRACE_WAVES;
 // Idle lanes of a tracing wave before the next rays are handed out (trace_shadow_rays_wide, `refill_lanes`; the
-// run-time knob is VKR_WIDE_REFILL, 0 = batch at a time)
+// run-time knob is VKR_WIDE_REFILL, 0 = always a batch at a time)
 #ifndef VKR_WIDE_REFILL_LANES
 #define VKR_WIDE_REFILL_LANES 16
 #endif
 constexpr uint32_t kWideRefillLanes = VKR_WIDE_REFILL_LANES;
+// ... by a wave whose batches kept less than this share (in 1/256) of its lanes busy (VKR_WIDE_REFILL_BELOW)
+constexpr uint32_t kWideRefillBelow = 166;
 
 // Experiment of round 3 (north_star: "LDS-staged BVH node packets"; profiles/r03_trace.md has the
 // measurement): the first VKR_LDS_TOP_NODES nodes of the four-wide tree - its top levels, breadth
@@ -189,17 +191,28 @@ __global__ void __launch_bounds__(256) trace_shadow_rays(bvh_view bvh, ray_strea
 // kernels and many rays (config 3) single waves overlap the neighbouring frame's shading better
 // (-2.6 %, config 4 -0.9 %); with few rays (config 2) or two-wave shading kernels launching four
 // times as many workgroups costs 2 % instead.  The host picks (shading_pass.hip).
-// REFILL (round 5; `refill_lanes` idle lanes): without it the kernel walks a batch of 64 rays until its last ray is done - the scheme above, as measured
-// until round 4.  n >= 1: a lane whose ray is done takes the next ray of the pending batch as soon as n lanes of
-// the wave are idle (or the whole wave is), wherever the other lanes are in their walks.  On the benchmark scene a
-// ray fetches 5.8 nodes and the longest one 16: 77 % of the lane-steps of a batch do work.  On the large scene
-// it is 22 fetches against 137 - 56 %: every batch waits for its longest ray with most lanes idle.  The pending batch
-// stays where the loads put it (lane i holds ray i); it is handed out in lane order, so the source of the r-th idle
-// lane is lane pending_next + r: five ds_bpermute_b32 per hand-out, no search.  The batch after it is requested when
-// the last ray of the pending one has been handed out, and is not looked at before the next hand-out: its cold read
-// still hides behind the walk.
-template <uint32_t THREADS, bool REFILL>
-__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, uint32_t wide_node_count, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries, uint32_t refill_lanes) {
+// Handing rays to idle lanes (round 5).  The scheme above walks a batch of 64 rays until its longest ray is done.  On the
+// benchmark scene a ray fetches 5.8 nodes and the longest one 16: 77 % of the lane-steps of a batch do work.  On the large
+// scene it is 22 fetches against 137 - 56 %, and the kernel is bound by the issue of its box tests (2.7e9 wave instructions
+// per launch, 94 % of its node reads hit the L1: profiles/r07b/large_scene_trace_counters.txt), i.e. by steps that most
+// lanes sit out.  In the second mode of the kernel a lane whose ray is done takes the next ray of the pending batch as soon
+// as `refill_lanes` lanes of the wave are idle (or the whole wave is), wherever the other lanes are in their walks.  The
+// pending batch stays where the loads put it (lane i holds ray i) and is handed out in lane order, so the source of the
+// r-th idle lane is lane pending_next + r: five ds_bpermute_b32, no search; the origins of the batch - a dependent read
+// behind the records - are fetched once, when its first ray is handed out, and wait in LDS (one float4 per lane: with the
+// 4 KB of the stack 5 KB per wave, four of the 1280-byte granules in which gfx950 hands out LDS - 32 waves still fit a
+// CU).  The batch after it is requested when the last ray of the pending one has been handed out and is not looked at
+// before the next hand-out: its cold read still hides behind the walk.
+// Measured (profiles/r07c, r07d; frame period, three frames in flight): large scene 5.31 -> 3.95 ms with 16 idle lanes (4, 8,
+// 24, 32, 48: 4.12, 4.01, 3.96, 4.04, 4.80); but the benchmark scene LOSES - config 2 0.135 -> 0.140 ms, config 3 1.147 ->
+// 1.157, config 4 18.95 -> 19.13, about a tenth of the kernel each time, also with hand-outs at least 4 or 8 steps apart:
+// short rays all reach their leaves at about the same step when they start together, and staggered they wait for the
+// sixteen that make a batch of triangle tests.  So a wave DECIDES: it walks its first batches the old way and counts how
+// busy its lanes were (lane-steps / 64 steps); a wave whose batches were less than `refill_below` / 256 busy (default 0.65,
+// between the two scenes' 0.77 and 0.56) hands out rays from then on.  VKR_WIDE_REFILL=0: never; VKR_WIDE_REFILL_BELOW=256:
+// from the first batch on.
+template <uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wide(bvh_view bvh, const uint4* __restrict__ wide_nodes, uint32_t wide_node_count, ray_stream rays, uint32_t* work_cursors, uint8_t* codes, uint32_t* spill, uint32_t leaf_batch, uint32_t lds_entries, uint32_t refill_lanes, uint32_t refill_below) {
 	__shared__ uint32_t stack[kWideStackLds * THREADS];
 #if VKR_LDS_TOP_NODES
 	__shared__ uint4 top_nodes[VKR_LDS_TOP_NODES * 4];
@@ -305,58 +318,12 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 			}
 		}
 	};
-	// the rays of the pending batch that have not been handed out are those of lanes [pending_next, pending_end)
-	uint32_t pending_next = 0, pending_end = 0;
 	bool batch_pending = fetch_batch();
-	if constexpr (REFILL) {
-		if (batch_pending) pending_end = min(64u, cursor.chunk_count + 64u - cursor.chunk_next);
-		while (true) {
-			// ---- rays of the pending batch for idle lanes ------------------------------------------
-			uint64_t idle_lanes = __ballot(item == kIdle);
-			uint32_t idle_count = (uint32_t) __popcll((unsigned long long) idle_lanes);
-			if (batch_pending && (idle_count >= refill_lanes || idle_count == 64u)) {
-				uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle_lanes, 0u));
-				uint32_t source = pending_next + rank;
-				// (every lane takes part in the exchange: a lane that is switched off would deliver nothing)
-				float4 a = make_float4(__shfl(next_direction.x, (int) (source & 63u)), __shfl(next_direction.y, (int) (source & 63u)),
-					__shfl(next_direction.z, (int) (source & 63u)), __shfl(next_direction.w, (int) (source & 63u)));
-				uint32_t record = (uint32_t) __shfl((int) next_record, (int) (source & 63u));
-				bool take = item == kIdle && source < pending_end;
-				pending_next += idle_count;
-				// (a slot that the shading wave reserved and did not need holds kNullRay)
-				if (take && record != kNullRay) {
-					uint32_t tid = ray_record_thread(rays.thread_bits, record);
-					float4 b = rays.origins[tid];
-					o = mk3(b.x, b.y, b.z); d = mk3(a.x, a.y, a.z); t_max = a.w;
-					code_index = (uint32_t) code_slot(rays.thread_count, ray_record_cursor(rays.thread_bits, record), tid);
-					ray = make_wide_ray(make_grid_ray(bvh, o, d));
-					item = 0;
-					top = my_stack;
-					if (!(t_max >= 1.0e-3f)) {
-						// empty interval: nothing can block the ray (same rule as any_hit)
-						codes[code_index] = (uint8_t) kCodeVisible;
-						item = kIdle;
-					}
-				}
-				if (pending_next >= pending_end) {
-					// the batch after it: requested now, looked at when lanes have run dry again
-					batch_pending = fetch_batch();
-					pending_next = 0;
-					pending_end = batch_pending ? min(64u, cursor.chunk_count + 64u - cursor.chunk_next) : 0u;
-				}
-			}
-			bool at_node = item != kIdle && !(item & kLeafBit);
-			bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
-			uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
-			if ((node_lanes | leaf_lanes) == 0) {
-				if (!batch_pending) break;
-				continue;
-			}
-			walk_step(at_node, at_leaf, node_lanes, leaf_lanes);
-		}
-	}
-	else while (batch_pending) {
-		// ---- the prefetched batch becomes the current one ---------------------------------------
+	// ---- a batch at a time, until the wave finds its lanes idle too often ------------------------------
+	bool handing = refill_lanes != 0u && refill_below >= 256u;
+	uint32_t steps = 0, lane_steps = 0;
+	while (batch_pending && !handing) {
+		// the prefetched batch becomes the current one
 		{
 			float4 a = next_direction;
 			uint32_t record = next_record;
@@ -379,14 +346,79 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 				}
 			}
 		}
-		// ---- walk until every lane has run dry -----------------------------------------------
+		// walk until every lane has run dry
 		while (true) {
 			bool at_node = item != kIdle && !(item & kLeafBit);
 			bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
 			uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
 			if ((node_lanes | leaf_lanes) == 0) break;
+			++steps;
+			lane_steps += (uint32_t) __popcll((unsigned long long) (node_lanes | leaf_lanes));
 			walk_step(at_node, at_leaf, node_lanes, leaf_lanes);
 		}
+		// (over all batches of the wave so far; a batch of null rays takes no step and decides nothing)
+		handing = refill_lanes != 0u && steps >= 8u && 4u * lane_steps < refill_below * steps;
+	}
+	if (!batch_pending) return;
+	// ---- rays handed to idle lanes ------------------------------------------------------------------------
+	__shared__ float4 origin_stage[THREADS];
+	float4* const my_wave_origins = origin_stage + (threadIdx.x & ~63u);
+	bool origins_staged = false;
+	// the rays of the pending batch that have not been handed out are those of lanes [pending_next, pending_end)
+	uint32_t pending_next = 0, pending_end = min(64u, cursor.chunk_count + 64u - cursor.chunk_next);
+	while (true) {
+		uint64_t idle_lanes = __ballot(item == kIdle);
+		uint32_t idle_count = (uint32_t) __popcll((unsigned long long) idle_lanes);
+		if (batch_pending && (idle_count >= refill_lanes || idle_count == 64u)) {
+			if (!origins_staged) {
+				float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (next_record != kNullRay) mine = rays.origins[ray_record_thread(rays.thread_bits, next_record)];
+				my_wave_origins[lane] = mine;
+				origins_staged = true;
+				__builtin_amdgcn_wave_barrier();
+			}
+			uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle_lanes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle_lanes, 0u));
+			uint32_t source = pending_next + rank;
+			// (every lane takes part in the exchange: a lane that is switched off would deliver nothing)
+			float4 a = make_float4(__shfl(next_direction.x, (int) (source & 63u)), __shfl(next_direction.y, (int) (source & 63u)),
+				__shfl(next_direction.z, (int) (source & 63u)), __shfl(next_direction.w, (int) (source & 63u)));
+			uint32_t record = (uint32_t) __shfl((int) next_record, (int) (source & 63u));
+			bool take = item == kIdle && source < pending_end;
+			pending_next += idle_count;
+			// (a slot that the shading wave reserved and did not need holds kNullRay)
+			if (take && record != kNullRay) {
+				uint32_t tid = ray_record_thread(rays.thread_bits, record);
+				float4 b = my_wave_origins[source & 63u];
+				o = mk3(b.x, b.y, b.z); d = mk3(a.x, a.y, a.z); t_max = a.w;
+				code_index = (uint32_t) code_slot(rays.thread_count, ray_record_cursor(rays.thread_bits, record), tid);
+				ray = make_wide_ray(make_grid_ray(bvh, o, d));
+				item = 0;
+				top = my_stack;
+				if (!(t_max >= 1.0e-3f)) {
+					// empty interval: nothing can block the ray (same rule as any_hit)
+					codes[code_index] = (uint8_t) kCodeVisible;
+					item = kIdle;
+				}
+			}
+			if (pending_next >= pending_end) {
+				// the batch after it: requested now, looked at when lanes have run dry again
+				// (every lane has read its origin before the stage is written again: the wave runs in lock step, and
+				// the barrier keeps the compiler from moving the accesses across it)
+				__builtin_amdgcn_wave_barrier();
+				batch_pending = fetch_batch();
+				origins_staged = false;
+				pending_next = 0;
+				pending_end = batch_pending ? min(64u, cursor.chunk_count + 64u - cursor.chunk_next) : 0u;
+			}
+		}
+		bool at_node = item != kIdle && !(item & kLeafBit);
+		bool at_leaf = item != kIdle && (item & kLeafBit) != 0;
+		uint64_t node_lanes = __ballot(at_node), leaf_lanes = __ballot(at_leaf);
+		if ((node_lanes | leaf_lanes) == 0) {
+			if (!batch_pending) break;
+			continue;
+		}
+		walk_step(at_node, at_leaf, node_lanes, leaf_lanes);
 	}
 }
 

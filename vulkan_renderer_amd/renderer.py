@@ -463,6 +463,15 @@ class Renderer(HostScene):
             raise RuntimeError("assemble_frame_from_slabs failed")
 
 
+def frames_in_flight_for(rank_count):
+    """Depth of the frame pipeline that bench.py and profiles/tools/predict_scaling.py use when the frame is tiled over
+    `rank_count` GPUs.  Three frames like the reference's frame queue (main.c:1498); four when a rank's slab is an eighth
+    of the frame or less: its kernels then last about as long as their slowest wave, whatever the slab's size, and one more
+    frame in flight fills what that leaves idle (profiles/r07c: config 3 at N = 8 0.200 -> 0.190 ms per slab, config 4
+    2.42 -> 2.39; five and more lose again, and at N <= 4 and on one GPU three are best)."""
+    return 4 if rank_count >= 8 else 3
+
+
 def setup_config(scene, config, dataset, width=None, height=None, **overrides):
     """Applies one of the BASELINE.json configurations to a HostScene / Renderer."""
     from . import synthetic
