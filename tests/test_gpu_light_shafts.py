@@ -96,12 +96,20 @@ def test_pairs_whose_walk_met_too_many_triangles_rest_for_a_few_frames(large_dat
     assert failed > 0.2 * first["pairs"] and first["not_clear"]["other"] == 0
     for index, (image, rays, stats) in enumerate(resting):
         assert np.array_equal(image.view(np.uint32), first_image.view(np.uint32)), index
-        assert rays == first_rays, (index, rays, first_rays)
-        assert stats["clear_pairs"] == first["clear_pairs"] and stats["list_pairs"] == first["list_pairs"], index
+        # The lights of a patch are walked together and share the walk's frontier and step budget: while a hopeless light
+        # rests, the walks of the others get further - a few more pairs end clear or with a list, a few more of them find
+        # out that they are hopeless too (and rest from the next frame on).  Never fewer, never more rays.
+        assert rays <= first_rays and rays > 0.98 * first_rays, (index, rays, first_rays)
+        assert stats["clear_pairs"] + stats["list_pairs"] >= first["clear_pairs"] + first["list_pairs"], index
+        assert stats["clear_pairs"] + stats["list_pairs"] + sum(stats["not_clear"].values()) == stats["pairs"] == first["pairs"]
         use = index // contexts  # how often this frame's context has rendered before
-        walked = use % 8 == 0
-        assert stats["not_clear"]["triangle_in_the_way"] == (failed if walked else 0), (index, stats)
-        assert stats["not_clear"]["other"] == (0 if walked else failed), (index, stats)
+        if use == 0:
+            assert stats["not_clear"] == first["not_clear"], (index, stats)
+        elif use % 8 == 0:
+            # the pairs that failed in the first frame are walked again (and fail again)
+            assert stats["not_clear"]["triangle_in_the_way"] >= failed, (index, stats)
+        else:
+            assert stats["not_clear"]["other"] >= failed and stats["not_clear"]["triangle_in_the_way"] < 0.05 * failed, (index, stats)
     for image, rays, stats in walking:
         assert np.array_equal(image.view(np.uint32), first_image.view(np.uint32))
         assert rays == first_rays and stats["not_clear"]["triangle_in_the_way"] == failed and stats["not_clear"]["other"] == 0

@@ -72,6 +72,7 @@ constexpr uint32_t kShaftLeaves = 320;                        // triangles waiti
 #endif
 constexpr uint32_t kShaftLeafBatch = VKR_SHAFT_LEAF_BATCH;         // triangles that must wait before a batch of them is tested
 constexpr uint32_t kShaftMaxSteps = 40;                       // steps of 16 nodes (plus a fifth of it per light); more -> not clear (run-time knob VKR_SHAFT_MAX_STEPS)
+constexpr uint32_t kShaftSmallLaunchSteps = 12;               // the same for launches of less than 12 288 patches (shading_pass.hip)
 constexpr float kShaftDilation = 1.0f / 32.0f;
 // Measured and not adopted (profiles/r05h/): cutting every candidate triangle by all planes of the shaft (test (iii) below)
 // finds 7 % more clear pairs at config 3 (25.0 instead of 23.3 % of all pairs) but costs the kernel 17 registers and 300

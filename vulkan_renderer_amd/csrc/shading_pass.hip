@@ -254,7 +254,8 @@ static frame_pipeline* ensure_frames(shading_pass_t* pass) {
 	frames->shaft_rest = environment_knob("VKR_SHAFT_REST", kShaftRestFrames, 0u, 200u);
 	// VKR_SHAFT_MAX_STEPS: steps after which a walk gives up (plus a fifth of it per light that is walked along).  The shaft
 	// kernel of a small launch - a rank's slab at N = 8 - lasts as long as its longest walk.
-	frames->shaft_max_steps = environment_knob("VKR_SHAFT_MAX_STEPS", kShaftMaxSteps, 5u, 1000u);
+	// (0: by the size of the launch - kShaftMaxSteps, or kShaftSmallLaunchSteps below 12 288 shading waves)
+	frames->shaft_max_steps = environment_knob("VKR_SHAFT_MAX_STEPS", 0u, 0u, 1000u);
 	frames->leaf_batch = environment_knob("VKR_LEAF_BATCH", 16u, 1u, 64u);
 	frames->refill_threshold = environment_knob("VKR_REFILL_THRESHOLD", 0u, 0u, 64u);
 	// VKR_WIDE_REFILL: lanes of a tracing wave (four-wide tree) that have to be idle before they are handed the next rays,
@@ -878,7 +879,15 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				if (hip_failed(hipStreamWaitEvent((hipStream_t) device->frame_streams[i], frames->inputs_ready, 0), "waiting for the inputs")) return 1;
 			pass->inputs_changed = 0;
 		}
-		trace_blocks = compute_units * (frames->trace_waves ? frames->trace_waves : (max_terms >= 8u ? 8u : 4u));
+		// Small launches (round 5, profiles/r07f): a rank's slab at N = 8 is 4 080 shading waves on 3 072 wave slots.  Its
+		// kernels then last about as long as their slowest wave, and what is launched for a whole frame - 8 192 tracing
+		// waves for 230 k rays, shaft walks of up to 72 steps - is mostly waiting: with 2 tracing waves per SIMD and walks
+		// that give up after 12 steps (more rays traced, a shorter chain of kernels) the slab of config 3 takes 0.177
+		// instead of 0.199 ms, the target shape's 0.070 instead of 0.084; a quarter of the frame (8 160 waves) 0.316
+		// instead of 0.333.  The whole frame (32 640 waves) loses with either: 1.150 -> 1.176 ms with 12 steps.
+		const uint32_t launch_waves = shade_grid_size(blocks_per_band);
+		const uint32_t small_launch_waves = frames->trace_waves ? 0u : (launch_waves < 6144u ? 2u : (launch_waves < 12288u ? 4u : 0u));
+		trace_blocks = compute_units * (frames->trace_waves ? frames->trace_waves : (small_launch_waves ? small_launch_waves : (max_terms >= 8u ? 8u : 4u)));
 		// (queues of XCD x are only served by workgroups b with b % 8 == x)
 		trace_blocks = (trace_blocks + 7u) & ~7u;
 		p.ray_block = ray_mode == kRaysDeferredBlocks ? ray_block_size(max_terms) : 0u;
@@ -1005,7 +1014,9 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				tag = (tag ^ word) * 0x100000001b3ull;
 			const bool same_launch = frame->buffers.shaft_tag == tag;
 			frame->buffers.shaft_tag = tag;
-			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, lists ? frame->buffers.shaft_lists : NULL, extent, work, same_launch ? frames->shaft_rest : 0u, frames->shaft_max_steps);
+			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, lists ? frame->buffers.shaft_lists : NULL, extent, work, same_launch ? frames->shaft_rest : 0u,
+				// (a small launch lasts as long as its longest walk: above, at trace_blocks)
+				frames->shaft_max_steps ? frames->shaft_max_steps : (shaft_groups < 12288u ? kShaftSmallLaunchSteps : kShaftMaxSteps));
 			if (hip_failed(hipGetLastError(), "launching the light shaft kernel")) return 1;
 			p.shaft_clear = frame->buffers.shaft_clear;
 			p.shaft_rectangles = frame->buffers.shaft_rectangles;
