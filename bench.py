@@ -533,6 +533,8 @@ def run_workload(job, config, role, scene=None):
                                              "fetches_per_visible_ray": round((s["node_visits"] - s["node_visits_of_blocked_rays"]) / visible_rays, 2),
                                              "deepest_stack": s["deepest_stack"], "rays_beyond_lds_stack": s["rays_beyond_lds_stack"]})
         traversal["walked"] = "wide" if (structure.wide_nodes and not args.binary_traversal) else "binary"
+        traversal["note"] = ("replayed by a statistics kernel that walks the queued rays in batches of 64, each to its end: lane_use is what share of the lanes of such a batch "
+                             "is busy per step - the figure by which a tracing wave decides to hand rays to idle lanes instead (below 0.65, csrc/wavefront_kernels.h)")
     if assembled is not None:
         # single-GPU render of the whole frame with the same pass settings
         r.set_tiles(16, 0, 1, slab_layout=False)

@@ -333,7 +333,7 @@ def test_slab_exchange_with_one_rank_reproduces_the_frame(dataset, slab_format):
 
 
 @pytest.mark.parametrize("slab_format", ["rgba32f", "rgb8"])
-@pytest.mark.parametrize("rank_count, tile_size, frames_in_flight, band_count", [(2, 32, 3, 0), (2, 16, 2, 2), (4, 64, 3, 0), (3, 32, 1, 0)])
+@pytest.mark.parametrize("rank_count, tile_size, frames_in_flight, band_count", [(2, 32, 3, 0), (2, 16, 2, 2), (4, 64, 3, 0), (3, 32, 1, 0), (2, 32, 4, 0), (2, 16, 7, 0)])
 def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_count, tile_size, frames_in_flight, band_count, slab_format):
     """render_and_exchange_frame() with rank_count > 1 on ONE device: every rank is an application_t of its
     own, driven by its own thread; the collective is the local one (device-to-device copies with a
