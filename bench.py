@@ -908,6 +908,49 @@ def write_details(result, path=None):
     return os.path.relpath(path, ROOT)
 
 
+def timing_matrix_cells(job):
+    """Two cells of the reference's own timing matrix (src/experiment_list.c:366-409; all 260: profiles/tools/timing_matrix.py
+    and profiles/r07h_timing_matrix.md), measured in this run by the reference's protocol - median frame time of 110 frames -
+    with the matrix's settings: 1920x1080, diffuse only, projected solid angle sampling, no shadow rays, a decentral quad;
+    128 lights x 1 sample and 1 light x 128 samples.  For the details file."""
+    import importlib.util
+    from vulkan_renderer_amd import renderer, synthetic
+    spec = importlib.util.spec_from_file_location("timing_matrix", os.path.join(ROOT, "profiles", "tools", "timing_matrix.py"))
+    matrix = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(matrix)
+    dataset = job.dataset_of("bench")
+    cells = {}
+    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, frames_in_flight=1, timing_stride=1, arithmetic=job.args.mode)
+    r.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=True)
+    r.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
+    r.load_noise_table("white")
+    cam = synthetic.DEFAULT_CAMERA
+    r.set_camera(cam["position"], cam["rotation_x"], cam["rotation_z"], cam["vertical_fov"], cam["near"], cam["far"])
+    r.set_settings(width=1920, height=1080, trace_shadow_rays=False, sampling_strategies="diffuse_only", polygon_technique="projected_solid_angle")
+    r.set_lights(matrix.timing_lights(4, False, 1))
+    r.create_targets()
+    r.create_pass()
+    r.render_visibility()
+    for light_count, sample_count in ((128, 1), (1, 128)):
+        r.set_settings(sample_count=sample_count)
+        r.set_lights(matrix.timing_lights(4, False, light_count))
+        r.create_pass()
+        for _ in range(8):
+            r.render()
+        r.sync()
+        for _ in range(110):
+            r.render()
+        r.sync()
+        times = sorted(r.dispatch_ms(110))
+        median = times[len(times) // 2]
+        cells["%d_lights_x_%d_samples" % (light_count, sample_count)] = {
+            "frame_ms": round(median, 4), "light_samples_per_s": round(1920 * 1080 * light_count * sample_count / (median * 1e-3), 0),
+            "experiment": "timings_decentral_4%s_projected_solid_angle_ours" % ("_128" if light_count == 128 else "")}
+    r.close()
+    cells["protocol"] = "median of 110 frame times, one frame at a time (no shadow rays: a frame is one kernel), %s arithmetic; scene, noise and lights are stand-ins for the reference's downloaded assets (profiles/tools/timing_matrix.py)" % job.args.mode
+    return cells
+
+
 def parse_config(text):
     return text if text == "target" else int(text)
 
@@ -982,6 +1025,11 @@ def main():
         target_value = result["extra_workloads"]["config_target"]["value"]
         result["north_star_target"] = {"shape": "1920x1080, 4 spp, 1 polygonal light", "target_Msamples_per_s": 1000.0, "value": target_value, "met": bool(target_value >= 1000.0),
                                        "parity": result["extra_workloads"]["config_target"].get("parity")}
+    if not args.no_extra and args.config == 3 and not customised and job.world == 1 and job.rank == 0:
+        try:
+            result["timing_matrix_cells"] = timing_matrix_cells(job)
+        except Exception as error:  # (diagnostics for the details file: never a reason to lose the line)
+            result["timing_matrix_cells"] = {"error": repr(error)}
     if not args.no_secondary and args.config != 4 and not customised:
         second = run_workload(job, 4, "secondary")
         keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "shadow_rays_per_frame", "Mrays_per_s", "light_shafts", "stages", "scaling_parity", "setup", "roofline", "traversal")
