@@ -235,8 +235,12 @@ typedef struct shading_pass_s {
 		triangles (an occluder list, at most 12): the shading kernel decides those rays itself, with the tracing kernel's
 		triangle test.  Results of ray queries - and frames - are unchanged.  Environment VKR_LIGHT_SHAFTS: 0 off, 1 on,
 		default automatic - on when a pixel may queue 8 rays or more (samples x techniques x lights), where the walks
-		repay themselves; VKR_SHAFT_LISTS=0: no occluder lists.  last_shaft_groups: patches of the most recent
-		launch that were tested (0: the launch ran without the test); get_light_shaft_statistics() counts. */
+		repay themselves; VKR_SHAFT_LISTS=0: no occluder lists.  A verdict is a hint (a pair without one has its rays
+		traced, with the same result), so a frame context keeps the verdicts of its previous frame: a pair whose walk met
+		more triangles than a list holds is not walked again for seven of that context's frames (VKR_SHAFT_REST=0: every
+		pair in every frame), and get_light_shaft_statistics() counts such pairs under "anything else".  Launches of less
+		than 12 288 patches walk at most 12 steps (+ 2 per light) instead of 40 (+ 8), VKR_SHAFT_MAX_STEPS overrides.
+		last_shaft_groups: patches of the most recent launch that were tested (0: the launch ran without the test). */
 	uint32_t last_shaft_groups, reserved;
 } shading_pass_t;
 
