@@ -15,7 +15,7 @@ case $UNIT in
 	*) echo "unknown unit $UNIT"; exit 1;;
 esac
 mkdir -p build/ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -I../../include -I. -I/opt/rocm/include -fno-slp-vectorize $DEFS $EXTRA -c $SRC -o build/ab/${UNIT}_$TAG.o
-OBJ=$(ls build/*.o | grep -v "build/$UNIT.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvkr_$TAG.so $OBJ build/ab/${UNIT}_$TAG.o -lm -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result --offload-compress -I../../include -I. -I/opt/rocm/include -fno-slp-vectorize $DEFS $EXTRA -c $SRC -o build/ab/${UNIT}_$TAG.o
+OBJ=$(ls build/*.o | grep -v "build/$UNIT.o" | grep -v "build/ieee_")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 --offload-compress -shared -fPIC -o ../libvkr_$TAG.so $OBJ build/ab/${UNIT}_$TAG.o -lm -ldl
 echo built vulkan_renderer_amd/libvkr_$TAG.so
