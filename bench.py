@@ -814,7 +814,8 @@ def _short_roofline(roofline):
     if not roofline:
         return None
     out = {k: roofline.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    out.update(_pick(roofline, ("kernel", "kernel_ms", "algorithmic_bytes_per_launch", "pass_alone_ms")))
+    # (kernel_ms brackets shade_pixels alone; the shaft kernel that runs in front of it since round 4 is named next to it)
+    out.update(_pick(roofline, ("kernel", "kernel_ms", "light_shaft_kernel_ms", "algorithmic_bytes_per_launch", "pass_alone_ms")))
     if roofline.get("flops"):
         out["flops"] = _pick(roofline["flops"], ("achieved", "peak", "unit", "frac"))
     if roofline.get("valu_issue"):

@@ -203,10 +203,12 @@ struct frame_pipeline {
 	// frame whose worst case needs more is rendered in bands); VKR_BAND_COUNT forces
 	// the number of bands per frame (0: automatic)
 	// VKR_LIGHT_SHAFTS: 0 turns the shaft test off (every shadow ray is traced, as until round 3), 1 on; default 2:
-	// on when a pixel may queue 16 rays or more (samples x techniques x lights) - the walk of a patch costs about as
+	// on when a pixel may queue 8 rays or more (samples x techniques x lights) - the walk of a patch costs about as
 	// much as tracing 2.5 rays per pixel and light, and it is the patches with many rays per light and several lights
 	// that repay it (measured, profiles/r05m: config 3, 32 rays per pixel, 1.553 -> 1.443 ms; config 4, 128, 25.9 -> 23.0;
-	// the target shape, 8, 0.488 -> 0.500; config 2, 2 rays per pixel, 0.127 -> 0.192)
+	// the target shape, 8, 0.488 -> 0.500 before the occluder lists and 0.501 -> 0.443 with them, which is what moved
+	// the rule from 16 to 8; config 2, 2 rays per pixel, 0.127 -> 0.192)
+	// VKR_SHAFT_REST, VKR_SHAFT_MAX_STEPS, VKR_WIDE_REFILL, VKR_WIDE_REFILL_BELOW (round 5): ensure_frames()
 	uint32_t wide_stack_lds, leaf_batch, refill_threshold, wide_refill, wide_refill_below, trace_waves, trace_single_waves, wavefront_budget_mib, band_count, light_shafts, shaft_lists, shaft_rest, shaft_max_steps;
 };
 
