@@ -556,10 +556,17 @@ def run_workload(job, config, role, scene=None):
     pass_ms = float(np.mean(period_ms if (pipelined and period_ms) else launch_ms)) if launch_ms else float("nan")
     # the reference's protocol (src/frame_timer.c:24,47-72, main.c:1958-1959): the median of at least 100 frame
     # times; here of the periods between the ends of consecutive timed frames inside the timed region
-    median_ms = job.max_over_ranks(float(np.median(period_ms))) if (period_ms and steps >= 100 and len(period_ms) >= 8) else None
+    median_ms = None
+    if steps >= 100:
+        slowest = job.max_over_ranks(float(np.median(period_ms)) if (period_ms and len(period_ms) >= 8) else -1.0)
+        median_ms = slowest if slowest > 0.0 else None
     median_frames = steps if median_ms else None
-    if median_ms is None and protocol_periods and len(protocol_periods) >= 8:
-        median_ms, median_frames = job.max_over_ranks(float(np.median(protocol_periods))), 128
+    if primary and steps < 100:
+        # (every rank takes part in the reduction whatever it measured: a collective behind a local condition would hang)
+        local = float(np.median(protocol_periods)) if (protocol_periods and len(protocol_periods) >= 8) else -1.0
+        slowest = job.max_over_ranks(local)
+        if slowest > 0.0:
+            median_ms, median_frames = slowest, 128
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
