@@ -68,6 +68,21 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_entry_for(table, config, mode, scene, width, height, world, csrc_hash):
+    """The entry of profiles/pmc_traffic.json (rocprofv3 --pmc passes, profiles/collect.sh + summarize.py) that belongs to a
+    workload, or None.  Entries belong to one configuration, arithmetic mode, frame size AND scene ("config3_libm" = the
+    benchmark scene, "config3_libm_large" = the 2.6 M-triangle one: round 4 attached the benchmark scene's counters to the
+    large scene's line) and to one rank rendering the whole frame; `stale` says that the kernels have changed since."""
+    key = "config%s_%s%s" % (config, mode, "" if scene == "bench" else "_" + scene)
+    entry = table.get(key)
+    if not entry or world != 1 or width != entry.get("width") or height != entry.get("height") or entry.get("scene", "bench") != scene:
+        return None
+    pmc = dict(entry)
+    pmc["valu_floor_us"] = table.get(key + "_valu_floor_us")
+    pmc["stale"] = entry.get("csrc_hash") != csrc_hash
+    return pmc
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -571,16 +586,7 @@ def run_workload(job, config, role, scene=None):
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            table = json.load(open(pmc_path))
-            # entries belong to one configuration, arithmetic mode, frame size AND scene ("config3_libm" = the benchmark
-            # scene, "config3_libm_large" = the 2.6 M-triangle one): round 4 attached the benchmark scene's counters to
-            # the large scene's line
-            key = "config%s_%s%s" % (config, args.mode, "" if scene == "bench" else "_" + scene)
-            entry = table.get(key)
-            if entry and world == 1 and width == entry.get("width") and height == entry.get("height") and entry.get("scene", "bench") == scene:
-                pmc = dict(entry)
-                pmc["valu_floor_us"] = table.get(key + "_valu_floor_us")
-                pmc["stale"] = entry.get("csrc_hash") != kernel_source_hash()
+            pmc = pmc_entry_for(json.load(open(pmc_path)), config, args.mode, scene, width, height, world, kernel_source_hash())
         except Exception:
             pmc = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),

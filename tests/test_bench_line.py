@@ -115,3 +115,26 @@ def test_details_file_holds_the_whole_record(tmp_path):
     path = bench.write_details(record, str(tmp_path / "sub" / "bench_details.json"))
     assert path is not None
     assert json.load(open(tmp_path / "sub" / "bench_details.json")) == record
+
+
+def test_counters_are_attached_to_the_workload_they_were_measured_on():
+    """profiles/pmc_traffic.json: an entry belongs to a configuration, an arithmetic mode, a frame size and a SCENE, and to
+    the kernel sources it was measured with (round 4 showed the benchmark scene's HBM bytes on the large scene's line)"""
+    bench = _bench()
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    now = bench.kernel_source_hash()
+    for config, scene, size in ((3, "bench", (1920, 1080)), (3, "large", (1920, 1080)), (4, "bench", (3840, 2160)), ("target", "bench", (1920, 1080)), (2, "bench", (1920, 1080))):
+        entry = bench.pmc_entry_for(table, config, "libm", scene, size[0], size[1], 1, now)
+        assert entry is not None, (config, scene)
+        assert entry["scene"] == scene and entry["hbm_bytes_per_launch"] > 0 and entry["valu_floor_us"]["shade_pixels"] > 0
+        # (the committed entries are those of the committed kernels)
+        assert not entry["stale"], (config, scene, entry["csrc_hash"], now)
+        assert bench.pmc_entry_for(table, config, "libm", scene, size[0], size[1], 1, "0" * 16)["stale"]
+    bench_scene = bench.pmc_entry_for(table, 3, "libm", "bench", 1920, 1080, 1, now)
+    large_scene = bench.pmc_entry_for(table, 3, "libm", "large", 1920, 1080, 1, now)
+    assert bench_scene["hbm_bytes_per_launch"] != large_scene["hbm_bytes_per_launch"]
+    # another frame size, several ranks, a scene without an entry: nothing is attached
+    assert bench.pmc_entry_for(table, 3, "libm", "bench", 1280, 720, 1, now) is None
+    assert bench.pmc_entry_for(table, 3, "libm", "bench", 1920, 1080, 8, now) is None
+    assert bench.pmc_entry_for(table, 2, "libm", "large", 1920, 1080, 1, now) is None
+    assert bench.pmc_entry_for({"config3_libm": dict(bench_scene, scene="large")}, 3, "libm", "bench", 1920, 1080, 1, now) is None
