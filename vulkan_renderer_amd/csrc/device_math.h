@@ -76,6 +76,10 @@ VKR_DEV float positive_part(float x) { return (x > 0.0f) ? x : 0.0f; }
 // select(load a[i], load a[j]) into load a[select(i, j)], which forces register
 // arrays into scratch memory.
 VKR_DEV float opaque(float x) { asm("" : "+v"(x)); return x; }
+// The same for an integer, and pinned where it stands (volatile): what is computed from the result cannot be moved out of
+// the loop the call stands in.  For loop-invariant comparisons whose results - execution masks, two scalar registers each -
+// the optimiser would otherwise keep across a loop that has no scalar registers to spare.
+VKR_DEV uint32_t opaque_here(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 
 // Division.  IEEE modes: the correctly rounded quotient from v_rcp_f32 - the estimate refined by one
 // Newton step, the quotient, ONE correction of it with an exact (FMA) residual, v_div_fixup_f32 for
