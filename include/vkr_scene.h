@@ -39,7 +39,7 @@ typedef struct materials_s {
 	float* host_constants;
 	void* constants;
 	/*! VK_TRUE if at least one material texture is a real image (8-bit or BC1 / BC5 *.vkt):
-		then the pass samples textures per pixel (trilinear, software) instead of constants */
+		then the pass samples textures per pixel (anisotropic, up to 16 trilinear taps, in software) instead of constants */
 	VkBool32 textured;
 	/*! 3 per material, 4 uint32 each: first texel in texels, width, height,
 		mip_count | srgb << 16.  Width 0: this texture is the constant in host_constants. */

@@ -95,9 +95,11 @@ typedef struct oracle_frame_s {
 	uint32_t light_texture_count;
 } oracle_frame_t;
 
-/* textureGrad() of this build: isotropic trilinear filtering, repeat addressing.  level of detail
- * = log2 of the longer of the two screen-space derivative vectors in texels, clamped to the mip
- * chain; bilinear weights in exact fp32, x first; sRGB texels are decoded before filtering. */
+/* textureGrad() of this build: anisotropic filtering as the Vulkan specification sketches it, repeat addressing.
+ * N = min(ceil(P_max / P_min), 16, ceil(P_max)) trilinear taps along the longer axis of the footprint (P_max, P_min: the
+ * lengths of the two screen-space derivative vectors in texels), level of detail = log2(P_max / N) clamped to the mip
+ * chain, averaged in order; N = 1 is plain trilinear.  Bilinear weights in exact fp32, x first; sRGB texels are decoded
+ * before filtering.  (Rounds 1 - 4: isotropic trilinear.) */
 void oracle_sample_texture(const oracle_texture_t* texture, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]);
 /* textureLod(g_light_textures[i], uv, 0) of this build (sampler of main.c:611-621: linear filter,
  * u repeats, v clamps to the edge): bilinear in exact fp32, x first.  u is wrapped to [0,1) before

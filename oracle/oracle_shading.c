@@ -335,10 +335,24 @@ static void sample_level(const oracle_texture_t* t, uint32_t level, float u, flo
 	}
 }
 
+/* textureGrad with the sampler of src/scene.c:546-552 (linear filters, repeat, 16x anisotropy).  What a driver does with
+ * "anisotropy" is its own business; this build does what the Vulkan specification sketches (Texel Anisotropic Filtering; the
+ * example of GL_EXT_texture_filter_anisotropic): the footprint's longer axis P_max and shorter axis P_min in texels,
+ * N = min(ceil(P_max / P_min), 16) taps - never more than the footprint is texels long -, each a trilinear sample at
+ * level log2(P_max / N), spread evenly along the longer axis at uv + (i / (N + 1) - 1 / 2) d(uv), i = 1 ... N, and averaged
+ * in that order.  N = 1 is the isotropic trilinear sample of rounds 1 - 4 in every bit. */
+#define ORACLE_MAX_ANISOTROPY 16.0f
 void oracle_sample_texture(const oracle_texture_t* t, const float uv[2], const float duv_dx[2], const float duv_dy[2], float out_rgba[4]) {
 	float w = (float) t->width, h = (float) t->height;
 	float ax = duv_dx[0] * w, ay = duv_dx[1] * h, bx = duv_dy[0] * w, by = duv_dy[1] * h;
-	float rho = g_max(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+	float px = sqrtf(ax * ax + ay * ay), py = sqrtf(bx * bx + by * by);
+	/* (a NaN length makes y the longer axis and N = 1) */
+	int x_major = px >= py;
+	float p_max = g_max(px, py), p_min = x_major ? py : px;
+	float taps = ceilf(p_max / p_min);
+	taps = g_min(g_min(taps, ORACLE_MAX_ANISOTROPY), g_max(ceilf(p_max), 1.0f));
+	if (!(taps >= 1.0f)) taps = 1.0f;
+	float rho = p_max / taps;
 	float max_level = (float) (t->mip_count - 1);
 	/* rho <= 1 (magnification), NaN and 0 all select the finest level */
 	float lambda = (rho > 1.0f) ? g_min(o_log2(rho), max_level) : 0.0f;
@@ -346,10 +360,25 @@ void oracle_sample_texture(const oracle_texture_t* t, const float uv[2], const f
 	float fraction = lambda - level_0;
 	uint32_t l0 = (uint32_t) level_0;
 	uint32_t l1 = (l0 + 1 < t->mip_count) ? l0 + 1 : l0;
-	float c0[4], c1[4];
-	sample_level(t, l0, uv[0], uv[1], c0);
-	sample_level(t, l1, uv[0], uv[1], c1);
-	for (int c = 0; c != 4; ++c) out_rgba[c] = c0[c] * (1.0f - fraction) + c1[c] * fraction;
+	uint32_t count = (uint32_t) taps;
+	float du = x_major ? duv_dx[0] : duv_dy[0], dv = x_major ? duv_dx[1] : duv_dy[1];
+	float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+	for (uint32_t i = 0; i != count; ++i) {
+		float u = uv[0], v = uv[1];
+		if (count > 1) {
+			float offset = (float) (i + 1) / (taps + 1.0f) - 0.5f;
+			u = u + du * offset;
+			v = v + dv * offset;
+		}
+		float c0[4], c1[4];
+		sample_level(t, l0, u, v, c0);
+		sample_level(t, l1, u, v, c1);
+		for (int c = 0; c != 4; ++c) {
+			float tap = c0[c] * (1.0f - fraction) + c1[c] * fraction;
+			sum[c] = (count > 1) ? sum[c] + tap : tap;
+		}
+	}
+	for (int c = 0; c != 4; ++c) out_rgba[c] = (count > 1) ? sum[c] / taps : sum[c];
 }
 
 void oracle_sample_light_texture(const oracle_light_texture_t* t, const float uv[2], float out_rgba[4]) {

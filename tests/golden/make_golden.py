@@ -34,7 +34,11 @@ from vulkan_renderer_amd import renderer, synthetic  # noqa: E402
 import golden_cases  # noqa: E402
 
 
-def frames():
+def frames(only=None):
+    """only: None = all three files, or "textured" = textured_frames.npz alone (what depends on the material sampler, which
+    the reference leaves to the driver and this build defines: oracle_sample_texture)"""
+    if only == "textured":
+        return textured_frames()
     out = {}
     with tempfile.TemporaryDirectory() as d:
         dataset = synthetic.write_dataset(d, **golden_cases.DATASET)
@@ -45,6 +49,11 @@ def frames():
             print("%-28s %-60s mean %.5f" % (case["key"], name, image[..., :3].mean()))
             hs.close()
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **out)
+    textured_frames()
+    light_texture_frames()
+
+
+def textured_frames():
     out = {}
     with tempfile.TemporaryDirectory() as d:
         dataset = synthetic.write_dataset(d, **golden_cases.TEXTURED_DATASET)
@@ -55,6 +64,9 @@ def frames():
             print("%-28s %-60s mean %.5f" % (case["key"], name, image[..., :3].mean()))
             hs.close()
     np.savez_compressed(os.path.join(HERE, "textured_frames.npz"), **out)
+
+
+def light_texture_frames():
     out = {}
     with tempfile.TemporaryDirectory() as d:
         dataset = synthetic.write_dataset(d, **golden_cases.DATASET)
@@ -238,6 +250,9 @@ def host():
 if __name__ == "__main__":
     if not reference.available():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
-    frames()
-    functions()
-    host()
+    if len(sys.argv) > 1 and sys.argv[1] == "textured":
+        frames("textured")
+    else:
+        frames()
+        functions()
+        host()

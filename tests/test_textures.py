@@ -142,17 +142,59 @@ def test_sampler_levels_weights_and_wrapping():
     # repeat addressing: one whole turn later, and across the border (texel 3 of the row blends with texel 0)
     assert sample(texture, (1.375, 3.125), *tiny)[0] == sample(texture, (0.375, 0.125), *tiny)[0]
     assert abs(sample(texture, (1.0, 0.125), *tiny)[0] - (48 + 0) / 2 / 255) < 1e-6
-    # footprint of two texels: level 1; of four: level 2; in between: the mix
-    assert abs(sample(texture, (0.3, 0.3), (0.5, 0.0), (0.0, 0.1))[0] - 100 / 255) < 1e-6
-    assert abs(sample(texture, (0.3, 0.3), (1.0, 0.0), (0.0, 0.1))[0] - 200 / 255) < 1e-6
-    between = sample(texture, (0.3, 0.3), (0.70710678, 0.0), (0.0, 0.1))[0]
+    # a round footprint of two texels: level 1; of four: level 2; in between: the mix
+    assert abs(sample(texture, (0.3, 0.3), (0.5, 0.0), (0.0, 0.5))[0] - 100 / 255) < 1e-6
+    assert abs(sample(texture, (0.3, 0.3), (1.0, 0.0), (0.0, 1.0))[0] - 200 / 255) < 1e-6
+    between = sample(texture, (0.3, 0.3), (0.70710678, 0.0), (0.0, 0.70710678))[0]
     assert abs(between - 150 / 255) < 2e-3
     # far beyond the chain: the coarsest level
-    assert abs(sample(texture, (0.3, 0.3), (50.0, 0.0), (0.0, 9.0))[0] - 200 / 255) < 1e-6
+    assert abs(sample(texture, (0.3, 0.3), (50.0, 0.0), (0.0, 40.0))[0] - 200 / 255) < 1e-6
     # sRGB texels are decoded before filtering
     texture["srgb"] = 1
-    value = sample(texture, (0.3, 0.3), (1.0, 0.0), (0.0, 0.1))
+    value = sample(texture, (0.3, 0.3), (1.0, 0.0), (0.0, 1.0))
     assert abs(value[0] - ((200 / 255 + 0.055) / 1.055) ** 2.4) < 1e-6 and abs(value[3] - 200 / 255) < 1e-6
+
+
+def test_sampler_takes_its_taps_along_the_longer_axis_of_a_stretched_footprint():
+    """Anisotropic filtering as the Vulkan specification sketches it (the reference asks its driver for 16x, src/scene.c:546-552):
+    N = min(ceil(P_max / P_min), 16, ceil(P_max)) trilinear taps at level log2(P_max / N) along the longer axis."""
+    level0 = np.zeros((8, 8, 4), np.uint8)
+    level0[..., 0] = (np.arange(64).reshape(8, 8) * 3) % 251
+    level0[..., 3] = 255
+    levels = [level0, np.full((4, 4, 4), 60, np.uint8), np.full((2, 2, 4), 120, np.uint8), np.full((1, 1, 4), 180, np.uint8)]
+    texture = {"texels": np.concatenate([l.reshape(-1, 4) for l in levels]), "width": 8, "height": 8, "mip_count": 4, "srgb": 0}
+
+    def bilinear(u, v):
+        x, y = u * 8 - 0.5, v * 8 - 0.5
+        x0, y0 = int(np.floor(x)), int(np.floor(y))
+        fx, fy = x - x0, y - y0
+        texel = lambda i, j: level0[j % 8, i % 8, 0] / 255.0
+        return (texel(x0, y0) * (1 - fx) + texel(x0 + 1, y0) * fx) * (1 - fy) + (texel(x0, y0 + 1) * (1 - fx) + texel(x0 + 1, y0 + 1) * fx) * fy
+    # four texels long, one wide, along x: four taps at the finest level (P_max / N = 1) at u - 0.15, - 0.05, + 0.05, + 0.15
+    uv = (0.40, 0.30)
+    got = sample(texture, uv, (0.5, 0.0), (0.0, 0.125))[0]
+    want = np.mean([bilinear(uv[0] + (i / 5 - 0.5) * 0.5, uv[1]) for i in range(1, 5)])
+    assert abs(got - want) < 1e-6, (got, want)
+    # the same footprint along y
+    got = sample(texture, uv, (0.125, 0.0), (0.0, 0.5))[0]
+    want = np.mean([bilinear(uv[0], uv[1] + (i / 5 - 0.5) * 0.5) for i in range(1, 5)])
+    assert abs(got - want) < 1e-6, (got, want)
+    # along a diagonal: both coordinates move
+    got = sample(texture, uv, (0.3, 0.3), (-0.05, 0.05))[0]
+    p_max, p_min = np.hypot(2.4, 2.4), np.hypot(0.4, 0.4)
+    taps = min(int(np.ceil(p_max / p_min)), 16, int(np.ceil(p_max)))
+    assert taps == 4
+    # (level log2(3.39 / 4) < 0: the finest)
+    want = np.mean([bilinear(uv[0] + (i / (taps + 1) - 0.5) * 0.3, uv[1] + (i / (taps + 1) - 0.5) * 0.3) for i in range(1, taps + 1)])
+    assert abs(got - want) < 1e-6, (got, want)
+    # 64 texels long and 2 wide: sixteen taps (the limit) at level log2(64 / 16) = 2, whose texels are all 120
+    assert abs(sample(texture, uv, (8.0, 0.0), (0.0, 0.25))[0] - 120 / 255) < 1e-6
+    # a derivative of zero: the other axis alone decides, no NaN
+    value = sample(texture, uv, (0.5, 0.0), (0.0, 0.0))
+    assert np.isfinite(value).all() and abs(value[0] - np.mean([bilinear(uv[0] + (i / 5 - 0.5) * 0.5, uv[1]) for i in range(1, 5)])) < 1e-6
+    assert np.isfinite(sample(texture, uv, (0.0, 0.0), (0.0, 0.0))).all()
+    # a round footprint is the plain trilinear sample
+    assert abs(sample(texture, uv, (0.25, 0.0), (0.0, 0.25))[0] - 60 / 255) < 1e-6
 
 
 @pytest.mark.parametrize("case", golden_cases.TEXTURED_CASES, ids=[c["key"] for c in golden_cases.TEXTURED_CASES])

@@ -3,8 +3,8 @@
  *
  * The reference uploads the blocks as they are and lets the GPU's texture unit decode BC1 / BC5
  * and filter anisotropically (scene.c:486-559); here the blocks are decoded once at load time and
- * the filtering is done in software by the material resolve kernel (trilinear, see
- * csrc/shading_pass.hip).  Block decoding follows the format definitions (endpoint expansion
+ * the filtering is done in software by the material resolve kernel (anisotropic: up to 16
+ * trilinear taps along the footprint's longer axis, sample_texture() in csrc/shading_kernel.h).  Block decoding follows the format definitions (endpoint expansion
  * by bit replication, interpolants rounded to nearest); what a given GPU does in the last bit
  * is not specified by Vulkan, so this is a documented choice, not a pinned one. */
 #include "vkr_internal.h"

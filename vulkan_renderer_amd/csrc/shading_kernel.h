@@ -369,20 +369,46 @@ VKR_DEV float4 sample_level(const shade_params& p, const texture_view& t, uint32
 	return out;
 }
 
-// textureGrad of this build: isotropic trilinear filtering with repeat addressing
+// textureGrad with the sampler of src/scene.c:546-552 (linear filters, repeat addressing, 16x anisotropy), operation for
+// operation oracle_sample_texture() of oracle/oracle_shading.c: what the Vulkan specification sketches as anisotropic
+// filtering - N = min(ceil(P_max / P_min), 16, ceil(P_max)) trilinear taps at level log2(P_max / N), spread along the longer
+// axis of the footprint at uv + (i / (N + 1) - 1 / 2) d(uv) and averaged in order; N = 1 is the isotropic trilinear sample of
+// rounds 1 - 4 in every bit.  (The quotients may have any operands - a derivative of zero, a footprint of a thousand texels:
+// the full-range division.)
+constexpr float kMaxAnisotropy = 16.0f;
 VKR_DEV float4 sample_texture(const shade_params& p, const texture_view& t, f2 uv, f2 duv_dx, f2 duv_dy) {
 	float w = (float) t.width, h = (float) t.height;
 	float ax = duv_dx.x * w, ay = duv_dx.y * h, bx = duv_dy.x * w, by = duv_dy.y * h;
-	float rho = gmax(square_root(ax * ax + ay * ay), square_root(bx * bx + by * by));
+	float px = square_root(ax * ax + ay * ay), py = square_root(bx * bx + by * by);
+	bool x_major = px >= py;
+	float p_max = gmax(px, py), p_min = x_major ? py : px;
+	float taps = ceilf(divide_full_range(p_max, p_min));
+	taps = gmin(gmin(taps, kMaxAnisotropy), gmax(ceilf(p_max), 1.0f));
+	if (!(taps >= 1.0f)) taps = 1.0f;
+	float rho = divide_full_range(p_max, taps);
 	float max_level = (float) (t.mip_count - 1);
 	float lambda = (rho > 1.0f) ? gmin(log2_poly(rho), max_level) : 0.0f;
 	float level_0 = floorf(lambda);
 	float fraction = lambda - level_0;
 	uint32_t l0 = (uint32_t) level_0;
 	uint32_t l1 = (l0 + 1 < t.mip_count) ? l0 + 1 : l0;
-	float4 c0 = sample_level(p, t, l0, uv.x, uv.y), c1 = sample_level(p, t, l1, uv.x, uv.y);
-	return make_float4(c0.x * (1.0f - fraction) + c1.x * fraction, c0.y * (1.0f - fraction) + c1.y * fraction,
-		c0.z * (1.0f - fraction) + c1.z * fraction, c0.w * (1.0f - fraction) + c1.w * fraction);
+	uint32_t count = (uint32_t) taps;
+	float du = x_major ? duv_dx.x : duv_dy.x, dv = x_major ? duv_dx.y : duv_dy.y;
+	float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	for (uint32_t i = 0; i != count; ++i) {
+		float u = uv.x, v = uv.y;
+		if (count > 1) {
+			float offset = divide_full_range((float) (i + 1), taps + 1.0f) - 0.5f;
+			u = u + du * offset;
+			v = v + dv * offset;
+		}
+		float4 c0 = sample_level(p, t, l0, u, v), c1 = sample_level(p, t, l1, u, v);
+		float4 tap = make_float4(c0.x * (1.0f - fraction) + c1.x * fraction, c0.y * (1.0f - fraction) + c1.y * fraction,
+			c0.z * (1.0f - fraction) + c1.z * fraction, c0.w * (1.0f - fraction) + c1.w * fraction);
+		sum = (count > 1) ? make_float4(sum.x + tap.x, sum.y + tap.y, sum.z + tap.z, sum.w + tap.w) : tap;
+	}
+	if (count > 1) sum = make_float4(divide_full_range(sum.x, taps), divide_full_range(sum.y, taps), divide_full_range(sum.z, taps), divide_full_range(sum.w, taps));
+	return sum;
 }
 
 // The texture reads of get_shading_data (:754-785) for one pixel: screen-space derivatives of the
