@@ -1,5 +1,5 @@
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r08z; mkdir -p $O; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r09z; mkdir -p $O; export TMPDIR=/tmp
 cd $R
 timeout 1400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -2 $O/pytest_gpu.log
