@@ -345,6 +345,17 @@ def libm_identity():
     return "%s %s, %s, %s" % (name or "libc", version or "?", platform.machine(), variant)
 
 
+def protocol_window(frames_in_flight, least=8):
+    """Frames between two timing brackets of a pipelined run: the smallest multiple of the frames in flight that is at
+    least `least`.  Frames in flight finish in BURSTS - n shading kernels share the GPU and end together, then nothing ends
+    for n frame times (profiles/r10a/frame_periods.jsonl: periods of 0.2, 0.2, 3.0 ms with three in flight) - so the time
+    between the ends of two frames that are k frames apart is a whole number of bursts, and its median over windows of k
+    frames is biased unless n divides k: with k = 8 and n = 3 two windows in three span three bursts, one spans two, and
+    the median sits 10 % above the mean (rounds 4 and 5 reported exactly that gap between `value` and `value_from_median`)."""
+    n = max(1, int(frames_in_flight))
+    return ((max(1, int(least)) + n - 1) // n) * n
+
+
 def run_workload(job, config, role, scene=None):
     """Sets one BASELINE configuration up, times it and returns the dict that describes the run.
     role: "primary" (the headline: CPU baseline, parity, other arithmetic modes), "extra" (a short run of another
@@ -373,8 +384,10 @@ def run_workload(job, config, role, scene=None):
     elif role == "extra":
         # at least 100 timed frames, so that the reference's protocol (median of >= 100 frame times) applies
         steps, warmup = 200, 20
-    timing_stride = 1 if steps < 4 * args.timing_stride else args.timing_stride
     frames_in_flight_requested = args.frames_in_flight or renderer.frames_in_flight_for(world if (world > 1 or args.force_distributed) else 1)
+    # frames between two timing brackets: a multiple of the frames in flight (protocol_window())
+    window = protocol_window(frames_in_flight_requested, args.timing_stride)
+    timing_stride = 1 if steps < 4 * window else window
 
     # ---- set-up (untimed, reported separately: BASELINE.md section 3) -------------------------
     r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=args.mode, inline_rays=args.inline_rays,
@@ -412,6 +425,10 @@ def run_workload(job, config, role, scene=None):
             # CPU process group (VKR_BENCH_BACKEND=gloo: several ranks on ONE GPU, where RCCL refuses to form a
             # communicator): the same schedule with the collective staged through the host
             r.create_exchange_with_gather(job.host_staged_gather(), exchange)
+
+        # the gathered slabs, tile-major, are the frame every rank holds; rows are made when somebody reads (the fences
+        # of this run, once each) unless --assemble every-frame asks for the scatter kernel behind every all-gather
+        r.assemble_on_demand(args.assemble == "on-demand")
 
         def step():
             r.render_and_exchange(None)
@@ -481,14 +498,40 @@ def run_workload(job, config, role, scene=None):
     # and `ms_per_step` stay those of the K timed steps.
     protocol_periods = None
     if primary and steps < 100:
-        for _ in range(128):
+        # sixteen more windows of `window` frames each (>= 128 frames), bracketed like the windows of a long run
+        r.app.shading_pass.timing_stride = window
+        for _ in range(17 * window):
             step()
         fence()
-        protocol_periods = r.frame_period_ms(max(1, 128 // max(timing_stride, 1) - 1))
-        if timing_stride == 1 and len(protocol_periods) >= 64:
-            # (frames in flight finish in bursts: a period between two consecutive frames says little; like the long runs,
-            # whose events bracket every eighth frame, periods are averaged over eight frames before the median is taken)
-            protocol_periods = [float(np.mean(protocol_periods[i:i + 8])) for i in range(0, len(protocol_periods) - 7, 8)]
+        protocol_periods = r.frame_period_ms(15)
+        r.app.shading_pass.timing_stride = timing_stride
+    # ---- every frame to the host (PCIe-inclusive; never `value`): a ring of targets, each read back through pinned staging
+    # on the pass's copy stream while the next frames render (begin_read_back / end_read_back, include/vkr_shading_pass.h)
+    with_readback = None
+    if primary and not distributed:
+        ring = [torch.empty((height, width, 4), dtype=torch.float32, device="cuda") for _ in range(frames_in_flight_requested + 1)]
+        frame_bytes = width * height * 16
+
+        def host_frames(count):
+            for i in range(count):
+                slot = i % len(ring)
+                if i >= len(ring):
+                    r.end_read_back(slot)  # the consumer takes frame i - len(ring) before its target and staging are reused
+                r.render(ring[slot].data_ptr())
+                r.begin_read_back(slot, ring[slot].data_ptr(), frame_bytes)
+            for slot in range(min(count, len(ring))):
+                r.end_read_back(slot)
+        host_frames(2 * len(ring))  # (the first use of a slot allocates its pinned memory)
+        frames_to_host = max(32, min(steps, 200))
+        fence()
+        t = time.perf_counter()
+        host_frames(frames_to_host)
+        fence()
+        host_ms = (time.perf_counter() - t) / frames_to_host * 1e3
+        with_readback = {"ms_per_frame": round(host_ms, 4), "value": round(total_pixels * sample_count / (host_ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "frames": frames_to_host,
+                         "bytes_per_frame": frame_bytes, "GB_per_s": round(frame_bytes / (host_ms * 1e-3) / 1e9, 2), "targets": len(ring),
+                         "note": "every frame lands in pinned host memory (RGBA32F, whole frame): render into a ring of device targets, begin_read_back() behind each frame on the pass's copy stream, end_read_back() when the ring comes round; PCIe-inclusive, never `value`"}
+        del ring
     stages = None
     if exchange != "none":
         mine = r.exchange_ms() or [float("nan")] * 3
@@ -561,6 +604,13 @@ def run_workload(job, config, role, scene=None):
     # PCIe-inclusive figures (never part of `value`): the frame to the host, a visibility buffer from the host
     t = time.perf_counter()
     gpu_image = r.read_radiance()
+    pageable_readback_ms = (time.perf_counter() - t) * 1e3
+    # ... and through the pinned staging of begin_read_back() / end_read_back() (second use of the slot: the first one allocates)
+    r.begin_read_back(0)
+    r.end_read_back(0)
+    t = time.perf_counter()
+    r.begin_read_back(0)
+    r.end_read_back(0)
     readback_ms = (time.perf_counter() - t) * 1e3
     t = time.perf_counter()
     r.upload_visibility(visibility)
@@ -575,13 +625,13 @@ def run_workload(job, config, role, scene=None):
     if steps >= 100:
         slowest = job.max_over_ranks(float(np.median(period_ms)) if (period_ms and len(period_ms) >= 8) else -1.0)
         median_ms = slowest if slowest > 0.0 else None
-    median_frames = steps if median_ms else None
+    median_frames = (len(period_ms) * window) if median_ms else None
     if primary and steps < 100:
         # (every rank takes part in the reduction whatever it measured: a collective behind a local condition would hang)
         local = float(np.median(protocol_periods)) if (protocol_periods and len(protocol_periods) >= 8) else -1.0
         slowest = job.max_over_ranks(local)
         if slowest > 0.0:
-            median_ms, median_frames = slowest, 128
+            median_ms, median_frames = slowest, len(protocol_periods) * window
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
@@ -589,7 +639,10 @@ def run_workload(job, config, role, scene=None):
             pmc = pmc_entry_for(json.load(open(pmc_path)), config, args.mode, scene, width, height, world, kernel_source_hash())
         except Exception:
             pmc = None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
+    # bound: what binds the dominant kernel - the issue of its VALU instructions (valu_issue below).  achieved /
+    # peak / frac are the NOMINAL HBM figures SURVEY.md 8(d) prescribes for the metric (algorithmic bytes over the kernel's
+    # duration against 8 TB/s): nominal_bound says so.
+    roofline = {"bound": "valu_issue", "nominal_bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                 "traffic": pmc["hbm_bytes_per_launch"] if (pmc and not pmc["stale"]) else None,
                 "traffic_source": (("%s: rocprofv3 --pmc passes of this configuration and arithmetic mode (profiles/collect.sh), kernel sources %s" % (pmc.get("source", "profiles/pmc_traffic.json"), pmc.get("csrc_hash")))
                                    if not pmc["stale"] else "profiles/pmc_traffic.json has an entry, but for other kernel sources (%s, now %s): not attached" % (pmc.get("csrc_hash"), kernel_source_hash())) if pmc else None,
@@ -622,13 +675,13 @@ def run_workload(job, config, role, scene=None):
     result = {
         "metric": "Msamples/s (pixels x spp / s), shading pass", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
-        "median_frame_period_ms": round(median_ms, 4) if median_ms else None, "median_over_frames": median_frames,
+        "median_frame_period_ms": round(median_ms, 4) if median_ms else None, "median_over_frames": median_frames, "median_window_frames": window if median_ms else None,
         "value_from_median": round(total_pixels * sample_count / (median_ms * 1e-3) / 1e6, 3) if median_ms else None,
         "latency_ms": round(float(np.mean(pass_alone_ms)), 4) if pass_alone_ms else None,
         "value_single_frame": round(total_pixels * sample_count / (float(np.mean(pass_alone_ms)) * 1e-3) / 1e6, 3) if pass_alone_ms else None,
         "shaded_fraction": round(shaded_fraction, 4), "value_shaded_only": round(value * shaded_fraction, 3),
         "value_note": "value = W x H x spp / time over ALL pixels of the frame (SURVEY.md 8d), background included, with config.frames_in_flight frames queued like the reference's frame queue (main.h:374-390); latency_ms / value_single_frame = one frame at a time (roofline.pass_alone_ms); value_shaded_only counts the pixels that see geometry"
-                      + ("; median_frame_period_ms = median of the periods between consecutive timed frames (the reference's protocol: median of >= 100 frame times)" if median_ms else "; the median of frame periods is reported from 100 steps on"),
+                      + ("; median_frame_period_ms = median over windows of median_window_frames frames - a multiple of the frames in flight, which finish in bursts - of the time between the ends of the window's first and last frame, per frame (the reference's protocol: median of >= 100 frame times, src/frame_timer.c:47-72)" if median_ms else "; the median of frame periods is reported from 100 steps on"),
         "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config %s: %dx%d, %d spp per technique, %d polygonal light(s), %s + %s, %s, %s arithmetic"
                                % ("%s%s" % (config, "" if scene == "bench" else " on the large scene"), width, height, sample_count, light_count, settings["sampling_strategies"], settings["polygon_technique"],
@@ -636,7 +689,7 @@ def run_workload(job, config, role, scene=None):
                                                                             renderer.BVH_BUILDER_NAME[int(structure.builder)])) if settings["trace_shadow_rays"] else "no shadow rays", args.mode),
                    "width": width, "height": height, "spp": sample_count, "lights": light_count, "techniques": techniques,
                    "parallelism": ("tiles %dx%d round-robin over %d rank(s), %s" % (args.tile_size, args.tile_size, world,
-                                   ("RCCL all-gather of %s slabs (ncclAllGather from C) + scatter per frame inside the timed region, overlapped with the next frame" % exchange) if exchange != "none" else "every rank keeps its slab of the frame (no data-path collective)")) if distributed else "one GPU, whole frame",
+                                   ("RCCL all-gather of %s slabs (ncclAllGather from C, in place) %s inside the timed region, overlapped with the next frame" % (exchange, "+ scatter per frame" if args.assemble == "every-frame" else "per frame, un-tiled when read")) if exchange != "none" else "every rank keeps its slab of the frame (no data-path collective)")) if distributed else "one GPU, whole frame",
                    "scene": scene, "scene_triangles": int(r.app.scene.mesh.triangle_count), "scene_materials": int(r.app.scene.materials.material_count), "ltc_resolution": int(r.app.ltc_table.roughness_count),
                    "arithmetic": args.mode, "bands_per_frame": bands_per_frame, "frames_in_flight": frames_in_flight},
         "prewarm_frames": prewarm, "host_issue_ms_per_step": round(issue_seconds / steps * 1e3, 4),
@@ -647,10 +700,12 @@ def run_workload(job, config, role, scene=None):
         "setup": {"load_and_upload_ms": round(load_ms - structure.build_milliseconds, 2), "bvh_build_ms": round(float(structure.build_milliseconds), 3),
                   "bvh_builder": renderer.BVH_BUILDER_NAME[int(structure.builder)], "bvh_node_bytes": 16 * int(structure.node_count) + 64 * int(structure.wide_node_count),
                   "bvh_wide_nodes": int(structure.wide_node_count), "bvh_stack_need": int(structure.wide_stack_need), "visibility_pass_ms": round(visibility_ms, 3), "first_visibility_pass_ms": round(first_visibility_ms, 3),
-                  "readback_ms": round(readback_ms, 3), "upload_ms": round(upload_ms, 3),
-                  "note": "untimed set-up, once per scene (load = parse .vks / LTC fits / noise + copies to the device); visibility_pass_ms = primary visibility per frame (mean of 4 launches after the first, host clock around a synchronised device), first_visibility_pass_ms includes one-time costs; readback = RGBA32F frame to the host, upload = a visibility buffer from the host (what a PCIe-inclusive frame would add; never part of value)"},
+                  "readback_ms": round(readback_ms, 3), "pageable_readback_ms": round(pageable_readback_ms, 3), "upload_ms": round(upload_ms, 3),
+                  "note": "untimed set-up, once per scene (load = parse .vks / LTC fits / noise + copies to the device); visibility_pass_ms = primary visibility per frame (mean of 4 launches after the first, host clock around a synchronised device), first_visibility_pass_ms includes one-time costs; readback = RGBA32F frame into pinned staging (begin_read_back + end_read_back, nothing else running), pageable_readback = read_back_radiance() into pageable memory, upload = a visibility buffer from the host; with_readback (top level) = frames per second when EVERY frame goes to the host while the next ones render; never part of value"},
         "roofline": roofline,
     }
+    if with_readback:
+        result["with_readback"] = with_readback
     if stages:
         result["stages"] = stages
     if scaling_parity:
@@ -753,6 +808,9 @@ def run_workload(job, config, role, scene=None):
         cores = available_cpus()
         band = int(min(height, 24))
         starts = sorted(set(int(f * (height - band)) for f in (1 / 6, 1 / 2, 5 / 6)))
+        if config == 1:
+            # BASELINE configs[0] is the CPU-runnable case: the WHOLE frame against the oracle, and the oracle timed beside it below
+            band, starts = height, [0]
         oracle.set_math_mode(renderer.ORACLE_MATH_MODE[args.mode])
         differing, compared, worst = 0, 0, 0.0
         for y0 in starts:
@@ -761,6 +819,16 @@ def run_workload(job, config, role, scene=None):
             differing += int((g[..., :3].view(np.uint32) != cpu[..., :3].view(np.uint32)).any(axis=-1).sum())
             compared += band * width
             worst = max(worst, float(np.abs(np.nan_to_num(g[..., :3].astype(np.float64) - cpu[..., :3], nan=1e3)).max()))
+        if config == 1:
+            # "CPU C reference of polygon_sampling math (plumbing, no GPU)": the same frame on the host cores, about two seconds of it
+            passes, cpu_time = 0, 0.0
+            while cpu_time < 2.0 and passes < 4096:
+                t = time.perf_counter()
+                oracle.shade(frame_o, 0, height, cores)
+                cpu_time += time.perf_counter() - t
+                passes += 1
+            result["cpu_only"] = {"value": round(passes * total_pixels * sample_count / cpu_time / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port", "seconds": round(cpu_time, 2),
+                                  "ms_per_frame": round(cpu_time / passes * 1e3, 3), "sample": "%d passes over the whole %dx%d frame" % (passes, width, height)}
         oracle.set_math_mode(0)
         result["parity"] = {"sample_pixels": compared, "sample": "%d bands of %d rows" % (len(starts), band), "pixels_differing_in_bits": differing, "max_abs": worst,
                             "nan": int(np.isnan(gpu_image).sum()), "oracle_math_mode": renderer.ORACLE_MATH_MODE[args.mode],
@@ -786,7 +854,7 @@ def mode_companion(job, config, mode, headline_image, width, height, sample_coun
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import classify_outliers
     args, torch = job.args, job.torch
-    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=mode, timing_stride=args.timing_stride, frames_in_flight=frames_in_flight)
+    r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=mode, timing_stride=protocol_window(frames_in_flight, args.timing_stride), frames_in_flight=frames_in_flight)
     renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh)
     r.set_tiles(16, 0, 1, slab_layout=False)
     r.create_targets()
@@ -827,6 +895,8 @@ def _short_roofline(roofline):
     if not roofline:
         return None
     out = {k: roofline.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if roofline.get("nominal_bound"):
+        out["nominal_bound"] = roofline["nominal_bound"]
     # (kernel_ms brackets shade_pixels alone; the shaft kernel that runs in front of it since round 4 is named next to it)
     out.update(_pick(roofline, ("kernel", "kernel_ms", "light_shaft_kernel_ms", "algorithmic_bytes_per_launch", "pass_alone_ms")))
     if roofline.get("flops"):
@@ -858,6 +928,8 @@ def _short_workload(w):
         out["parity"] = _pick(_short_parity(w["parity"]), ("pixels_differing", "sample_pixels", "within_tolerance"))
     if w.get("scaling_parity"):
         out["scaling_parity"] = _pick(w["scaling_parity"], ("pixels_differing_from_single_gpu_frame", "pixels"))
+    if w.get("cpu_only"):
+        out["cpu_only"] = _pick(w["cpu_only"], ("value", "cores"))
     return out
 
 
@@ -865,10 +937,12 @@ def short_line(result, details_path=None):
     """The ONE line bench.py prints: the contract's keys, numbers and short identifiers only (no prose), at most
     LINE_LIMIT characters.  Everything else the run measured - extra workloads in full, traversal and light-shaft
     statistics, set-up times, the other arithmetic mode, where each number comes from - goes to the details file."""
-    line = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_frame_period_ms", "median_over_frames", "value_from_median",
+    line = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_frame_period_ms", "median_over_frames", "median_window_frames", "value_from_median",
                           "higher_is_better", "scaling", "dtype", "data"))
     line["vs_baseline"] = result.get("vs_baseline")
     line.update(_pick(result, ("value_shaded_only", "shaded_fraction", "latency_ms")))
+    if result.get("with_readback"):
+        line["value_with_readback"] = result["with_readback"].get("value")
     cfg = result.get("config", {})
     line["config"] = _pick(cfg, ("workload", "width", "height", "spp", "lights", "techniques", "scene", "scene_triangles", "arithmetic", "frames_in_flight", "parallelism"))
     for key in ("workload", "parallelism"):
@@ -893,7 +967,7 @@ def short_line(result, details_path=None):
         line["secondary"] = _short_workload(result["secondary"])
     extras = result.get("extra_workloads") or {}
     if extras:
-        line["extra_workloads"] = {name: _pick(_short_workload(w), ("value", "ms_per_step", "parity")) for name, w in extras.items()}
+        line["extra_workloads"] = {name: _pick(_short_workload(w), ("value", "ms_per_step", "parity", "cpu_only")) for name, w in extras.items()}
     if result.get("other_modes"):
         line["other_modes"] = {m: _pick(v, ("value", "ms_per_step", "within_tolerance")) for m, v in result["other_modes"].items()}
     line["details"] = details_path
@@ -903,7 +977,7 @@ def short_line(result, details_path=None):
             break
         line.pop(drop, None)
     if len(json.dumps(line, separators=(",", ":"))) > LINE_LIMIT:
-        line["config"]["workload"] = line["config"]["workload"][:160]
+        line["config"]["workload"] = str(line["config"].get("workload", ""))[:160]
     return line
 
 
@@ -935,32 +1009,35 @@ def timing_matrix_cells(job):
     dataset = job.dataset_of("bench")
     cells = {}
     r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, frames_in_flight=1, timing_stride=1, arithmetic=job.args.mode)
-    r.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=True)
-    r.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
-    r.load_noise_table("white")
-    cam = synthetic.DEFAULT_CAMERA
-    r.set_camera(cam["position"], cam["rotation_x"], cam["rotation_z"], cam["vertical_fov"], cam["near"], cam["far"])
-    r.set_settings(width=1920, height=1080, trace_shadow_rays=False, sampling_strategies="diffuse_only", polygon_technique="projected_solid_angle")
-    r.set_lights(matrix.timing_lights(4, False, 1))
-    r.create_targets()
-    r.create_pass()
-    r.render_visibility()
-    for light_count, sample_count in ((128, 1), (1, 128)):
-        r.set_settings(sample_count=sample_count)
-        r.set_lights(matrix.timing_lights(4, False, light_count))
+    try:
+        r.load_scene(dataset["scene"], dataset["textures"], acceleration_structure=True)
+        r.load_ltc_table(dataset["ltc"], dataset["fresnel_count"])
+        r.load_noise_table("white")
+        cam = synthetic.DEFAULT_CAMERA
+        r.set_camera(cam["position"], cam["rotation_x"], cam["rotation_z"], cam["vertical_fov"], cam["near"], cam["far"])
+        r.set_settings(width=1920, height=1080, trace_shadow_rays=False, sampling_strategies="diffuse_only", polygon_technique="projected_solid_angle")
+        r.set_lights(matrix.timing_lights(4, False, 1))
+        r.create_targets()
         r.create_pass()
-        for _ in range(8):
-            r.render()
-        r.sync()
-        for _ in range(110):
-            r.render()
-        r.sync()
-        times = sorted(r.dispatch_ms(110))
-        median = times[len(times) // 2]
-        cells["%d_lights_x_%d_samples" % (light_count, sample_count)] = {
-            "frame_ms": round(median, 4), "light_samples_per_s": round(1920 * 1080 * light_count * sample_count / (median * 1e-3), 0),
-            "experiment": "timings_decentral_4%s_projected_solid_angle_ours" % ("_128" if light_count == 128 else "")}
-    r.close()
+        r.render_visibility()
+        for light_count, sample_count in ((128, 1), (1, 128)):
+            r.set_settings(sample_count=sample_count)
+            r.set_lights(matrix.timing_lights(4, False, light_count))
+            r.create_pass()
+            for _ in range(8):
+                r.render()
+            r.sync()
+            for _ in range(110):
+                r.render()
+            r.sync()
+            times = sorted(r.dispatch_ms(110))
+            median = times[len(times) // 2]
+            cells["%d_lights_x_%d_samples" % (light_count, sample_count)] = {
+                "frame_ms": round(median, 4), "light_samples_per_s": round(1920 * 1080 * light_count * sample_count / (median * 1e-3), 0),
+                "experiment": "timings_decentral_4%s_projected_solid_angle_ours" % ("_128" if light_count == 128 else "")}
+    finally:
+        # (also when a launch fails: the config-4 secondary that follows needs the memory)
+        r.close()
     cells["protocol"] = "median of 110 frame times, one frame at a time (no shadow rays: a frame is one kernel), %s arithmetic; scene, noise and lights are stand-ins for the reference's downloaded assets (profiles/tools/timing_matrix.py)" % job.args.mode
     return cells
 
@@ -983,6 +1060,8 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the fixed frame is cut into tiles (default); weak = the frame height grows with N")
     ap.add_argument("--exchange", choices=("rgba32f", "rgb8", "none"), default="rgba32f",
                     help="N > 1: all-gather of the tile slabs per frame as float radiance (default) or as packed RGB8 of the encoded output, then the scatter into the frame on every rank; none leaves every rank's slab in its HBM")
+    ap.add_argument("--assemble", choices=("on-demand", "every-frame"), default="on-demand",
+                    help="N > 1: on-demand (default) = a frame stays the gathered slabs (tile-major) and is un-tiled when it is read - once per fence of this run; every-frame = a scatter kernel behind every all-gather (SURVEY.md 8e names both)")
     ap.add_argument("--tile-size", type=int, default=32)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -1000,7 +1079,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=(1, 2, 3, 4, 5, 6, 7, 8),
                     help="n >= 2: n consecutive frames overlap on the device's frame streams, like the frames of the reference's frame queue, which is as deep as "
                          "its swapchain (main.c:1498: typically 3).  Default: 3, and 4 from eight ranks on (renderer.frames_in_flight_for)")
-    ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events")
+    ap.add_argument("--timing-stride", type=int, default=8, help="bracket every n-th frame of the timed region with HIP events (rounded up to a multiple of the frames in flight: protocol_window())")
     ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")
     ap.add_argument("--ltc-resolution", type=int, default=64, help="roughness / inclination resolution R of the generated LTC tables (SURVEY.md 8d: 64)")
@@ -1031,9 +1110,9 @@ def main():
     if not args.no_extra and args.config == 3 and not customised and job.world == 1:
         # the other 1920x1080 shapes the contract names, on the same clock: north_star's target and BASELINE config 2
         keep = ("value", "unit", "steps", "warmup", "ms_per_step", "median_frame_period_ms", "value_from_median", "latency_ms", "value_single_frame", "shaded_fraction",
-                "config", "shadow_rays_per_frame", "Mrays_per_s", "light_shafts", "roofline", "parity", "traversal", "setup")
+                "config", "shadow_rays_per_frame", "Mrays_per_s", "light_shafts", "roofline", "parity", "traversal", "setup", "cpu_only")
         result["extra_workloads"] = {}
-        for extra, scene in (("target", args.scene), (2, args.scene)) + ((("3", "large"),) if args.scene == "bench" and not args.no_large_scene else ()):
+        for extra, scene in (("target", args.scene), (2, args.scene), (1, args.scene)) + ((("3", "large"),) if args.scene == "bench" and not args.no_large_scene else ()):
             line = run_workload(job, int(extra) if extra != "target" else extra, "extra", scene)
             result["extra_workloads"]["config_%s%s" % (extra, "" if scene == args.scene else "_large_scene")] = {k: line[k] for k in keep if k in line}
         target_value = result["extra_workloads"]["config_target"]["value"]

@@ -242,6 +242,8 @@ typedef struct shading_pass_s {
 		than 12 288 patches walk at most 12 steps (+ 2 per light) instead of 40 (+ 8), VKR_SHAFT_MAX_STEPS overrides.
 		last_shaft_groups: patches of the most recent launch that were tested (0: the launch ran without the test). */
 	uint32_t last_shaft_groups, reserved;
+	/*! pinned staging, copy stream and events of begin_read_back() / end_read_back() (internal) */
+	void* readback;
 } shading_pass_t;
 
 /*! The slice of reference application_t (main.h:440-476) that the pass uses */
@@ -368,6 +370,19 @@ VKR_API int encode_output(application_t* app, VkBool32 output_linear_rgb);
 VKR_API int read_back_radiance(application_t* app, float* host_rgba);
 VKR_API int read_back_encoded(application_t* app, uint8_t* host_rgba8);
 VKR_API int read_back_visibility(application_t* app, uint32_t* host_primitives);
+/*! Asynchronous read-back through pinned staging (round 6).  The reference's screenshot path maps a host-visible image
+	and waits for the device (implement_screenshot, main.c:1719-1770); a host that wants EVERY frame cannot afford
+	that - read_back_radiance() into pageable memory runs at 12 GB/s and stops the frame pipeline, 2.8 ms for a
+	1920x1080 RGBA32F frame of 1.15 ms.  begin_read_back() queues the copy of `bytes` bytes at `device_source` (NULL: the
+	whole radiance target) into the pinned staging buffer of `slot` (0 ... VKR_MAX_FRAMES_IN_FLIGHT) on a copy stream
+	of the pass, ordered behind the most recent render_shading_pass() / render_and_exchange_frame() - and behind
+	app->device.stream, for sources produced there (encode_output) - and returns at once; the frames that follow
+	keep running.  end_read_back() waits for that copy and returns the staging memory (valid until the slot's next
+	begin_read_back(); NULL on failure).  A later frame that WRITES the same device buffer (the resolve kernel of the
+	wavefront path, the shading kernel otherwise) waits for the copy on the device by itself; callers that want no
+	such wait render into a ring of targets (render_shading_pass(app, target[i])) and read them back slot by slot. */
+VKR_API int begin_read_back(application_t* app, uint32_t slot, const void* device_source, uint64_t bytes);
+VKR_API const void* end_read_back(application_t* app, uint32_t slot);
 /*! Upload a visibility buffer produced elsewhere (tests, external rasteriser) */
 VKR_API int upload_visibility(application_t* app, const uint32_t* host_primitives);
 /*! GPU time of the last render_shading_pass launch in milliseconds, measured with

@@ -42,6 +42,9 @@ typedef struct slab_exchange_id_s {
 /*! The collective behind the exchange: rank-major concatenation of every rank's `send_bytes` bytes
 	at `send` into `gathered` on EVERY rank, queued on hipStream_t `stream`; `set` is the buffer set
 	of the frame (slab_exchange_t.gathered[set] == gathered).  Called once per frame by every rank.
+	The exchange calls it IN PLACE: send == gathered + rank * send_bytes (the rank has shaded its slab into
+	its own slot), which is ncclAllGather's in-place form; a transport must not read `send` after it has
+	begun to overwrite that slot with anything else.
 	The default is ncclAllGather (create_slab_exchange); create_slab_exchange_with_gather() takes any
 	other transport, create_local_slab_exchange() one made of device-to-device copies for ranks that
 	live in one process.  Returns 0 on success. */
@@ -83,6 +86,14 @@ typedef struct slab_exchange_s {
 	uint32_t timing_stride;
 	/*! where the most recent frame is assembled */
 	void* last_frame;
+	/*! Set by the caller after creation.  0 (default): every frame is scattered into its target by
+		render_and_exchange_frame().  1: a frame stays what the all-gather delivers - all slabs, tile-major, in
+		gathered[last_set] on every rank - and is un-tiled only when a reader asks: assemble_exchanged_frame(), or
+		finish_slab_exchange() for the most recent frame ("un-tile on the consumer only").  A frame
+		rendered with an explicit out_frame is always scattered. */
+	uint32_t assemble_on_demand;
+	/*! buffer set of the most recent frame; whether that frame has been scattered into the default target */
+	uint32_t last_set, last_frame_assembled;
 } slab_exchange_t;
 
 /*! Creates the rendezvous token (ncclGetUniqueId).  Call on one rank. */
@@ -109,16 +120,21 @@ VKR_API int create_local_slab_exchange(slab_exchange_t* exchange, application_t*
 VKR_API void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app);
 /*! One frame of the multi-GPU pass, queued asynchronously: render_shading_pass() of this rank's
 	tiles into a slab (encoded on the same stream for rgb8), ncclAllGather of the slabs on the
-	exchange stream, scatter into `out_frame` (NULL: render_targets.radiance for rgba32f,
-	render_targets.encoded for rgb8).  The collective and the scatter of frame k overlap the
+	exchange stream - in place: the slab is shaded into this rank's slot of the gathered buffer -, scatter into
+	`out_frame` (NULL: render_targets.radiance for rgba32f, render_targets.encoded for rgb8; not at all with
+	exchange->assemble_on_demand and no out_frame).  The collective and the scatter of frame k overlap the
 	shading of frame k + 1; frames complete in order. */
 VKR_API int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, void* out_frame);
+/*! Un-tiles the most recent frame - the gathered slabs of its buffer set - into `out_frame` (NULL: render_targets.radiance
+	for rgba32f, render_targets.encoded for rgb8) on the exchange stream, behind that frame's all-gather.  For exchanges with
+	assemble_on_demand; call finish_slab_exchange() before reading the target on app->device.stream. */
+VKR_API int assemble_exchanged_frame(application_t* app, slab_exchange_t* exchange, void* out_frame);
 /*! The collective alone (ncclAllGather unless the exchange was created with another one):
 	`send_bytes` bytes per rank from `send` into `gathered` (rank-major) on hipStream_t `stream`, for
 	callers that schedule the steps themselves */
 VKR_API int all_gather_slabs(slab_exchange_t* exchange, const void* send, void* gathered, void* stream);
 /*! Makes app->device.stream wait (on the device) for every frame submitted so far to be
-	assembled.  read_back_radiance() / read_back_encoded() / encode_output() then see that frame. */
+	assembled (assemble_on_demand: un-tiles the most recent frame into the default target first).  read_back_radiance() / read_back_encoded() / encode_output() then see that frame. */
 VKR_API int finish_slab_exchange(application_t* app, slab_exchange_t* exchange);
 /*! Durations in milliseconds of the most recent timed frame that has completed:
 	{shading (+ encoding) of the slab, all-gather, scatter into the frame}.  Blocks until that

@@ -144,24 +144,29 @@ def test_full_size_config_3_is_bit_exact_in_the_polynomial_mode_too(big_dataset)
     assert stats["bit_exact"] and stats["nan"] == 0, stats
 
 
-def test_bands_of_full_size_config_4_are_bit_exact(big_dataset):
+def test_the_whole_full_size_config_4_frame_is_bit_exact(big_dataset):
     """BASELINE config 4 at its full size (3840x2160, 8 lights of 3 ... 6 vertices, 8 spp per technique,
-    478 M shadow rays): the V = 7 kernel, whose polygon tables leave room for two waves per SIMD only.
-    The oracle shades three bands of 16 rows (a whole frame would take it minutes)."""
+    128 shadow rays per pixel at most): the V = 7 kernel.  EVERY pixel of the frame against the oracle (until round 5
+    three bands of 16 rows; the whole frame takes the oracle about a minute on the GPU box's host cores), shaded in
+    slices of 120 rows so that a failure names where it is."""
     import oracle
-    r, image = render_config(big_dataset, 4, 3840, 2160)
+    r, image = render_config(big_dataset, 4, 3840, 2160, frames_in_flight=3)
     assert r.app.shading_pass.max_polygon_vertex_count == 7
     inputs = r.host_inputs(r.read_visibility())
     bvh = oracle.Bvh(inputs["quantized_positions"], inputs["dequantization_factor"], inputs["dequantization_summand"])
     frame = oracle.make_frame(inputs, r.oracle_settings(), bvh)
     oracle.set_math_mode(renderer.ORACLE_MATH_MODE[r.arithmetic])
+    differing = {}
     try:
-        for y0 in (600, 1272, 2000):
-            cpu = oracle.shade(frame, y0, y0 + 16)
-            assert np.array_equal(image[y0:y0 + 16].view(np.uint32), cpu[y0:y0 + 16].view(np.uint32)), y0
+        for y0 in range(0, 2160, 120):
+            cpu = oracle.shade(frame, y0, y0 + 120)
+            count = int((image[y0:y0 + 120].view(np.uint32) != cpu[y0:y0 + 120].view(np.uint32)).any(axis=-1).sum())
+            if count:
+                differing[y0] = count
     finally:
         oracle.set_math_mode(0)
         r.close()
+    assert not differing, "pixels that differ from the oracle, by first row of the slice: %r" % differing
     assert not np.isnan(image).any()
 
 
@@ -334,6 +339,26 @@ def test_slab_exchange_with_one_rank_reproduces_the_frame(dataset, slab_format):
         assert np.array_equal(out, expected[3.0])
     stages = r.exchange_ms()
     assert stages is not None and all(ms >= 0.0 for ms in stages)
+    # on demand (round 6): frames stay the gathered slabs, tile-major; the reader - finish_slab_exchange() for the render
+    # target, assemble_exchanged_frame() for a buffer of the caller - un-tiles the most recent one
+    r.assemble_on_demand(True)
+    for exposure in (1.0, 3.0, 2.0):
+        r.app.render_settings.exposure_factor = exposure
+        r.render_and_exchange(None)
+    assert r.exchange.last_frame_assembled == 0
+    mine = DeviceBuffer(e.width * e.height * (16 if slab_format == "rgba32f" else 4))
+    r.assemble_exchanged(mine.ptr.value)
+    r.finish_exchange()
+    assert r.exchange.last_frame_assembled == 1
+    r.sync()
+    if slab_format == "rgba32f":
+        assert np.array_equal(r.read_radiance().view(np.uint32), expected[2.0].view(np.uint32))
+        assert np.array_equal(mine.download((e.height, e.width, 4), np.float32).view(np.uint32), expected[2.0].view(np.uint32))
+    else:
+        assert r.lib.read_back_encoded(C.byref(r.app), out.ctypes.data) == 0
+        assert np.array_equal(out, expected[2.0])
+        assert np.array_equal(mine.download((e.height, e.width, 4), np.uint8), expected[2.0])
+    mine.free()
     r.destroy_exchange()
     r.close()
 
@@ -384,6 +409,19 @@ def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_coun
             results[rank] = [frame.download((height, width, 4), np.float32 if slab_format == "rgba32f" else np.uint8) for frame in frames]
             for frame in frames:
                 frame.free()
+            # the same ranks with frames that stay tile-major until they are read (assemble_on_demand): the last frame of
+            # a run of frames, un-tiled by finish_slab_exchange() into the render target
+            r.assemble_on_demand(True)
+            for exposure in exposures[:frames_in_flight + 2]:
+                r.app.render_settings.exposure_factor = exposure
+                r.render_and_exchange(None)
+            r.finish_exchange()
+            if slab_format == "rgba32f":
+                results[rank].append(r.read_radiance())
+            else:
+                encoded = np.zeros((height, width, 4), np.uint8)
+                assert r.lib.read_back_encoded(C.byref(r.app), encoded.ctypes.data) == 0
+                results[rank].append(encoded)
             r.destroy_exchange()
             r.close()
         except Exception as error:  # (a rank that dies would leave its peers in the rendezvous)
@@ -399,7 +437,7 @@ def test_ranks_of_one_process_exchange_their_slabs_end_to_end(dataset, rank_coun
     assert all(not t.is_alive() for t in threads), "a rank is stuck in the exchange"
     lib.destroy_local_slab_group(group)
     for rank in range(rank_count):
-        for index, exposure in enumerate(exposures):
+        for index, exposure in enumerate(exposures + [exposures[min(len(exposures), frames_in_flight + 2) - 1]]):
             got, want = results[rank][index], expected[exposure]
             same = np.array_equal(got.view(np.uint32), want.view(np.uint32)) if slab_format == "rgba32f" else np.array_equal(got, want)
             assert same, (rank, index, exposure, int((got != want).any(axis=-1).sum()))
@@ -569,3 +607,48 @@ def test_c_program_tiles_an_experiment_over_the_gpus_of_the_node(tmp_path):
         assert done.returncode == 0, done.stdout + done.stderr
         assert "0 values differ from the single-GPU frame" in done.stdout, done.stdout
     assert os.path.exists(os.path.join(root, "data", "multi_gpu.png"))
+
+
+@pytest.mark.parametrize("frames_in_flight", [1, 3])
+def test_asynchronous_read_back_delivers_every_frame_while_the_next_ones_render(dataset, frames_in_flight):
+    """begin_read_back() / end_read_back() (round 6): copies into pinned staging on a stream of their own, ordered behind the
+    frame they read and in front of the next frame that writes the same buffer.  (a) one target, a copy queued behind every
+    frame and collected a frame later: each staging buffer holds ITS frame although the next one was already queued;
+    (b) a ring of targets, all copies in flight at once."""
+    r, _ = render_config(dataset, 3, 200, 120, frames_in_flight=frames_in_flight)
+    e = r.app.swapchain.extent
+    expected = {}
+    for exposure in (1.0, 2.0, 3.0):
+        r.app.render_settings.exposure_factor = exposure
+        r.render()
+        expected[exposure] = r.read_radiance()
+    exposures = [1.0, 2.0, 3.0, 1.0, 3.0, 2.0, 1.0]
+    # (a) the render target itself, two slots in turn
+    got = []
+    for index, exposure in enumerate(exposures):
+        r.app.render_settings.exposure_factor = exposure
+        r.render()
+        r.begin_read_back(index % 2)
+        if index:
+            got.append(r.end_read_back((index - 1) % 2).copy())
+    got.append(r.end_read_back((len(exposures) - 1) % 2).copy())
+    for exposure, image in zip(exposures, got):
+        assert np.array_equal(image.view(np.uint32), expected[exposure].view(np.uint32)), exposure
+    # (b) a ring of targets of the caller
+    targets = [DeviceBuffer(e.width * e.height * 16) for _ in range(4)]
+    for index, exposure in enumerate(exposures[:4]):
+        r.app.render_settings.exposure_factor = exposure
+        r.render(targets[index].ptr.value)
+        r.begin_read_back(index, targets[index].ptr.value, e.width * e.height * 16)
+    for index, exposure in enumerate(exposures[:4]):
+        assert np.array_equal(r.end_read_back(index).view(np.uint32), expected[exposure].view(np.uint32)), (index, exposure)
+    # an encoded frame goes the same way (the source is produced on device->stream)
+    r.app.render_settings.exposure_factor = 2.0
+    r.render()
+    encoded = r.read_encoded(False, 0)
+    r.begin_read_back(0, r.app.render_targets.encoded, e.width * e.height * 4)
+    assert np.array_equal(r.end_read_back(0, (e.height, e.width, 4), np.uint8), encoded)
+    assert r.lib.begin_read_back(C.byref(r.app), 99, None, 0) == 1
+    for t in targets:
+        t.free()
+    r.close()

@@ -185,3 +185,36 @@ def test_long_thin_triangles_are_split_into_several_leaves_and_nothing_else_chan
     assert split["stats"]["triangle_tests"] < 0.5 * whole["stats"]["triangle_tests"]
     bench = build(big_dataset, True)
     assert bench["leaves"] == bench["triangles"]
+
+
+def test_a_mesh_of_nothing_but_slivers_is_still_split_within_four_leaves_per_triangle(tmp_path):
+    """Every triangle of this mesh wants 16 fragments (diagonal slats 6 m long, 4 cm wide): sixteenfold growth, which the
+    builder refuses.  Until round 5 it then built the whole mesh unsplit; now it lowers the cap per triangle until the
+    leaves fit into four per triangle.  The frame stays the oracle's either way."""
+    from helpers import oracle_render
+    dataset = synthetic.write_dataset(str(tmp_path / "slats"), grid=8, box_count=0, ltc_resolution=16, fresnel_count=8)
+    rng = np.random.default_rng(7)
+    count = 600
+    centres = np.stack([rng.uniform(-4.0, 4.0, count), rng.uniform(-4.0, 4.0, count), rng.uniform(0.5, 3.0, count)], -1)
+    along = np.stack([np.cos(rng.uniform(0.6, 1.0, count)), np.sin(rng.uniform(0.6, 1.0, count)), rng.uniform(-0.4, 0.4, count)], -1) * 3.0
+    across = np.cross(along, np.array([0.0, 0.0, 1.0]))
+    across *= 0.02 / np.linalg.norm(across, axis=-1, keepdims=True)
+    a, b, c, d = centres - along - across, centres + along - across, centres + along + across, centres - along + across
+    slats = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)], 0)
+    floor = np.array([[[-8, -8, 0], [8, -8, 0], [8, 8, 0]], [[-8, -8, 0], [8, 8, 0], [-8, 8, 0]]], np.float64)
+    positions = np.concatenate([floor, slats], 0)
+    normals = np.cross(positions[:, 1] - positions[:, 0], positions[:, 2] - positions[:, 0])
+    normals /= np.linalg.norm(normals, axis=-1, keepdims=True)
+    normals = np.repeat(normals[:, None, :], 3, 1)
+    names = synthetic.write_material_textures(dataset["textures"])
+    synthetic.write_vks(dataset["scene"], positions, normals, positions[:, :, :2] * 0.5, np.zeros(len(positions), np.uint8), names)
+    r, image = render(dataset, 3, 384, 216)
+    structure = r.app.scene.acceleration_structure
+    leaves, triangles = int(structure.leaf_count), int(r.app.scene.mesh.triangle_count)
+    rays = r.last_ray_count()
+    cpu, _, _ = oracle_render(r, visibility=r.read_visibility(), math_mode=renderer.ORACLE_MATH_MODE[r.arithmetic])
+    r.close()
+    print(leaves, triangles, rays)
+    assert triangles == 2 * count + 2
+    assert 2 * triangles < leaves <= 4 * triangles, (leaves, triangles)
+    assert rays > 0 and compare(image, cpu)["bit_exact"]

@@ -42,6 +42,18 @@ def test_ieee_modes_match_their_oracle_bitwise(dataset, config, arithmetic, inli
     assert stats["bit_exact"], stats
 
 
+@pytest.mark.parametrize("arithmetic", ["libm", "exact"])
+def test_config_1_at_its_stated_size_matches_its_oracle_bitwise(dataset, arithmetic):
+    """BASELINE configs[0] as it is worded: 512x512, 1 spp, one triangle light, diffuse-only LTC, no ray visibility"""
+    r, image, visibility = gpu_render(dataset, 1, 512, 512, arithmetic)
+    assert not r.app.shading_pass.use_ray_tracing and r.app.scene_specification.polygonal_light_count == 1
+    cpu, inputs, bvh = oracle_render(r, visibility=visibility, math_mode=renderer.ORACLE_MATH_MODE[arithmetic])
+    stats = compare(image, cpu)
+    r.close()
+    assert (visibility != 0xFFFFFFFF).mean() > 0.3
+    assert stats["nan"] == 0 and stats["bit_exact"], stats
+
+
 @pytest.mark.parametrize("config", [1, 2, 3])
 def test_fast_mode_within_tolerance(dataset, config):
     r, image, visibility = gpu_render(dataset, config, 256, 144, "fast")

@@ -140,7 +140,7 @@ class ShadingPass(C.Structure):
                 ("arithmetic_mode", C.c_int32), ("inline_rays", C.c_int32), ("frames_in_flight", C.c_uint32), ("inputs_changed", C.c_uint32), ("last_frame_in_flight", C.c_uint32), ("wavefront", C.c_void_p), ("ray_counter", C.c_void_p), ("pixel_materials", C.c_void_p), ("pixel_materials_size", C.c_size_t), ("last_dispatch_ms", C.c_float), ("timing_ring", C.c_void_p), ("timing_ring_size", C.c_uint32), ("timing_cursor", C.c_uint32),
                 ("timing_stride", C.c_uint32), ("frame_counter", C.c_uint32), ("last_frame_traced_rays", C.c_uint32), ("binary_traversal", C.c_int32),
                 ("wait_before_next_frame", C.c_void_p), ("last_frame_stream", C.c_void_p), ("band_count", C.c_uint32), ("last_band_count", C.c_uint32),
-                ("last_shaft_groups", C.c_uint32), ("reserved", C.c_uint32)]
+                ("last_shaft_groups", C.c_uint32), ("reserved", C.c_uint32), ("readback", C.c_void_p)]
 
 
 class Application(C.Structure):
@@ -177,7 +177,8 @@ class SlabExchange(C.Structure):
                 ("gathered", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("stream", C.c_void_p),
                 ("rendered", C.c_void_p * MAX_FRAMES_IN_FLIGHT), ("assembled", C.c_void_p * MAX_FRAMES_IN_FLIGHT),
                 ("timing", (C.c_void_p * 5) * MAX_FRAMES_IN_FLIGHT), ("timed", C.c_uint32 * MAX_FRAMES_IN_FLIGHT),
-                ("frame_counter", C.c_uint64), ("timing_stride", C.c_uint32), ("last_frame", C.c_void_p)]
+                ("frame_counter", C.c_uint64), ("timing_stride", C.c_uint32), ("last_frame", C.c_void_p),
+                ("assemble_on_demand", C.c_uint32), ("last_set", C.c_uint32), ("last_frame_assembled", C.c_uint32)]
 
 
 SLAB_FORMAT = {"rgba32f": 0, "rgb8": 1}
@@ -233,6 +234,8 @@ SIGNATURES = {
     "read_back_radiance": (C.c_int, [P(Application), C.c_void_p]),
     "read_back_encoded": (C.c_int, [P(Application), C.c_void_p]),
     "read_back_visibility": (C.c_int, [P(Application), C.c_void_p]),
+    "begin_read_back": (C.c_int, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
+    "end_read_back": (C.c_void_p, [P(Application), C.c_uint32]),
     "upload_visibility": (C.c_int, [P(Application), C.c_void_p]),
     "get_last_dispatch_milliseconds": (C.c_float, [P(Application)]),
     "get_last_ray_count": (C.c_uint64, [P(Application)]),
@@ -274,6 +277,7 @@ SIGNATURES = {
     "create_local_slab_exchange": (C.c_int, [P(SlabExchange), P(Application), C.c_void_p, C.c_int]),
     "destroy_slab_exchange": (None, [P(SlabExchange), P(Application)]),
     "render_and_exchange_frame": (C.c_int, [P(Application), P(SlabExchange), C.c_void_p]),
+    "assemble_exchanged_frame": (C.c_int, [P(Application), P(SlabExchange), C.c_void_p]),
     "all_gather_slabs": (C.c_int, [P(SlabExchange), C.c_void_p, C.c_void_p, C.c_void_p]),
     "finish_slab_exchange": (C.c_int, [P(Application), P(SlabExchange)]),
     "get_slab_exchange_milliseconds": (C.c_uint32, [P(SlabExchange), P(C.c_float)]),

@@ -5,9 +5,15 @@
  *
  * Streams of one frame k (buffer set b = k mod set_count):
  *   frame stream (the pass's own, render_shading_pass)   shade, trace, resolve [, encode] -> rendered[b]
- *   exchange stream (owned by the exchange)              wait rendered[b], all-gather, scatter -> assembled[b]
+ *   exchange stream (owned by the exchange)              wait rendered[b], all-gather [, scatter] -> assembled[b]
  * and the frame that reuses set b waits for assembled[b] before it starts, so the collective of
- * frame k runs while frame k + 1 is shaded.  Contract: BASELINE.json configs[3], SURVEY.md 8(e). */
+ * frame k runs while frame k + 1 is shaded.  Contract: BASELINE.json configs[3], SURVEY.md 8(e).
+ *
+ * Round 6: the all-gather is IN PLACE - a rank shades (or encodes) straight into its own slot of gathered[b],
+ * send == gathered + rank * send_bytes, the form ncclAllGather documents as in place: no copy of the own slab, and
+ * with one rank no data moves at all.  And the scatter is optional (exchange->assemble_on_demand): the gathered
+ * slabs, tile-major, ARE the frame every rank holds; a reader that wants rows un-tiles them when it reads
+ * (assemble_exchanged_frame, finish_slab_exchange) - SURVEY.md 8(e): "or un-tile on the consumer only". */
 #include "vkr_internal.h"
 #include "vkr_slab_exchange.h"
 #include <hip/hip_runtime_api.h>
@@ -178,7 +184,9 @@ static int gather_with_copies(void* context, uint32_t rank, uint32_t set, const 
 			break;
 		}
 		if (reused && q != rank) failed = hip_failed(hipStreamWaitEvent(s, (hipEvent_t) peer->assembled[set], 0), "waiting for a peer's scatter");
-		if (!failed) failed = hip_failed(hipMemcpyAsync((uint8_t*) peer->gathered[set] + (size_t) rank * send_bytes, send, (size_t) send_bytes, hipMemcpyDeviceToDevice, s), "copying a slab to a peer");
+		/* (the rank's own slot is where the frame was shaded into: in place, nothing to copy) */
+		void* slot = (uint8_t*) peer->gathered[set] + (size_t) rank * send_bytes;
+		if (!failed && slot != send) failed = hip_failed(hipMemcpyAsync(slot, send, (size_t) send_bytes, hipMemcpyDeviceToDevice, s), "copying a slab to a peer");
 	}
 	if (!failed) failed = hip_failed(hipEventRecord(group->copied[rank][set], s), "marking the copies");
 	++group->frames[rank];
@@ -205,8 +213,8 @@ void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
 		free(binding);
 	}
 	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT; ++b) {
-		if (exchange->send[b] && exchange->send[b] != exchange->slab_radiance[b]) (void) hipFree(exchange->send[b]);
-		if (exchange->slab_radiance[b]) (void) hipFree(exchange->slab_radiance[b]);
+		/* (rgba32f: slab_radiance[b] == send[b] is the rank's slot of gathered[b]; rgb8: send[b] is, and the float slab is its own) */
+		if (exchange->slab_radiance[b] && exchange->slab_radiance[b] != exchange->send[b]) (void) hipFree(exchange->slab_radiance[b]);
 		if (exchange->gathered[b]) (void) hipFree(exchange->gathered[b]);
 		if (exchange->rendered[b]) (void) hipEventDestroy((hipEvent_t) exchange->rendered[b]);
 		if (exchange->assembled[b]) (void) hipEventDestroy((hipEvent_t) exchange->assembled[b]);
@@ -239,16 +247,19 @@ static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app
 	if (hip_failed(hipSetDevice(app->device.hip_device), "selecting the device")) return 1;
 	int failed = hip_failed(hipStreamCreateWithFlags((hipStream_t*) &exchange->stream, hipStreamNonBlocking), "creating the exchange stream");
 	for (uint32_t b = 0; b != sets && !failed; ++b) {
-		failed = hip_failed(hipMalloc(&exchange->slab_radiance[b], exchange->slab_pixel_count * 16u), "allocating a slab")
-			|| hip_failed(hipMalloc(&exchange->gathered[b], exchange->send_bytes * rank_count), "allocating the gathered slabs")
+		failed = hip_failed(hipMalloc(&exchange->gathered[b], exchange->send_bytes * rank_count), "allocating the gathered slabs")
 			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->rendered[b], hipEventDisableTiming), "creating events")
 			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->assembled[b], hipEventDisableTiming), "creating events");
-		if (!failed && format == slab_format_rgba32f) exchange->send[b] = exchange->slab_radiance[b];
-		else if (!failed) failed = hip_failed(hipMalloc(&exchange->send[b], exchange->send_bytes), "allocating an encoded slab");
+		/* in place: what this rank sends is its own slot of the gathered slabs */
+		if (!failed) exchange->send[b] = (uint8_t*) exchange->gathered[b] + (size_t) exchange->rank * exchange->send_bytes;
+		if (!failed && format == slab_format_rgba32f) exchange->slab_radiance[b] = exchange->send[b];
+		else if (!failed) failed = hip_failed(hipMalloc(&exchange->slab_radiance[b], exchange->slab_pixel_count * 16u), "allocating a slab");
 		for (uint32_t i = 0; i != 5 && !failed; ++i)
 			failed = hip_failed(hipEventCreate((hipEvent_t*) &exchange->timing[b][i]), "creating timing events");
-		/* padding slots of the last tile row / column are never written by the kernels */
-		if (!failed) failed = hip_failed(hipMemsetAsync(exchange->slab_radiance[b], 0, exchange->slab_pixel_count * 16u, (hipStream_t) exchange->stream), "clearing a slab");
+		/* padding slots of the last tile row / column are never written by the kernels (the other ranks' slots arrive
+		   with their padding cleared the same way) */
+		if (!failed) failed = hip_failed(hipMemsetAsync(exchange->gathered[b], 0, exchange->send_bytes * rank_count, (hipStream_t) exchange->stream), "clearing the gathered slabs");
+		if (!failed && exchange->slab_radiance[b] != exchange->send[b]) failed = hip_failed(hipMemsetAsync(exchange->slab_radiance[b], 0, exchange->slab_pixel_count * 16u, (hipStream_t) exchange->stream), "clearing a slab");
 	}
 	/* the frames that write the slabs run on non-blocking streams, which nothing orders behind the clears */
 	if (!failed) failed = hip_failed(hipStreamSynchronize((hipStream_t) exchange->stream), "clearing the slabs");
@@ -385,10 +396,31 @@ int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, voi
 	if (exchange->gather(exchange->gather_context, exchange->rank, b, exchange->send[b], exchange->gathered[b], exchange->send_bytes, exchange_stream)) return 1;
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][3], exchange_stream);
 	void* target = out_frame ? out_frame : (exchange->format == slab_format_rgba32f ? app->render_targets.radiance : app->render_targets.encoded);
-	if (vkr_assemble_slabs_on_stream(app, exchange->gathered[b], target, (int) exchange->format, exchange_stream)) return 1;
+	/* on demand: the gathered slabs of this set are the frame until a reader asks for rows (assemble_exchanged_frame) */
+	exchange->last_set = b;
+	exchange->last_frame_assembled = 0;
+	if (!exchange->assemble_on_demand || out_frame) {
+		if (vkr_assemble_slabs_on_stream(app, exchange->gathered[b], target, (int) exchange->format, exchange_stream)) return 1;
+		exchange->last_frame_assembled = 1;
+	}
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][4], exchange_stream);
 	if (timed) exchange->timed[b] = 1;
 	exchange->last_frame = target;
+	return hip_failed(hipEventRecord((hipEvent_t) exchange->assembled[b], exchange_stream), "marking the assembled frame");
+}
+
+int assemble_exchanged_frame(application_t* app, slab_exchange_t* exchange, void* out_frame) {
+	if (!exchange->frame_counter) {
+		printf("assemble_exchanged_frame() needs a frame: call render_and_exchange_frame() first.\n");
+		return 1;
+	}
+	uint32_t b = exchange->last_set;
+	hipStream_t exchange_stream = (hipStream_t) exchange->stream;
+	void* target = out_frame ? out_frame : (exchange->format == slab_format_rgba32f ? app->render_targets.radiance : app->render_targets.encoded);
+	/* (the exchange stream is behind the gather of that frame; the set is not reused before `assembled` is recorded again) */
+	if (vkr_assemble_slabs_on_stream(app, exchange->gathered[b], target, (int) exchange->format, exchange_stream)) return 1;
+	exchange->last_frame = target;
+	if (!out_frame) exchange->last_frame_assembled = 1;
 	return hip_failed(hipEventRecord((hipEvent_t) exchange->assembled[b], exchange_stream), "marking the assembled frame");
 }
 
@@ -396,6 +428,8 @@ int finish_slab_exchange(application_t* app, slab_exchange_t* exchange) {
 	if (!exchange->frame_counter) return 0;
 	/* the exchange stream completes frames in order: the most recent set is the last one */
 	uint32_t last = (exchange->next_set + exchange->set_count - 1) % exchange->set_count;
+	/* on demand: this is the reader - the most recent frame is un-tiled into the render target now, once */
+	if (exchange->assemble_on_demand && !exchange->last_frame_assembled && assemble_exchanged_frame(app, exchange, NULL)) return 1;
 	return finish_frames(app)
 		|| hip_failed(hipStreamWaitEvent((hipStream_t) app->device.stream, (hipEvent_t) exchange->assembled[last], 0), "waiting for the assembled frame");
 }

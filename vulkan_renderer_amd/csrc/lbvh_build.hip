@@ -613,7 +613,8 @@ __global__ void __launch_bounds__(256) k_sah_assign(build_params p, uint32_t* tr
 // return what they returned (the same triangles are tested, some by more than one leaf); the tree is what changes.
 constexpr uint32_t kMostFragments = 16;
 
-__device__ __forceinline__ uint32_t fragments_wanted(const f3 (&v)[3], f3 lo, f3 hi, float least_extent, int& out_axis) {
+// `most`: the cap per triangle (kMostFragments, or less for a mesh that would otherwise grow more than fourfold)
+__device__ __forceinline__ uint32_t fragments_wanted(const f3 (&v)[3], f3 lo, f3 hi, float least_extent, uint32_t most, int& out_axis) {
 	f3 e = hi - lo;
 	out_axis = (e.x >= e.y && e.x >= e.z) ? 0 : (e.y >= e.z ? 1 : 2);
 	float longest = out_axis == 0 ? e.x : (out_axis == 1 ? e.y : e.z);
@@ -624,16 +625,16 @@ __device__ __forceinline__ uint32_t fragments_wanted(const f3 (&v)[3], f3 lo, f3
 	float ratio = box_half_area / fmaxf(twice_area, 1.0e-30f);
 	if (!(ratio > 4.0f)) return 1u;
 	float wanted = ceilf(0.5f * ratio);
-	return wanted >= (float) kMostFragments ? kMostFragments : (uint32_t) wanted;
+	return wanted >= (float) most ? most : (uint32_t) wanted;
 }
 
-__global__ void __launch_bounds__(256) k_count_fragments(build_params p, float least_extent, uint32_t* counts) {
+__global__ void __launch_bounds__(256) k_count_fragments(build_params p, float least_extent, uint32_t most, uint32_t* counts) {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= p.triangle_count) return;
 	f3 v[3], lo, hi;
 	triangle_bounds(p, t, v, lo, hi);
 	int axis;
-	counts[t] = fragments_wanted(v, lo, hi, least_extent, axis);
+	counts[t] = fragments_wanted(v, lo, hi, least_extent, most, axis);
 }
 
 // bounds of the part of the triangle with s0 <= x_axis <= s1 (the triangle is cut by the two planes)
@@ -669,13 +670,13 @@ __device__ __forceinline__ void slab_bounds(const f3 (&v)[3], int axis, float s0
 }
 
 // first[t]: exclusive prefix sum of the counts
-__global__ void __launch_bounds__(256) k_write_fragments(build_params p, float least_extent, const uint32_t* first, uint32_t* fragment_triangle, float* fragment_boxes) {
+__global__ void __launch_bounds__(256) k_write_fragments(build_params p, float least_extent, uint32_t most, const uint32_t* first, uint32_t* fragment_triangle, float* fragment_boxes) {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= p.triangle_count) return;
 	f3 v[3], lo, hi;
 	triangle_bounds(p, t, v, lo, hi);
 	int axis;
-	uint32_t count = fragments_wanted(v, lo, hi, least_extent, axis);
+	uint32_t count = fragments_wanted(v, lo, hi, least_extent, most, axis);
 	uint32_t base = first[t];
 	float a0 = axis == 0 ? lo.x : (axis == 1 ? lo.y : lo.z), a1 = axis == 0 ? hi.x : (axis == 1 ? hi.y : hi.z);
 	for (uint32_t j = 0; j != count; ++j) {
@@ -1060,30 +1061,35 @@ extern "C" int vkr_build_acceleration_structure(acceleration_structure_t* struct
 		uint32_t blocks = (n + 255) / 256, total = n;
 		bool ok = hipMalloc(&counts, sizeof(uint32_t) * 2 * (size_t) n) == hipSuccess;
 		uint32_t* first = counts ? counts + n : NULL;
-		if (ok) {
-			k_count_fragments<<<blocks, 256, 0, stream>>>(p, least_extent, counts);
-			ok = hipcub::DeviceScan::ExclusiveSum(NULL, scan_bytes, counts, first, (int) n, stream) == hipSuccess
-				&& hipMalloc(&scan_storage, scan_bytes ? scan_bytes : 1) == hipSuccess
-				&& hipcub::DeviceScan::ExclusiveSum(scan_storage, scan_bytes, counts, first, (int) n, stream) == hipSuccess;
-		}
-		if (ok) {
+		// A mesh of nothing but slivers would grow leaves, nodes and triangle_vertices sixteenfold.  Beyond four leaves per
+		// triangle on average the cap per triangle is halved until the mesh fits (16, 8, 4, 2: with two fragments a mesh at
+		// most doubles), so that the longest slivers - the ones for which splitting pays most - are still split (ADVICE round
+		// 5: until then such a mesh was built unsplit, a performance cliff exactly where splitting matters).
+		uint32_t most = kMostFragments;
+		while (ok) {
+			k_count_fragments<<<blocks, 256, 0, stream>>>(p, least_extent, most, counts);
+			if (!scan_storage)
+				ok = hipcub::DeviceScan::ExclusiveSum(NULL, scan_bytes, counts, first, (int) n, stream) == hipSuccess
+					&& hipMalloc(&scan_storage, scan_bytes ? scan_bytes : 1) == hipSuccess;
+			ok = ok && hipcub::DeviceScan::ExclusiveSum(scan_storage, scan_bytes, counts, first, (int) n, stream) == hipSuccess;
 			uint32_t last[2] = {0, 0};
-			ok = hipMemcpyAsync(&last[0], counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess
+			ok = ok && hipMemcpyAsync(&last[0], counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess
 				&& hipMemcpyAsync(&last[1], first + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess
 				&& hipStreamSynchronize(stream) == hipSuccess;
+			if (!ok) break;
 			total = last[0] + last[1];
+			if ((uint64_t) total <= 4ull * n || most <= 2u) break;
+			most /= 2u;
 		}
-		// a mesh of nothing but slivers would grow leaves, nodes and triangle_vertices sixteenfold: beyond four leaves per
-		// triangle on average the split is not worth its memory, and the tree is built over whole triangles
-		if (ok && total > n && (uint64_t) total > 4ull * n)
-			printf("Splitting long thin triangles would turn %u triangles into %u leaves; the BVH is built over whole triangles.\n", n, total);
+		if (ok && most != kMostFragments && trace)
+			printf("Long thin triangles are split into at most %u fragments (16 would turn %u triangles into more than %llu leaves).\n", most, n, 4ull * n);
 		if (ok && total > n && (uint64_t) total <= 4ull * n) {
 			// fragment_triangle[total], then fragment_boxes[6 total]
 			ok = hipMalloc(&fragment_memory, sizeof(uint32_t) * (size_t) total + sizeof(float) * 6 * (size_t) total + 16) == hipSuccess;
 			if (ok) {
 				uint32_t* fragment_triangle = (uint32_t*) fragment_memory;
 				float* fragment_boxes = (float*) (fragment_triangle + total);
-				k_write_fragments<<<blocks, 256, 0, stream>>>(p, least_extent, first, fragment_triangle, fragment_boxes);
+				k_write_fragments<<<blocks, 256, 0, stream>>>(p, least_extent, most, first, fragment_triangle, fragment_boxes);
 				ok = hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
 				if (ok) {
 					p.fragment_triangle = fragment_triangle;

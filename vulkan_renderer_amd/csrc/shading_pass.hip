@@ -187,6 +187,9 @@ struct frame_pipeline {
 	// frames; this is the opposite direction.)
 	hipEvent_t readers_done;
 	uint32_t readers_generation;
+	// bumped whenever an input that the frames read from device memory has been rewritten (visibility buffer, scene):
+	// part of the light shafts' tag
+	uint32_t inputs_generation;
 	uint32_t next;            // context of the next pipelined frame
 	uint32_t last;            // context of the most recent frame
 	uint32_t depth;           // frames in flight of the most recent pipelined frame
@@ -414,6 +417,8 @@ static int ensure_wavefront(wavefront_buffers* w, uint32_t thread_count, uint32_
 
 extern "C" void mark_inputs_changed(application_t* app) {
 	app->shading_pass.inputs_changed = 1;
+	// (no pipeline yet: no verdict of an earlier arrangement exists either)
+	if (app->shading_pass.wavefront) ++((frame_pipeline*) app->shading_pass.wavefront)->inputs_generation;
 }
 
 // The stream the next render_shading_pass() will run on if it is pipelined the way the last
@@ -556,9 +561,120 @@ static int upload_constants(application_t* app, hipStream_t stream) {
 	return hip_failed(hipStreamWaitEvent(stream, ring->uploaded[ring->current], 0), "waiting for the constants");
 }
 
+// ---- asynchronous read-back through pinned staging (include/vkr_shading_pass.h begin_read_back) ----------------
+// One staging buffer, one event and the device address it was filled from per slot; all copies run on one stream of their
+// own (device-to-host copies into pinned memory are served by a DMA engine: they take no compute unit from the frames).
+constexpr uint32_t kReadBackSlots = VKR_MAX_FRAMES_IN_FLIGHT + 1;
+struct read_back_state {
+	hipStream_t stream;
+	hipEvent_t source_ready;               // marks device->stream when a copy is queued
+	void* staging[kReadBackSlots];
+	size_t staging_size[kReadBackSlots];
+	hipEvent_t copied[kReadBackSlots];
+	const void* source[kReadBackSlots];    // device range [source, source + bytes) of the slot's most recent copy
+	size_t bytes[kReadBackSlots];
+	bool pending[kReadBackSlots];          // the copy may still be running: a writer of its source waits for `copied`
+};
+
+static void destroy_read_back(shading_pass_t* pass) {
+	read_back_state* rb = (read_back_state*) pass->readback;
+	if (!rb) return;
+	if (rb->stream) { (void) hipStreamSynchronize(rb->stream); (void) hipStreamDestroy(rb->stream); }
+	if (rb->source_ready) (void) hipEventDestroy(rb->source_ready);
+	for (uint32_t i = 0; i != kReadBackSlots; ++i) {
+		if (rb->copied[i]) (void) hipEventDestroy(rb->copied[i]);
+		vkr_host_free_pinned(rb->staging[i]);
+	}
+	free(rb);
+	pass->readback = NULL;
+}
+
+// Makes `stream` wait for every pending copy that reads from [target, target + bytes): called in front of the kernel
+// of a frame that writes its output (the resolve kernel with wavefront rays, the shading kernel otherwise)
+static void wait_for_read_backs_of(shading_pass_t* pass, const void* target, size_t bytes, hipStream_t stream) {
+	read_back_state* rb = (read_back_state*) pass->readback;
+	if (!rb) return;
+	for (uint32_t i = 0; i != kReadBackSlots; ++i) {
+		if (!rb->pending[i]) continue;
+		if (hipEventQuery(rb->copied[i]) == hipSuccess) { rb->pending[i] = false; continue; }
+		const uint8_t* a = (const uint8_t*) rb->source[i];
+		const uint8_t* b = (const uint8_t*) target;
+		if (a < b + bytes && b < a + rb->bytes[i]) (void) hipStreamWaitEvent(stream, rb->copied[i], 0);
+	}
+}
+
+extern "C" int begin_read_back(application_t* app, uint32_t slot, const void* device_source, uint64_t bytes) {
+	shading_pass_t* pass = &app->shading_pass;
+	if (slot >= kReadBackSlots) {
+		printf("begin_read_back(): slot %u does not exist (0 ... %u).\n", slot, kReadBackSlots - 1u);
+		return 1;
+	}
+	if (!device_source) {
+		device_source = app->render_targets.radiance;
+		bytes = sizeof(float) * 4 * (uint64_t) app->swapchain.extent.width * app->swapchain.extent.height;
+	}
+	if (!device_source || !bytes) {
+		printf("begin_read_back() needs a device buffer (or render targets) to read from.\n");
+		return 1;
+	}
+	read_back_state* rb = (read_back_state*) pass->readback;
+	if (!rb) {
+		rb = (read_back_state*) calloc(1, sizeof(read_back_state));
+		pass->readback = rb;
+		if (!rb || hip_failed(hipStreamCreateWithFlags(&rb->stream, hipStreamNonBlocking), "creating the read-back stream")
+			|| hip_failed(hipEventCreateWithFlags(&rb->source_ready, kSyncEventFlags), "creating read-back events"))
+		{
+			destroy_read_back(pass);
+			return 1;
+		}
+	}
+	// (the host waits for this one: no device-scope-only release)
+	if (!rb->copied[slot] && hip_failed(hipEventCreateWithFlags(&rb->copied[slot], hipEventDisableTiming), "creating read-back events")) return 1;
+	// (the slot's previous copy has to have landed before its staging memory is reused or freed)
+	if (rb->pending[slot] && hip_failed(hipEventSynchronize(rb->copied[slot]), "waiting for the slot's previous read-back")) return 1;
+	rb->pending[slot] = false;
+	if (rb->staging_size[slot] < bytes) {
+		vkr_host_free_pinned(rb->staging[slot]);
+		rb->staging[slot] = NULL; rb->staging_size[slot] = 0;
+		if (vkr_host_alloc_pinned(&rb->staging[slot], (size_t) bytes)) {
+			printf("Failed to allocate %.1f MiB of pinned host memory for read-backs.\n", bytes / 1048576.0);
+			return 1;
+		}
+		rb->staging_size[slot] = (size_t) bytes;
+	}
+	// behind the frames in flight (the most recent one completes last: resolves are chained) ...
+	frame_pipeline* frames = (frame_pipeline*) pass->wavefront;
+	if (frames && pass->last_frame_in_flight) {
+		frame_context* last = &frames->contexts[frames->last];
+		if (last->recorded && hip_failed(hipStreamWaitEvent(rb->stream, last->done, 0), "ordering the read-back behind the frame")) return 1;
+	}
+	// ... and behind what device->stream has queued (frames without the pipeline, output encoding, an assembled frame)
+	if (hip_failed(hipEventRecord(rb->source_ready, (hipStream_t) app->device.stream), "marking the source")
+		|| hip_failed(hipStreamWaitEvent(rb->stream, rb->source_ready, 0), "ordering the read-back behind the device stream")
+		|| hip_failed(hipMemcpyAsync(rb->staging[slot], device_source, (size_t) bytes, hipMemcpyDeviceToHost, rb->stream), "queueing the read-back")
+		|| hip_failed(hipEventRecord(rb->copied[slot], rb->stream), "marking the read-back"))
+		return 1;
+	rb->source[slot] = device_source;
+	rb->bytes[slot] = (size_t) bytes;
+	rb->pending[slot] = true;
+	return 0;
+}
+
+extern "C" const void* end_read_back(application_t* app, uint32_t slot) {
+	read_back_state* rb = (read_back_state*) app->shading_pass.readback;
+	if (!rb || slot >= kReadBackSlots || !rb->staging[slot] || !rb->copied[slot]) {
+		printf("end_read_back(): slot %u has no read-back in flight.\n", slot);
+		return NULL;
+	}
+	if (hip_failed(hipEventSynchronize(rb->copied[slot]), "waiting for the read-back")) return NULL;
+	rb->pending[slot] = false;
+	return rb->staging[slot];
+}
+
 extern "C" void destroy_shading_pass(shading_pass_t* pass, const device_t* device) {
 	// frames in flight still read the buffers that are freed below
 	if (device && pass->wavefront) (void) wait_for_device(device);
+	destroy_read_back(pass);
 	destroy_constants_ring(pass, device);
 	if (pass->ray_counter) (void) hipFree(pass->ray_counter);
 	if (pass->pixel_materials) (void) hipFree(pass->pixel_materials);
@@ -944,6 +1060,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 	pass->wait_before_next_frame = NULL;
 	int status = 0;
 	frame_context* frame = NULL;
+	// bytes of the output this call writes (a slab in slab layout, else the frame): what pending read-backs are checked against
+	const size_t frame_output_bytes = sizeof(float4) * (p.slab_layout ? (size_t) grid_blocks * 256u : (size_t) p.width * p.height);
 	for (uint32_t band = 0; band != band_count && status == 0; ++band) {
 		p.first_block = band * blocks_per_band;
 		p.block_count = grid_blocks - p.first_block < blocks_per_band ? grid_blocks - p.first_block : blocks_per_band;
@@ -1010,10 +1128,31 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				work = (unsigned long long*) (frame->buffers.shaft_clear + (((size_t) shaft_groups * p.light_count + 1u) & ~(size_t) 1u));
 				(void) hipMemsetAsync(work, 0, 3 * sizeof(unsigned long long), stream);
 			}
+			// The tag of the launch: its geometry AND what its verdicts were derived from - the tree (address, sizes,
+			// build time: a scene loaded into the same allocation differs in one of them), the contents of the visibility buffer
+			// (a generation counter, bumped by render_visibility_pass / upload_visibility / mark_inputs_changed), the camera and the
+			// bytes of the light array in the constants.  When any of them changes no pair rests on a verdict of the old
+			// arrangement: ray counts and shaft statistics are then a function of the frame and of how long it has stood still,
+			// not of what was rendered before.
 			uint64_t tag = 0xcbf29ce484222325ull;
+			uint32_t build_bits;
+			memcpy(&build_bits, &structure->build_milliseconds, sizeof(build_bits));
 			for (uint64_t word : {(uint64_t) p.first_block, (uint64_t) p.block_count, (uint64_t) p.width, (uint64_t) p.height, (uint64_t) p.tile_size, (uint64_t) p.rank, (uint64_t) p.rank_count,
-					(uint64_t) p.slab_layout, (uint64_t) p.light_count, (uint64_t) (uintptr_t) p.visibility, (uint64_t) lists})
+					(uint64_t) p.slab_layout, (uint64_t) p.light_count, (uint64_t) (uintptr_t) p.visibility, (uint64_t) lists,
+					(uint64_t) (uintptr_t) structure->wide_nodes, (uint64_t) structure->wide_node_count, (uint64_t) structure->node_count, (uint64_t) build_bits, (uint64_t) frames->inputs_generation})
 				tag = (tag ^ word) * 0x100000001b3ull;
+			{
+				const uint8_t* bytes = (const uint8_t*) pass->constants_host;
+				const size_t ranges[3][2] = {{offsetof(per_frame_constants_t, world_to_projection_space), offsetof(per_frame_constants_t, mis_visibility_estimate)},
+					{offsetof(per_frame_constants_t, mesh_dequantization_factor), offsetof(per_frame_constants_t, error_factor)},
+					{sizeof(per_frame_constants_t), pass->constants_size}};
+				for (const size_t* range : ranges)
+					for (size_t i = range[0]; i + 4 <= range[1]; i += 4) {
+						uint32_t word;
+						memcpy(&word, bytes + i, sizeof(word));
+						tag = (tag ^ word) * 0x100000001b3ull;
+					}
+			}
 			const bool same_launch = frame->buffers.shaft_tag == tag;
 			frame->buffers.shaft_tag = tag;
 			k_light_shafts<<<shaft_groups, 64, 0, stream>>>(p, (const uint4*) structure->wide_nodes, frame->buffers.shaft_clear, frame->buffers.shaft_rectangles, lists ? frame->buffers.shaft_lists : NULL, extent, work, same_launch ? frames->shaft_rest : 0u,
@@ -1026,6 +1165,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			pass->last_shaft_groups = shaft_groups;
 		}
 		else pass->last_shaft_groups = 0;
+		// (a frame without wavefront rays writes its output from the shading kernel)
+		if (!is_deferred(ray_mode)) wait_for_read_backs_of(pass, p.out_radiance, frame_output_bytes, stream);
 		// (the second event of a timed frame: the shading kernel itself begins here, behind the shaft kernel)
 		if (timed && band == 0) (void) hipEventRecord(ring[kTimingEvents * slot + 1], stream);
 		status = error_mode != kErrorNone
@@ -1070,6 +1211,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 					frame->readers_seen = frames->readers_generation;
 				}
 			}
+			wait_for_read_backs_of(pass, p.out_radiance, frame_output_bytes, stream);
 			resolve_shadow_terms_and_reset<<<p.block_count, 256, 0, stream>>>(p);
 			status = hipGetLastError() != hipSuccess;
 		}
@@ -1754,7 +1896,7 @@ __global__ void __launch_bounds__(256) k_primary_visibility(const uint8_t* const
 extern "C" int render_visibility_pass(application_t* app) {
 	// frames in flight read the visibility buffer that this pass overwrites
 	if (finish_frames(app)) return 1;
-	app->shading_pass.inputs_changed = 1;
+	mark_inputs_changed(app);
 	shading_pass_t* pass = &app->shading_pass;
 	const acceleration_structure_t* as = &app->scene.acceleration_structure;
 	if (!as->triangle_vertices || !pass->constants_device) {
@@ -1790,7 +1932,7 @@ extern "C" int read_back_visibility(application_t* app, uint32_t* host_primitive
 extern "C" int upload_visibility(application_t* app, const uint32_t* host_primitives) {
 	// a blocking copy outside the streams: nothing may still be reading the old buffer
 	if (wait_for_device(&app->device)) return 1;
-	app->shading_pass.inputs_changed = 1;
+	mark_inputs_changed(app);
 	size_t pixels = (size_t) app->swapchain.extent.width * app->swapchain.extent.height;
 	if (hip_failed(hipMemcpy(app->render_targets.visibility_buffer, host_primitives, sizeof(uint32_t) * pixels, hipMemcpyHostToDevice), "uploading the visibility buffer")) return 1;
 	return 0;

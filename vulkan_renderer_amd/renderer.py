@@ -391,6 +391,15 @@ class Renderer(HostScene):
             self.exchange = None
             raise RuntimeError("create_local_slab_exchange failed")
 
+    def assemble_on_demand(self, on=True):
+        """The frame stays tile-major - the gathered slabs - until a reader asks for it (finish_exchange(), assemble_exchanged());
+        include/vkr_slab_exchange.h slab_exchange_t.assemble_on_demand"""
+        self.exchange.assemble_on_demand = int(bool(on))
+
+    def assemble_exchanged(self, out_pointer=None):
+        if self.lib.assemble_exchanged_frame(C.byref(self.app), C.byref(self.exchange), out_pointer):
+            raise RuntimeError("assemble_exchanged_frame failed")
+
     def destroy_exchange(self):
         if self.exchange is not None:
             self.lib.destroy_slab_exchange(C.byref(self.exchange), C.byref(self.app))
@@ -420,6 +429,25 @@ class Renderer(HostScene):
         if self.lib.read_back_radiance(C.byref(self.app), out.ctypes.data):
             raise RuntimeError("read_back_radiance failed")
         return out
+
+    def begin_read_back(self, slot=0, pointer=None, nbytes=0):
+        """Queues the copy of a device buffer (default: the radiance target) into the slot's pinned staging memory behind
+        the most recent frame and returns at once (include/vkr_shading_pass.h begin_read_back)"""
+        if self.lib.begin_read_back(C.byref(self.app), slot, pointer, nbytes):
+            raise RuntimeError("begin_read_back failed")
+
+    def end_read_back(self, slot=0, shape=None, dtype=np.float32):
+        """Waits for the slot's copy; returns a numpy VIEW of the pinned staging memory (valid until the slot's next
+        begin_read_back), shaped like the radiance target unless `shape` says otherwise"""
+        address = self.lib.end_read_back(C.byref(self.app), slot)
+        if not address:
+            raise RuntimeError("end_read_back failed")
+        if shape is None:
+            e = self.app.swapchain.extent
+            shape = (e.height, e.width, 4)
+        count = int(np.prod(shape))
+        buffer = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(address)
+        return np.frombuffer(buffer, dtype=dtype, count=count).reshape(shape)
 
     def read_visibility(self):
         e = self.app.swapchain.extent
