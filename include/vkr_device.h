@@ -47,7 +47,9 @@ typedef struct device_s {
 	/*! Internal hipStream_t on which consecutive frames of a shading pass with
 		frames_in_flight >= 2 run in turn, so that the ray tracing of one frame overlaps the
 		shading of the next ones (the analogue of the reference's frame queue,
-		main.h:353-390).  Owned by the device. */
+		main.h:353-390).  Owned by the device.  Four exist from the start, the others are made when a pass
+		first asks for a deeper pipeline (every stream takes a share of the few hardware queues of the GPU,
+		GPU_MAX_HW_QUEUES; csrc/host/device.c). */
 	void* frame_streams[VKR_MAX_FRAMES_IN_FLIGHT];
 } device_t;
 

@@ -49,6 +49,7 @@ def time_frames(r, target, steps):
     t0 = time.perf_counter()
     for _ in range(steps):
         r.render(target)
+    time_frames.issue_ms = (time.perf_counter() - t0) / steps * 1e3
     r.finish_frames(); r.sync()
     return (time.perf_counter() - t0) / steps * 1e3
 
@@ -60,6 +61,8 @@ def time_exchanged_frames(r, steps):
     t0 = time.perf_counter()
     for _ in range(steps):
         r.render_and_exchange(None)
+    # (host time to queue a frame: a bound when the host cannot keep up with slabs of 0.1 ms)
+    time_exchanged_frames.issue_ms = (time.perf_counter() - t0) / steps * 1e3
     r.finish_exchange(); r.sync()
     return (time.perf_counter() - t0) / steps * 1e3
 

@@ -9,6 +9,31 @@ static int check(hipError_t error, const char* what) {
 	return 1;
 }
 
+/* Makes sure that the first `count` frame streams exist (and have run their first kernel).
+   Tuning knob VKR_FRAME_STREAM_PRIORITY=low: the frame streams get the lowest priority, so
+   that the small kernels which consume a frame on device->stream (output encoding, slab
+   assembly) get their waves before the next frame's shading kernel fills the chip (measured:
+   encode 50 -> 16 us, assemble 110 -> 10 us beside config 2's kernels).  Not the default:
+   the frame rate did not change at config 2 and fell by 7 % at config 3 with an exchange
+   per frame. */
+int vkr_ensure_frame_streams(device_t* device, uint32_t count) {
+	if (count > VKR_MAX_FRAMES_IN_FLIGHT) count = VKR_MAX_FRAMES_IN_FLIGHT;
+	int least_priority = 0, greatest_priority = 0;
+	const char* knob = getenv("VKR_FRAME_STREAM_PRIORITY");
+	if (knob && strcmp(knob, "low") == 0) (void) hipDeviceGetStreamPriorityRange(&least_priority, &greatest_priority);
+	for (uint32_t i = 0; i != count; ++i) {
+		if (device->frame_streams[i]) continue;
+		hipStream_t stream = NULL;
+		if (check(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least_priority), "creating a frame stream")) return 1;
+		device->frame_streams[i] = stream;
+		/* The first kernel a process launches on a stream pays for the stream's hardware queue and for
+		   loading the code object: several milliseconds that would otherwise be billed to whatever
+		   comes first.  An empty kernel moves them here.  VKR_NO_WARM_UP=1 leaves it out. */
+		if (!getenv("VKR_NO_WARM_UP") && (vkr_launch_empty_kernel(stream) || check(hipStreamSynchronize(stream), "warming a frame stream up"))) return 1;
+	}
+	return 0;
+}
+
 int create_hip_device(device_t* device, int32_t hip_device, void* existing_stream) {
 	memset(device, 0, sizeof(*device));
 	int count = 0;
@@ -30,22 +55,18 @@ int create_hip_device(device_t* device, int32_t hip_device, void* existing_strea
 	strncpy(device->architecture, properties.gcnArchName, sizeof(device->architecture) - 1);
 	if (strncmp(device->architecture, "gfx950", 6) != 0)
 		printf("Warning: the kernels are built for gfx950 but device %d is %s.\n", hip_device, device->architecture);
-	/* Tuning knob VKR_FRAME_STREAM_PRIORITY=low: the frame streams get the lowest priority, so
-	   that the small kernels which consume a frame on device->stream (output encoding, slab
-	   assembly) get their waves before the next frame's shading kernel fills the chip (measured:
-	   encode 50 -> 16 us, assemble 110 -> 10 us beside config 2's kernels).  Not the default:
-	   the frame rate did not change at config 2 and fell by 7 % at config 3 with an exchange
-	   per frame. */
-	int least_priority = 0, greatest_priority = 0;
-	const char* knob = getenv("VKR_FRAME_STREAM_PRIORITY");
-	if (knob && strcmp(knob, "low") == 0) (void) hipDeviceGetStreamPriorityRange(&least_priority, &greatest_priority);
-	for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i) {
-		hipStream_t stream = NULL;
-		if (check(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least_priority), "creating a frame stream")) {
-			destroy_hip_device(device);
-			return 1;
-		}
-		device->frame_streams[i] = stream;
+	/* Frame streams: four now, the others when a pass first asks for more frames in flight (vkr_ensure_frame_streams).
+	   The runtime deals streams onto GPU_MAX_HW_QUEUES hardware queues (8 in bench.py's environment, 4 by default), each
+	   served in order: streams nobody uses should not share the queues of the busy ones.  (Round 6 suspected that of the
+	   slab exchange's stream and measured eight against four streams: no difference, profiles/r10e/exchange_overhead.jsonl -
+	   the queues were not what the exchange loses its time to.)  VKR_FRAME_STREAMS overrides the four. */
+	const char* stream_knob = getenv("VKR_FRAME_STREAMS");
+	long initial_streams = stream_knob ? strtol(stream_knob, NULL, 10) : 4;
+	if (initial_streams < 0) initial_streams = 0;
+	if (initial_streams > VKR_MAX_FRAMES_IN_FLIGHT) initial_streams = VKR_MAX_FRAMES_IN_FLIGHT;
+	if (vkr_ensure_frame_streams(device, (uint32_t) initial_streams)) {
+		destroy_hip_device(device);
+		return 1;
 	}
 	/* tables the kernels read from device globals exist before anything can be launched on this device_t */
 	if (vkr_fill_device_tables(device->stream)) {
@@ -57,9 +78,7 @@ int create_hip_device(device_t* device, int32_t hip_device, void* existing_strea
 	   comes first (the BVH build of the first scene: 7.8 instead of 3.5 ms).  An empty kernel on
 	   every stream moves them here, to the creation of the device.  VKR_NO_WARM_UP=1 leaves it out. */
 	if (!getenv("VKR_NO_WARM_UP")) {
-		int failed = vkr_launch_empty_kernel(device->stream);
-		for (int i = 0; i != VKR_MAX_FRAMES_IN_FLIGHT; ++i) failed |= vkr_launch_empty_kernel(device->frame_streams[i]);
-		if (failed || wait_for_device(device)) {
+		if (vkr_launch_empty_kernel(device->stream) || wait_for_device(device)) {
 			printf("Launching a kernel on the new device failed.\n");
 			destroy_hip_device(device);
 			return 1;

@@ -217,6 +217,8 @@ void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
 		if (exchange->slab_radiance[b] && exchange->slab_radiance[b] != exchange->send[b]) (void) hipFree(exchange->slab_radiance[b]);
 		if (exchange->gathered[b]) (void) hipFree(exchange->gathered[b]);
 		if (exchange->rendered[b]) (void) hipEventDestroy((hipEvent_t) exchange->rendered[b]);
+		/* (the pass may still hold the event as the reader of this set's slab: vkr_note_target_reader) */
+		if (exchange->assembled[b] && app) vkr_forget_target_reader(app, exchange->assembled[b]);
 		if (exchange->assembled[b]) (void) hipEventDestroy((hipEvent_t) exchange->assembled[b]);
 		for (uint32_t i = 0; i != 5; ++i)
 			if (exchange->timing[b][i]) (void) hipEventDestroy((hipEvent_t) exchange->timing[b][i]);
@@ -248,8 +250,10 @@ static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app
 	int failed = hip_failed(hipStreamCreateWithFlags((hipStream_t*) &exchange->stream, hipStreamNonBlocking), "creating the exchange stream");
 	for (uint32_t b = 0; b != sets && !failed; ++b) {
 		failed = hip_failed(hipMalloc(&exchange->gathered[b], exchange->send_bytes * rank_count), "allocating the gathered slabs")
-			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->rendered[b], hipEventDisableTiming), "creating events")
-			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->assembled[b], hipEventDisableTiming), "creating events");
+			/* (device-scope release like every event of the pass: an event without the flag releases to system scope, i.e. the
+			   L2s are written back under the frames that are running, every time it is recorded) */
+			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->rendered[b], hipEventDisableTiming | hipEventReleaseToDevice), "creating events")
+			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->assembled[b], hipEventDisableTiming | hipEventReleaseToDevice), "creating events");
 		/* in place: what this rank sends is its own slot of the gathered slabs */
 		if (!failed) exchange->send[b] = (uint8_t*) exchange->gathered[b] + (size_t) exchange->rank * exchange->send_bytes;
 		if (!failed && format == slab_format_rgba32f) exchange->slab_radiance[b] = exchange->send[b];
@@ -322,7 +326,7 @@ int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, lo
 		}
 	}
 	for (uint32_t b = 0; b != VKR_MAX_FRAMES_IN_FLIGHT && !failed; ++b)
-		if (!group->copied[rank][b]) failed = hip_failed(hipEventCreateWithFlags(&group->copied[rank][b], hipEventDisableTiming), "creating events");
+		if (!group->copied[rank][b]) failed = hip_failed(hipEventCreateWithFlags(&group->copied[rank][b], hipEventDisableTiming | hipEventReleaseToDevice), "creating events");
 	if (!failed) {
 		group->exchanges[rank] = exchange;
 		group->frames[rank] = 0;
@@ -370,8 +374,10 @@ int render_and_exchange_frame(application_t* app, slab_exchange_t* exchange, voi
 	/* The set's previous frame must have left the buffers before this frame writes them.  Which stream
 	   the frame takes - device->stream or one of the frame streams - is the pass's decision (it depends
 	   on the ray mode, the scene, the pipeline depth, and differs for the first frame of a fresh pass), so
-	   the pass itself waits for the event, on the stream it picks, before its first kernel. */
-	if (reused) app->shading_pass.wait_before_next_frame = exchange->assembled[b];
+	   the pass itself waits for the event, on the stream it picks, before its first kernel.
+	   Round 6: not the whole frame waits but the kernel that writes what the collective of the set's previous frame reads -
+	   this rank's slot of gathered[b] (vkr_note_target_reader, shading_pass.hip). */
+	if (reused) vkr_note_target_reader(app, exchange->assembled[b], exchange->send[b], (size_t) exchange->send_bytes);
 	/* (an untimed frame leaves the set's timing events alone: they keep the last timed frame; the
 	   start mark goes to the stream the frame is expected on, which only the very first frame may miss) */
 	if (timed) (void) hipEventRecord((hipEvent_t) exchange->timing[b][0], (hipStream_t) get_next_frame_stream(app));

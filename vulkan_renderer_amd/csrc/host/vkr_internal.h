@@ -62,6 +62,12 @@ void vkr_destroy_acceleration_structure(acceleration_structure_t* structure, con
 /*! shading_pass.hip: scatters all-gathered slabs (format: slab_format_t of vkr_slab_exchange.h)
 	into a frame on the given hipStream_t */
 int vkr_assemble_slabs_on_stream(application_t* app, const void* gathered_slabs, void* out_frame, int format, void* stream);
+/* (shading_pass.hip) `event`, a hipEvent_t, marks the end of a reader of [target, target + bytes): the next frame that
+   writes that range waits for it in front of the kernel that writes */
+void vkr_note_target_reader(application_t* app, void* event, const void* target, size_t bytes);
+void vkr_forget_target_reader(application_t* app, void* event);
+/* (device.c) creates the frame streams 0 ... count - 1 of the device that do not exist yet */
+int vkr_ensure_frame_streams(device_t* device, uint32_t count);
 
 #ifdef __cplusplus
 }

@@ -574,7 +574,51 @@ struct read_back_state {
 	const void* source[kReadBackSlots];    // device range [source, source + bytes) of the slot's most recent copy
 	size_t bytes[kReadBackSlots];
 	bool pending[kReadBackSlots];          // the copy may still be running: a writer of its source waits for `copied`
+	// readers outside the pass (vkr_note_target_reader: the slab exchange's collectives): an event of the caller and the
+	// device range that is read until it completes
+	hipEvent_t reader_event[kReadBackSlots];
+	const void* reader_source[kReadBackSlots];
+	size_t reader_bytes[kReadBackSlots];
 };
+
+// ... and before the caller destroys such an event
+extern "C" void vkr_forget_target_reader(application_t* app, void* event) {
+	read_back_state* rb = (read_back_state*) app->shading_pass.readback;
+	if (!rb || !event) return;
+	for (uint32_t i = 0; i != kReadBackSlots; ++i)
+		if (rb->reader_event[i] == (hipEvent_t) event) rb->reader_event[i] = NULL;
+	if (app->shading_pass.wait_before_next_frame == event) app->shading_pass.wait_before_next_frame = NULL;
+}
+
+static read_back_state* ensure_read_back_state(shading_pass_t* pass) {
+	if (!pass->readback) pass->readback = calloc(1, sizeof(read_back_state));
+	return (read_back_state*) pass->readback;
+}
+
+// For host/slab_exchange.c: `event` (a hipEvent_t of the caller, recorded behind a reader of [target, target + bytes)) must
+// have completed before a later frame writes that range.  The frame that writes it waits on the device, in front of the
+// kernel that does the writing - the resolve kernel of a frame with wavefront rays, the shading kernel otherwise, the
+// encoding kernel for an encoded slab - and not in front of its first kernel, as shading_pass_t.wait_before_next_frame
+// makes it: shaft walks, shading and tracing of frame k + n overlap the collective of frame k (round 6: a rank's slab at
+// N = 8 took 0.220 instead of 0.176 ms through the exchange with a collective that did nothing,
+// profiles/r10c/exchange_overhead_before.jsonl).  One entry per range; a new event for a known range replaces the old one.
+extern "C" void vkr_note_target_reader(application_t* app, void* event, const void* target, size_t bytes) {
+	read_back_state* rb = ensure_read_back_state(&app->shading_pass);
+	if (!rb) return;
+	uint32_t slot = kReadBackSlots;
+	for (uint32_t i = 0; i != kReadBackSlots; ++i) {
+		if (rb->reader_event[i] && rb->reader_source[i] == target) { slot = i; break; }
+		if (!rb->reader_event[i] && slot == kReadBackSlots) slot = i;
+	}
+	if (slot == kReadBackSlots) {
+		// (more ranges than buffer sets can exist: fall back to the oldest rule - the whole next frame waits)
+		app->shading_pass.wait_before_next_frame = event;
+		return;
+	}
+	rb->reader_event[slot] = (hipEvent_t) event;
+	rb->reader_source[slot] = target;
+	rb->reader_bytes[slot] = bytes;
+}
 
 static void destroy_read_back(shading_pass_t* pass) {
 	read_back_state* rb = (read_back_state*) pass->readback;
@@ -594,6 +638,14 @@ static void destroy_read_back(shading_pass_t* pass) {
 static void wait_for_read_backs_of(shading_pass_t* pass, const void* target, size_t bytes, hipStream_t stream) {
 	read_back_state* rb = (read_back_state*) pass->readback;
 	if (!rb) return;
+	for (uint32_t i = 0; i != kReadBackSlots; ++i) {
+		if (!rb->reader_event[i]) continue;
+		const uint8_t* a = (const uint8_t*) rb->reader_source[i];
+		const uint8_t* b = (const uint8_t*) target;
+		if (!(a < b + bytes && b < a + rb->reader_bytes[i])) continue;
+		if (hipEventQuery(rb->reader_event[i]) == hipSuccess) { rb->reader_event[i] = NULL; continue; }
+		(void) hipStreamWaitEvent(stream, rb->reader_event[i], 0);
+	}
 	for (uint32_t i = 0; i != kReadBackSlots; ++i) {
 		if (!rb->pending[i]) continue;
 		if (hipEventQuery(rb->copied[i]) == hipSuccess) { rb->pending[i] = false; continue; }
@@ -617,17 +669,11 @@ extern "C" int begin_read_back(application_t* app, uint32_t slot, const void* de
 		printf("begin_read_back() needs a device buffer (or render targets) to read from.\n");
 		return 1;
 	}
-	read_back_state* rb = (read_back_state*) pass->readback;
-	if (!rb) {
-		rb = (read_back_state*) calloc(1, sizeof(read_back_state));
-		pass->readback = rb;
-		if (!rb || hip_failed(hipStreamCreateWithFlags(&rb->stream, hipStreamNonBlocking), "creating the read-back stream")
-			|| hip_failed(hipEventCreateWithFlags(&rb->source_ready, kSyncEventFlags), "creating read-back events"))
-		{
-			destroy_read_back(pass);
-			return 1;
-		}
-	}
+	read_back_state* rb = ensure_read_back_state(pass);
+	if (!rb) return 1;
+	if (!rb->stream && (hip_failed(hipStreamCreateWithFlags(&rb->stream, hipStreamNonBlocking), "creating the read-back stream")
+		|| hip_failed(hipEventCreateWithFlags(&rb->source_ready, kSyncEventFlags), "creating read-back events")))
+		return 1;
 	// (the host waits for this one: no device-scope-only release)
 	if (!rb->copied[slot] && hip_failed(hipEventCreateWithFlags(&rb->copied[slot], hipEventDisableTiming), "creating read-back events")) return 1;
 	// (the slot's previous copy has to have landed before its staging memory is reused or freed)
@@ -960,6 +1006,8 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		if (!frames) return 1;
 		// (a textured scene has one per-pixel material buffer: one frame at a time)
 		depth = pass->frames_in_flight < VKR_MAX_FRAMES_IN_FLIGHT ? pass->frames_in_flight : VKR_MAX_FRAMES_IN_FLIGHT;
+		// (the device creates four frame streams; a deeper pipeline gets the others now)
+		if (depth >= 2 && !device->frame_streams[depth - 1] && vkr_ensure_frame_streams(&app->device, depth)) return 1;
 		while (depth >= 2 && !device->frame_streams[depth - 1]) --depth;
 		if (depth < 1) depth = 1;
 		pipelined = depth >= 2 && !app->scene.materials.textured;
@@ -1224,6 +1272,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				status = 1;
 			}
 			else {
+				wait_for_read_backs_of(pass, out_rgb8, (size_t) pixels * 3u, stream);
 				k_encode_output_rgb8<<<(uint32_t) ((pixels / 4 + 255) / 256), 256, 0, stream>>>((const float4*) p.out_radiance, (uint32_t*) out_rgb8, pixels / 4, app->screenshot.frame_bits, 0);
 				status = hipGetLastError() != hipSuccess;
 			}
