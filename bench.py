@@ -83,6 +83,51 @@ def pmc_entry_for(table, config, mode, scene, width, height, world, csrc_hash):
     return pmc
 
 
+def live_traffic(job, config, scene, timeout=150):
+    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do
+    not fit one pass: MI355X_MICROARCH.md, PMC slots) around a short child run of this file on the same workload - one frame at a
+    time, one launch per frame -, counters averaged over the dispatches of shade_pixels.  FETCH_SIZE counts wide coalesced reads
+    at half their bytes on gfx950 (the guide's HBM section): doubled.  None if rocprofv3 is not usable here (the caller then falls
+    back to the committed passes of profiles/pmc_traffic.json and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    args = job.args
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or any(k.startswith(("ROCPROFILER_", "ROCP_TOOL")) for k in os.environ):
+        return None
+    out = tempfile.mkdtemp(prefix="vkr_bench_pmc_")
+    child = [sys.executable, os.path.abspath(__file__), "--config", str(config), "--scene", scene, "--mode", args.mode, "--bvh", args.bvh, "--ltc-resolution", str(args.ltc_resolution),
+             "--no-cpu-baseline", "--no-secondary", "--no-other-modes", "--no-extra", "--no-live-pmc", "--no-host-frames", "--frames-in-flight", "1", "--steps", "6", "--warmup", "2", "--prewarm-frames", "8",
+             "--details", os.path.join(out, "child_details.json")]
+    env = dict(os.environ, TMPDIR="/tmp", VKR_BENCH_DATASET_CACHE=job.dataset_cache or job.tmp.name, VKR_BAND_COUNT="1")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            directory = os.path.join(out, counter)
+            command = [rocprof, "--kernel-trace", "--kernel-include-regex", "shade_pixels", "--output-format", "csv", "--pmc", counter, "-d", directory, "-o", "pmc", "--"] + child
+            done = subprocess.run(command, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            values = []
+            for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if "shade_pixels" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        values.append(float(row["Counter_Value"]))
+            if done.returncode != 0 or not values:
+                return None
+            sums[counter] = (sum(values) / len(values), len(values))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    fetch_kib, write_kib = sums["FETCH_SIZE"][0], sums["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": int((2.0 * fetch_kib + write_kib) * 1024), "fetch_size_kib": round(fetch_kib, 1), "write_size_kib": round(write_kib, 1),
+            "dispatches": [sums["FETCH_SIZE"][1], sums["WRITE_SIZE"][1]],
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over %d / %d dispatches of the kernel (one frame at a time), 2 x FETCH_SIZE + WRITE_SIZE (the guide's correction for wide reads on gfx950)" % (sums["FETCH_SIZE"][1], sums["WRITE_SIZE"][1])}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -245,6 +290,7 @@ class Job:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.tmp = tempfile.TemporaryDirectory(prefix="vkr_bench_%d_" % self.rank)
         self.datasets = {}
+        self.dataset_cache = None
         self.dataset = self.dataset_of(args.scene)
         self.stream = torch.cuda.current_stream()
 
@@ -258,17 +304,18 @@ class Job:
             # VKR_BENCH_DATASET_CACHE=<directory>: the generated files are kept there and found again by later runs of one
             # profiling session (profiles/collect.sh starts bench.py dozens of times; the large scene takes 25 s to generate)
             cache = os.environ.get("VKR_BENCH_DATASET_CACHE")
-            directory = os.path.join(cache, "%s_R%d_rank%d" % (scene, self.args.ltc_resolution, self.rank)) if cache else os.path.join(self.tmp.name, scene)
+            self.dataset_cache = cache
+            # (the same layout in the run's own temporary directory: the child run of live_traffic() finds the files there)
+            directory = os.path.join(cache or self.tmp.name, "%s_R%d_rank%d" % (scene, self.args.ltc_resolution, self.rank))
             marker = os.path.join(directory, "dataset.json")
-            if cache and os.path.exists(marker):
+            if os.path.exists(marker):
                 self.datasets[scene] = json.load(open(marker))
             else:
                 if scene == "large":
                     self.datasets[scene] = synthetic.write_dataset(directory, seed=4321, ltc_resolution=self.args.ltc_resolution, fresnel_count=51, large={})
                 else:
                     self.datasets[scene] = synthetic.write_dataset(directory, grid=256, box_count=64, seed=1234, ltc_resolution=self.args.ltc_resolution, fresnel_count=51)
-                if cache:
-                    json.dump(self.datasets[scene], open(marker, "w"))
+                json.dump(self.datasets[scene], open(marker, "w"))
             self.datasets[scene]["generate_seconds"] = round(time.perf_counter() - t, 2)
         return self.datasets[scene]
 
@@ -508,7 +555,7 @@ def run_workload(job, config, role, scene=None):
     # ---- every frame to the host (PCIe-inclusive; never `value`): a ring of targets, each read back through pinned staging
     # on the pass's copy stream while the next frames render (begin_read_back / end_read_back, include/vkr_shading_pass.h)
     with_readback = None
-    if primary and not distributed:
+    if primary and not distributed and not args.no_host_frames:
         ring = [torch.empty((height, width, 4), dtype=torch.float32, device="cuda") for _ in range(frames_in_flight_requested + 1)]
         frame_bytes = width * height * 16
 
@@ -642,9 +689,14 @@ def run_workload(job, config, role, scene=None):
     # bound: what binds the dominant kernel - the issue of its VALU instructions (valu_issue below).  achieved /
     # peak / frac are the NOMINAL HBM figures SURVEY.md 8(d) prescribes for the metric (algorithmic bytes over the kernel's
     # duration against 8 TB/s): nominal_bound says so.
+    live = None
+    if primary and world == 1 and not distributed and not args.no_live_pmc and rank == 0:
+        r.sync()
+        live = live_traffic(job, config, scene)
     roofline = {"bound": "valu_issue", "nominal_bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                "traffic": pmc["hbm_bytes_per_launch"] if (pmc and not pmc["stale"]) else None,
-                "traffic_source": (("%s: rocprofv3 --pmc passes of this configuration and arithmetic mode (profiles/collect.sh), kernel sources %s" % (pmc.get("source", "profiles/pmc_traffic.json"), pmc.get("csrc_hash")))
+                "traffic": live["hbm_bytes_per_launch"] if live else (pmc["hbm_bytes_per_launch"] if (pmc and not pmc["stale"]) else None),
+                "traffic_live": live,
+                "traffic_source": live["source"] if live else (("%s: rocprofv3 --pmc passes of this configuration and arithmetic mode (profiles/collect.sh), kernel sources %s" % (pmc.get("source", "profiles/pmc_traffic.json"), pmc.get("csrc_hash")))
                                    if not pmc["stale"] else "profiles/pmc_traffic.json has an entry, but for other kernel sources (%s, now %s): not attached" % (pmc.get("csrc_hash"), kernel_source_hash())) if pmc else None,
                 "kernel": "shade_pixels<%s, V=%d, rays=%d, %s>" % (settings["sampling_strategies"], r.app.shading_pass.max_polygon_vertex_count, int(r.app.shading_pass.use_ray_tracing), args.mode),
                 "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -836,8 +888,7 @@ def run_workload(job, config, role, scene=None):
     if primary and rank == 0 and world == 1 and not distributed and args.mode != "fast" and not args.no_other_modes and not args.inline_rays and not args.no_rays:
         r.close()
         result["other_modes"] = {}
-        # (the fast mode fails the tolerance rule - DESIGN.md section 2 - and is only measured on request)
-        for other in ("exact", "fast") if args.fast_mode else ("exact",):
+        for other in ("exact",) if args.no_fast_mode else ("exact", "fast"):
             if other != args.mode:
                 result["other_modes"][other] = mode_companion(job, config, other, gpu_image, width, height, sample_count, max(20, min(steps, 200)), frames_in_flight_requested)
         return result
@@ -873,13 +924,28 @@ def mode_companion(job, config, mode, headline_image, width, height, sample_coun
     image = r.read_radiance()
     r.close()
     stats = classify_outliers(image, headline_image)
+    if stats["pixels_over_threshold"] != stats["guard_pixels"]:
+        # some outlier is not a NaN-guard pixel: the two modes' frames WITHOUT shadow rays tell a silhouette (a ray that passes
+        # a triangle edge on the other side: the frames agree at that pixel once no ray is traced) from anything else
+        without = {}
+        for m in (mode, args.mode):
+            q = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=m, frames_in_flight=1)
+            renderer.setup_config(q, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh, trace_shadow_rays=False)
+            q.create_targets()
+            q.create_pass()
+            q.render_visibility()
+            q.render()
+            without[m] = q.read_radiance()
+            q.close()
+        stats = classify_outliers(image, headline_image, without[mode], without[args.mode])
     stats.pop("other_coordinates", None)
-    # the rule of DESIGN.md section 2 as far as one frame can decide it: every outlier must be a NaN-guard pixel
-    # (silhouettes need the frames without rays: tests/test_gpu_full_size.py) and the rest within 1e-4 RMSE
-    within = bool(stats["rmse_without_outliers"] <= 1e-4 and stats["pixels_over_threshold"] == stats["guard_pixels"] and not np.isnan(image).any())
+    # the rule of DESIGN.md section 2: every pixel that differs by more than 1e-2 is a NaN-guard pixel or a shadow-ray
+    # silhouette, the rest is within 1e-4 RMSE
+    within = bool(stats["rmse_without_outliers"] <= 1e-4 and stats["other_pixels"] == 0 and not np.isnan(image).any())
     return {"mode": mode, "within_tolerance": within, "value": round(width * height * sample_count / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "steps": steps,
+            "rmse": stats["rmse"], "rmse_without_discontinuity_pixels": stats["rmse_without_outliers"], "guard_pixels": stats["guard_pixels"], "silhouette_pixels": stats["silhouette_pixels"], "other_pixels": stats["other_pixels"],
             "vs_headline_frame": stats, "nan": int(np.isnan(image).sum()), "tolerance_rmse": 1e-4,
-            "note": "pixels over 1e-2 that are not guard pixels are shadow-ray silhouettes or unclassified (tests/test_gpu_full_size.py tells them apart with the frames without rays)"}
+            "note": "against the headline frame of this run (libm: the oracle's, bit for bit); pixels over 1e-2 are classified as NaN-guard pixels, shadow-ray silhouettes (the two modes agree there without shadow rays) or `other`, which fails the tolerance"}
 
 
 LINE_LIMIT = 4096  # the driver keeps 8 KB of stdout; round 4's 25 KB line could not be parsed from that
@@ -969,7 +1035,7 @@ def short_line(result, details_path=None):
     if extras:
         line["extra_workloads"] = {name: _pick(_short_workload(w), ("value", "ms_per_step", "parity", "cpu_only")) for name, w in extras.items()}
     if result.get("other_modes"):
-        line["other_modes"] = {m: _pick(v, ("value", "ms_per_step", "within_tolerance")) for m, v in result["other_modes"].items()}
+        line["other_modes"] = {m: _pick(v, ("value", "ms_per_step", "within_tolerance", "rmse", "rmse_without_discontinuity_pixels", "guard_pixels", "silhouette_pixels", "other_pixels")) for m, v in result["other_modes"].items()}
     line["details"] = details_path
     # a long workload string is the first thing to go if the line ever outgrows the driver's buffer
     for drop in ("other_modes", "extra_workloads", "stages"):
@@ -1071,8 +1137,8 @@ def main():
     ap.add_argument("--no-rays", action="store_true", help="disable shadow rays (TRACE_SHADOW_RAYS=0) for experiments")
     ap.add_argument("--inline-rays", action="store_true", help="trace shadow rays inside the shading kernel instead of the wavefront path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-modes", "--no-fast-mode", dest="no_other_modes", action="store_true", help="do not also measure the workload in the exact (polynomial arctangent) arithmetic mode (reported as \"other_modes\" next to the headline)")
-    ap.add_argument("--fast-mode", action="store_true", help="also measure the fast arithmetic mode; it is OUTSIDE the stated tolerance (within_tolerance false) and never part of a claim")
+    ap.add_argument("--no-other-modes", dest="no_other_modes", action="store_true", help="do not also measure the workload in the exact (polynomial arctangent) and fast arithmetic modes (reported as \"other_modes\" next to the headline)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="other_modes without the fast arithmetic mode (approximate reciprocals and roots, contraction, polynomial transcendentals)")
     ap.add_argument("--no-large-scene", action="store_true", help="do not also run config 3 on the large scene (2.6 M triangles) as an extra workload")
     ap.add_argument("--no-extra", action="store_true", help="do not also run the north_star target shape (1920x1080, 4 spp, 1 light) and BASELINE config 2 as short extra workloads")
     ap.add_argument("--traversal-stats", action="store_true", help="attach BVH traversal work counters to the secondary workload too (diagnostics)")
@@ -1083,6 +1149,8 @@ def main():
     ap.add_argument("--prewarm-frames", type=int, default=200, help="untimed frames before --warmup that bring clocks and the frame pipeline to their steady state")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="... but no longer than this (after the first eight)")
     ap.add_argument("--ltc-resolution", type=int, default=64, help="roughness / inclination resolution R of the generated LTC tables (SURVEY.md 8d: 64)")
+    ap.add_argument("--no-host-frames", action="store_true", help="do not also measure the rate with every frame read back to the host (with_readback)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc passes around a child run of the headline workload); the committed passes of profiles/pmc_traffic.json are used instead")
     ap.add_argument("--force-distributed", action="store_true", help="run the N > 1 code path (slab layout, exchange) even with one rank")
     ap.add_argument("--details", default=None, help="where the full record of the run goes (default gpurun_out/bench_details.json); the printed line is the short one")
     ap.add_argument("--dry-line", default=None, metavar="RECORD", help="no GPU work: print the short line for the full record of an earlier run (a details file, or a file whose last line is a record)")

@@ -23,7 +23,7 @@ for W in $WORKLOADS; do
 	CFG=${W%%_*}
 	SCENE=bench; [ "$W" != "$CFG" ] && SCENE=${W#*_}
 	P=$O/cfg${W}
-	QUIET="--scene $SCENE --mode $MODE --no-cpu-baseline --no-secondary --no-other-modes --no-extra"
+	QUIET="--scene $SCENE --mode $MODE --no-cpu-baseline --no-secondary --no-other-modes --no-extra --no-live-pmc --no-host-frames"
 	FULL=0; [ "$W" = "2" ] || [ "$W" = "3" ] && FULL=1
 	STEPS="--steps 6 --warmup 2 --prewarm-frames 8"; [ "$CFG" = "4" ] && STEPS="--steps 3 --warmup 1 --prewarm-frames 3"
 	# config 4: one launch per frame like the pass that bench.py times the kernel alone with (three bands by default), so

@@ -17,12 +17,12 @@ from vulkan_renderer_amd import renderer, synthetic
 pytestmark = pytest.mark.gpu
 
 
-def frames_with_and_without(monkeypatch, setup, frames_in_flight=1):
+def frames_with_and_without(monkeypatch, setup, frames_in_flight=1, arithmetic="libm"):
     """-> (frame with shafts, frame without, rays with, rays without, shaft statistics)"""
     out = {}
     for shafts in (1, 0):
         monkeypatch.setenv("VKR_LIGHT_SHAFTS", str(shafts))
-        r = renderer.Renderer(frames_in_flight=frames_in_flight)
+        r = renderer.Renderer(frames_in_flight=frames_in_flight, arithmetic=arithmetic)
         setup(r)
         r.create_targets()
         r.create_pass()
@@ -47,6 +47,18 @@ def test_benchmark_scene_same_frame_fewer_rays(big_dataset, monkeypatch, config,
     assert stats["clear_pairs"] > 0.15 * stats["pairs"], stats
     assert stats["clear_pairs"] + stats["list_pairs"] + sum(stats["not_clear"].values()) == stats["pairs"]
     assert 0 < rays_on < 0.8 * rays_off, (rays_on, rays_off)
+
+
+@pytest.mark.parametrize("config, width, height", [(3, 1280, 720), (4, 960, 540)])
+def test_the_fast_mode_keeps_its_frame_too(big_dataset, monkeypatch, config, width, height):
+    """Round 6: the fast arithmetic mode runs with shafts, occluder lists and pre-summed final terms like the other two.  Its
+    translation units contract a b + c into fused operations, so the two places where the shading kernel repeats what another
+    kernel does - the triangle test of an occluder list (the tracing kernel's), the sum of a clear light's terms (the resolve
+    kernel's) - are kept free of contraction; the frame is then the same with the test and without it, bit for bit."""
+    on, off, rays_on, rays_off, stats, stats_off = frames_with_and_without(
+        monkeypatch, lambda r: renderer.setup_config(r, config, big_dataset, width=width, height=height, acceleration_structure="sah_device"), frames_in_flight=2, arithmetic="fast")
+    assert np.array_equal(on.view(np.uint32), off.view(np.uint32)), int((on != off).any(axis=-1).sum())
+    assert stats["list_pairs"] > 0 and stats["clear_pairs"] > 0 and 0 < rays_on < 0.8 * rays_off, (stats, rays_on, rays_off)
 
 
 def test_large_scene_same_frame(monkeypatch, tmp_path):

@@ -51,6 +51,30 @@ struct bvh_view {
 	f3 grid_origin, grid_inverse_cell;
 };
 
+#if VKR_FAST_MATH
+// the triangle test below with every product rounded before it is added (see ray_triangle_edges)
+VKR_DEV float unfused_dot(f3 a, f3 b) { return (opaque(a.x * b.x) + opaque(a.y * b.y)) + opaque(a.z * b.z); }
+VKR_DEV f3 unfused_cross(f3 a, f3 b) { return mk3(opaque(a.y * b.z) - opaque(a.z * b.y), opaque(a.z * b.x) - opaque(a.x * b.z), opaque(a.x * b.y) - opaque(a.y * b.x)); }
+template <bool CULL_BACK>
+VKR_DEV bool ray_triangle_edges_unfused(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float t_max, float& dist) {
+	f3 p = unfused_cross(d, e2);
+	float det = unfused_dot(e1, p);
+	if (CULL_BACK ? !(det > 0.0f) : !(det != 0.0f)) return false;
+	float sign = (det < 0.0f) ? -1.0f : 1.0f;
+	float adet = det * sign;
+	f3 s = mk3(o.x - p0.x, o.y - p0.y, o.z - p0.z);
+	float U = unfused_dot(s, p) * sign;
+	if (!(U >= 0.0f && U <= adet)) return false;
+	f3 q = unfused_cross(s, e1);
+	float V = unfused_dot(d, q) * sign;
+	if (!(V >= 0.0f && opaque(U) + V <= adet)) return false;
+	float T = unfused_dot(e2, q) * sign;
+	if (!(T >= opaque(t_min * adet) && T <= opaque(t_max * adet))) return false;
+	if (CULL_BACK) dist = T * __builtin_amdgcn_rcpf(adet);
+	return true;
+}
+#endif
+
 // Moeller-Trumbore without the division, fp32, same operation order as
 // oracle/oracle_bvh.c ray_triangle: with det = e1 . (d x e2) the barycentrics u, v and
 // the distance t are compared in their det-scaled form (U = u det, V = v det, T = t det)
@@ -58,8 +82,14 @@ struct bvh_view {
 // (then triangles whose normal (v1-v0)x(v2-v0) points along the ray are rejected).
 // `dist` (only needed by the closest-hit query) is T / det.
 // (the test proper, on a vertex and the two edges that leave it - what an occluder list of light_shafts.h stores)
+// (never contracted, whatever the translation unit's flags say: the shading kernels decide the rays of an occluder list with
+// this test, and their verdict must be the tracing kernel's in every arithmetic mode - the products are made opaque, because
+// -ffp-contract=fast fuses in the back end whatever a pragma says, like difference_of_products in polygon_sampling.h)
 template <bool CULL_BACK>
 VKR_DEV bool ray_triangle_edges(f3 p0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float t_max, float& dist) {
+#if VKR_FAST_MATH
+	return ray_triangle_edges_unfused<CULL_BACK>(p0, e1, e2, o, d, t_min, t_max, dist);
+#endif
 	f3 p = cross(d, e2);
 	float det = dot(e1, p);
 	if (CULL_BACK ? !(det > 0.0f) : !(det != 0.0f)) return false;

@@ -108,6 +108,9 @@ struct shade_params {
 	// front of every frame cleared the counter: one more (tiny) kernel in the chain of every frame, which the GPU schedules
 	// when it finds room - 4 to 800 us under load (profiles/r07b).
 	uint32_t first_launch_of_frame;
+	// the table of the second prepared polygon of every shading workgroup, for the kernel variants that keep only one in
+	// LDS (psa_table_in_memory(V)): [workgroup of the launch][slot][thread] float2; NULL for all other variants
+	float2* psa_table_memory;
 	// error display (ERROR_INDEX of the reference; the two constants of error_to_color
 	// that the GLSL compiler folds: 10^4.99 and 20 / (5 log2 10), computed on the host)
 	uint32_t error_index;
@@ -130,6 +133,15 @@ constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic 
 //   kRaysDeferredBlocks  the same with queue slots reserved a block at a time (push_ray)
 enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2, kRaysDeferredBlocks = 3 };
 constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == kRaysDeferredBlocks; }
+
+// Round 6: from V = 6 on only ONE of the two tables is in LDS; the specular polygon's goes to device memory, [workgroup][slot]
+// [thread] like the LDS table (shade_params::psa_table_memory; a wave writes and reads its own 7.5 KB, which stay in its XCD's
+// L2).  Why: the V = 7 kernel of BASELINE config 4 runs 16.93 / 18.50 / 20.51 / 23.15 ms with 9 / 8 / 7 / 6 waves per CU
+// (profiles/r10f/waves_per_cu.jsonl: LDS that is asked for and not used) - every wave more is worth 7 - 9 % -, the two tables
+// of V = 7 (15 360 B + 1 312 B of other LDS = 14 granules of 1 280 B) hold it at nine where its registers allow twelve, and one
+// table (8 granules) does not hold it at all.  V <= 5 fits twelve waves with both tables and keeps them.
+constexpr bool psa_table_in_memory(int v) { return v >= 6; }
+constexpr uint32_t psa_table_memory_bytes_per_workgroup(int v) { return (2u * (uint32_t) v + 1u) * 64u * 8u; }
 // codes of the per-thread term stream written in deferred mode
 // (kCodePendingHiddenNaN: the value of the blocked term is not stored because it can only be NaN - every
 // estimator but the plain optimal MIS heuristic computes it as 0 x something, i.e. +-0 or NaN, and a NaN
@@ -140,18 +152,15 @@ constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == k
 #endif
 constexpr uint32_t kShaftListMax = VKR_SHAFT_LIST;
 constexpr uint32_t kShaftListEntry = 12;  // floats of a list entry: p0, e1, e2, each padded to four
-// (not in the fast mode: its translation units contract a b + c into fused operations, the tracing kernel's do not, and
-// the list test must be the tracing kernel's test to the bit)
-#if VKR_FAST_MATH
-constexpr bool kUseShaftLists = false;
-#else
+// (In every arithmetic mode since round 6: the list test must be the tracing kernel's test to the bit, and the fast mode's
+// translation units contract a b + c into fused operations where the tracing kernel's do not - so the triangle test itself,
+// lbvh.h ray_triangle_edges, is compiled without contraction wherever it is compiled.)
 constexpr bool kUseShaftLists = kShaftListMax != 0u;
-#endif
-// The final terms of a light that needs no ray are added up here instead of by the resolve kernel.  Not in the fast mode:
-// its translation units contract (a b) + c into a fused operation, the resolve kernel's do not, so the sum formed here
-// could differ from the one formed there - and a frame would depend on whether the shaft test is on.
+// The final terms of a light that needs no ray are added up here instead of by the resolve kernel.  (In the fast mode the
+// term is made opaque before it is added: a product contracted into the sum would make the sum formed here differ from the one
+// the resolve kernel forms, and a frame would depend on whether the shaft test is on.)
 #ifndef VKR_SUM_FINAL_TERMS
-#define VKR_SUM_FINAL_TERMS (!VKR_FAST_MATH)
+#define VKR_SUM_FINAL_TERMS 1
 #endif
 enum { kCodeEnd = 0, kCodePending = 1, kCodeVisible = 2, kCodePendingWithHidden = 3, kCodeEndOfLight = 4, kCodeFinal = 5, kCodePendingHiddenNaN = 6 };
 // Byte index of code `cursor` of thread `tid`: four consecutive codes of a thread share one 32-bit
@@ -808,6 +817,8 @@ struct pixel_context {
 	// this thread's column of the LDS tables of the prepared polygons (strategies with two
 	// techniques per light: 2 x kPsaTableSlots(V) slots, [slot][thread]), else NULL
 	float2* psa_tables;
+	// ... and of the one table that lives in device memory when LDS has room for one only (psa_table_in_memory), else NULL
+	float2* psa_table_memory;
 	// the pixel's noise accessor (accumulate() settles its outstanding request before it stores), or NULL
 	noise_accessor* noise;
 };
@@ -977,6 +988,9 @@ VKR_DEV void accumulate(pixel_context& ctx, f3& result, bool candidate, f3 visib
 #if VKR_SUM_FINAL_TERMS
 		if (ctx.light_clear && (ctx.final_state & 2u)) {
 			if (is_final) {
+#if VKR_FAST_MATH
+				value = mk3(opaque(value.x), opaque(value.y), opaque(value.z));
+#endif
 				ctx.final_sum = ctx.final_sum + value;
 				ctx.final_state |= 1u;
 				return;
@@ -1382,7 +1396,9 @@ VKR_DEV f3 evaluate_light(pixel_context& ctx, const shading_data& sd, const ltc_
 #pragma unroll
 			for (int i = 0; i < V; ++i) ps.sector[i] = 0.0f;
 			float2* const tables_d = ctx.psa_tables;
-			float2* const tables_s = ctx.psa_tables + kPsaTableSlots(V) * kPsaTableStride;
+			// ... unless there is room for one table only (psa_table_in_memory(): V >= 6): then the specular polygon's table
+			// is this thread's column of a table in device memory
+			float2* const tables_s = psa_table_in_memory(V) ? ctx.psa_table_memory : ctx.psa_tables + kPsaTableSlots(V) * kPsaTableStride;
 #pragma unroll
 			for (int t = 0; t != 2; ++t) {
 				const m43& to_local = (t == 0) ? world_to_shading : world_to_cosine;
@@ -1604,7 +1620,7 @@ constexpr int shade_min_workgroups(int strategy, int technique, int v, int rays,
 }
 // bytes of dynamic LDS of a shading workgroup: the polygon tables
 constexpr uint32_t shade_lds_bytes(int strategy, int technique, int v, int error) {
-	return has_psa_tables(strategy, technique, error) ? 2u * (2u * (uint32_t) v + 1u) * kShadeThreads * 8u : 0u;
+	return has_psa_tables(strategy, technique, error) ? (psa_table_in_memory(v) ? 1u : 2u) * (2u * (uint32_t) v + 1u) * kShadeThreads * 8u : 0u;
 }
 template <int STRATEGY, int TECHNIQUE, int V, int RAYS, int ERROR = kErrorNone>
 __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, TECHNIQUE, V, RAYS, ERROR)) shade_pixels(const shade_params p) {
@@ -1631,7 +1647,8 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	// waves fit a CU, i.e. three on two of the four SIMDs)
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
-	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, 0u, nullptr, queue, mk3(0.0f, 0.0f, 0.0f), 2u, kTables ? psa_tables + threadIdx.x : nullptr, nullptr};
+	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, 0u, nullptr, queue, mk3(0.0f, 0.0f, 0.0f), 2u, kTables ? psa_tables + threadIdx.x : nullptr,
+		(kTables && psa_table_in_memory(V) && p.psa_table_memory) ? p.psa_table_memory + (size_t) b * (kPsaTableSlots(V) * kPsaTableStride) + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		lds_state_word* state = ray_block_state();

@@ -151,6 +151,10 @@ struct wavefront_buffers {
 	// ... and per pair kShaftListMax triangle slots: the occluder lists (VKR_SHAFT_LISTS)
 	float* shaft_lists;
 	size_t shaft_list_words;
+	// the second polygon table of every shading workgroup, for the kernel variants that keep one table in LDS only
+	// (shading_kernel.h psa_table_in_memory); allocated when such a variant first runs
+	float2* psa_table_memory;
+	size_t psa_table_bytes;
 };
 
 static void free_wavefront_buffers(wavefront_buffers* w) {
@@ -160,6 +164,7 @@ static void free_wavefront_buffers(wavefront_buffers* w) {
 	(void) hipFree(w->shaft_clear);
 	(void) hipFree(w->shaft_rectangles);
 	(void) hipFree(w->shaft_lists);
+	(void) hipFree(w->psa_table_memory);
 	memset(w, 0, sizeof(*w));
 }
 
@@ -190,6 +195,9 @@ struct frame_pipeline {
 	// bumped whenever an input that the frames read from device memory has been rewritten (visibility buffer, scene):
 	// part of the light shafts' tag
 	uint32_t inputs_generation;
+	// the polygon tables in device memory (wavefront_buffers::psa_table_memory) of frames WITHOUT wavefront rays, which
+	// run on device->stream one at a time and own no context
+	wavefront_buffers device_stream_buffers;
 	uint32_t next;            // context of the next pipelined frame
 	uint32_t last;            // context of the most recent frame
 	uint32_t depth;           // frames in flight of the most recent pipelined frame
@@ -231,6 +239,7 @@ static void destroy_wavefront(shading_pass_t* pass) {
 		if (c.shaded) (void) hipEventDestroy(c.shaded);
 		free_wavefront_buffers(&c.buffers);
 	}
+	free_wavefront_buffers(&frames->device_stream_buffers);
 	if (frames->inputs_ready) (void) hipEventDestroy(frames->inputs_ready);
 	if (frames->readers_done) (void) hipEventDestroy(frames->readers_done);
 	free(frames);
@@ -333,6 +342,19 @@ static int ensure_shaft_words(wavefront_buffers* w, size_t words, uint32_t light
 	return 0;
 }
 
+static int ensure_psa_table_memory(wavefront_buffers* w, size_t bytes) {
+	if (bytes <= w->psa_table_bytes) return 0;
+	// (frees while other frames may be in flight: hipFree waits for the device)
+	(void) hipFree(w->psa_table_memory);
+	w->psa_table_memory = NULL; w->psa_table_bytes = 0;
+	if (hipMalloc(&w->psa_table_memory, bytes) != hipSuccess) {
+		printf("Failed to allocate %.1f MiB for the polygon tables that do not fit into LDS.\n", bytes / 1048576.0);
+		return 1;
+	}
+	w->psa_table_bytes = bytes;
+	return 0;
+}
+
 static int ensure_spill(wavefront_buffers* w, uint32_t stack_need, uint32_t in_lds, uint32_t trace_threads) {
 	size_t entries = stack_need > in_lds ? (size_t) (stack_need - in_lds) * trace_threads : 0;
 	if (entries <= w->spill_entries) return 0;
@@ -356,12 +378,12 @@ static uint32_t queue_capacity_for(uint32_t thread_count, uint32_t max_terms) {
 
 // bytes that ensure_wavefront() allocates for a launch of thread_count threads
 // (with the light shafts' table: a verdict word per 8x8 patch and light and, with occluder lists, kShaftListMax entries each)
-static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count, bool hidden_terms, bool base_color) {
+static double wavefront_bytes(uint32_t thread_count, uint32_t max_terms, uint32_t light_count, bool hidden_terms, bool base_color, uint32_t table_bytes_per_thread = 0) {
 	double terms = (double) max_terms * thread_count;
 	double shaft_pairs = (double) (thread_count / 64u) * light_count;
 	return terms * (hidden_terms ? 24.0 : 12.0) + (double) ((max_terms + light_count + 2 + 3) & ~3u) * thread_count + (base_color ? 16.0 : 0.0) * thread_count
 		+ 16.0 * thread_count + (double) queue_capacity_for(thread_count, max_terms) * kRayQueueCount * 20.0
-		+ shaft_pairs * (4.0 + 4.0 * kShaftListMax * kShaftListEntry);
+		+ shaft_pairs * (4.0 + 4.0 * kShaftListMax * kShaftListEntry) + (double) table_bytes_per_thread * thread_count;
 }
 
 // `stream`: the stream the frame that uses these buffers is about to run on.  The counters are cleared
@@ -977,6 +999,13 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		if (!pass->ray_counter && hip_failed(hipMalloc(&pass->ray_counter, 16 * sizeof(unsigned long long)), "allocating the ray counters")) return 1;
 		p.ray_counter = (unsigned long long*) pass->ray_counter;
 	}
+	int strategy = (int) app->render_settings.sampling_strategies;
+	int technique = technique_index(&app->render_settings);
+	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping || technique == kTechniquePsaArvo;
+	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
+	// the kernel variants that keep one of their two polygon tables in device memory (shading_kernel.h psa_table_in_memory)
+	const bool table_in_memory = strategy >= kStrategySeparately && (technique == kTechniquePsa || technique == kTechniquePsaBiased) && error_mode == kErrorNone && psa_table_in_memory(capacity);
+	const uint32_t table_bytes_per_workgroup = table_in_memory ? psa_table_memory_bytes_per_workgroup(capacity) : 0u;
 	// Launches with wavefront rays may run n at a time: launch k on frame stream k mod n with
 	// its own buffers, so that the (latency-bound) tracing of one launch overlaps the
 	// (VALU-bound) shading of the next ones.  Everything else runs on device->stream, behind
@@ -1020,7 +1049,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		uint32_t wanted = pass->band_count ? pass->band_count : frames->band_count;
 		if (!wanted) {
 			wanted = 1;
-			while (depth * wavefront_bytes(((grid_blocks + wanted - 1) / wanted) * 256u, max_terms, p.light_count, hidden_terms, base_color) > budget
+			while (depth * wavefront_bytes(((grid_blocks + wanted - 1) / wanted) * 256u, max_terms, p.light_count, hidden_terms, base_color, table_bytes_per_workgroup / 64u) > budget
 				&& (grid_blocks + wanted) / (wanted + 1) >= kMinBandBlocks)
 				++wanted;
 		}
@@ -1059,7 +1088,11 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		p.ray_block = ray_mode == kRaysDeferredBlocks ? ray_block_size(max_terms) : 0u;
 		p.refill_threshold = frames->refill_threshold;
 	}
-	else if (finish_frames(app)) return 1;
+	else {
+		if (finish_frames(app)) return 1;
+		// (no wavefront buffers, but the table in device memory lives with them: context 0)
+		if (table_in_memory && !(frames = ensure_frames(pass))) return 1;
+	}
 	pass->last_frame_traced_rays = ray_mode != kRaysNone;
 	pass->last_frame_in_flight = pipelined ? depth : 0u;
 	pass->last_band_count = band_count;
@@ -1090,10 +1123,6 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		p.light_texture_descriptors = (const uint4*) app->light_textures.descriptors;
 		p.light_texels = (const float4*) app->light_textures.texels;
 	}
-	int strategy = (int) app->render_settings.sampling_strategies;
-	int technique = technique_index(&app->render_settings);
-	bool is_clipped = technique == kTechniquePsa || technique == kTechniquePsaBiased || technique == kTechniqueClippedSolidAngle || technique == kTechniqueHartBilinearClipping || technique == kTechniqueHartBiquadraticClipping || technique == kTechniquePsaArvo;
-	int capacity = (int) p.max_light_vertex_count + (is_clipped ? 1 : 0);
 	// every timing_stride-th frame is bracketed by events: start, end of the (last band's) shading
 	// kernel, end of the frame (an event record costs about 5 us of idle time on the stream, a tenth
 	// of a config-2 frame for the pair)
@@ -1114,7 +1143,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		p.first_block = band * blocks_per_band;
 		p.block_count = grid_blocks - p.first_block < blocks_per_band ? grid_blocks - p.first_block : blocks_per_band;
 		frame = NULL;
-		if (frames) {
+		if (frames && is_deferred(ray_mode)) {
 			uint32_t index = 0;
 			if (pipelined) {
 				index = frames->next;
@@ -1132,6 +1161,11 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			p.ray_directions = w->ray_directions; p.ray_records = w->ray_records; p.ray_origins = w->ray_origins; p.ray_queue_size = w->ray_queue_size;
 			p.thread_count = w->thread_count; p.max_terms = w->max_terms; p.max_codes = w->max_codes;
 			p.ray_queue_capacity = w->queue_capacity; p.ray_thread_bits = w->thread_bits;
+		}
+		if (table_in_memory) {
+			wavefront_buffers* owner = frame ? &frame->buffers : &frames->device_stream_buffers;
+			if (ensure_psa_table_memory(owner, (size_t) shade_grid_size(blocks_per_band) * table_bytes_per_workgroup)) return 1;
+			p.psa_table_memory = owner->psa_table_memory;
 		}
 		pass->last_frame_stream = stream;
 		// (a target that earlier work of the caller still reads: every stream that writes it waits)
@@ -1163,9 +1197,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 		{
 			const acceleration_structure_t* structure = &app->scene.acceleration_structure;
 			uint32_t shaft_groups = shade_grid_size(p.block_count);
-			// (the fast-mode shading kernels do not use the lists - kUseShaftLists, shading_kernel.h - and would trace the rays
-			// of a listed pair anyway: their walks end at the first triangle in the way)
-			const bool lists = frames->shaft_lists != 0u && kShaftListMax != 0u && pass->arithmetic_mode != arithmetic_mode_fast;
+			const bool lists = frames->shaft_lists != 0u && kShaftListMax != 0u;
 			if (ensure_shaft_words(&frame->buffers, (size_t) shaft_groups * p.light_count + 8, p.light_count, lists, stream)) return 1;
 			float extent = 0.0f;
 			for (int j = 0; j != 3; ++j) extent = fmaxf(extent, kGridMax / structure->grid_inverse_cell[j]);

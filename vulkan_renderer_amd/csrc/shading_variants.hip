@@ -38,6 +38,15 @@
 
 using namespace vkr;
 
+// VKR_EXPERIMENT_EXTRA_LDS=<bytes> (a measurement aid; frames are unchanged): every shading workgroup asks for that much more
+// LDS than it uses, i.e. fewer of them are resident per CU - how the kernel's speed depends on its resident waves, measured
+// downwards from the nine that fit at V = 7 (profiles/r10f)
+static uint32_t extra_lds() {
+	static const uint32_t bytes = [] { const char* text = getenv("VKR_EXPERIMENT_EXTRA_LDS"); return text ? (uint32_t) strtoul(text, NULL, 10) : 0u; }();
+	return bytes;
+}
+#define shade_lds_bytes(...) (shade_lds_bytes(__VA_ARGS__) + extra_lds())
+
 template <int TECHNIQUE, int V>
 static int launch_rays(int rays, const shade_params& p, dim3 grid, hipStream_t stream) {
 	if (rays == kRaysDeferred) shade_pixels<VKR_STRATEGY, TECHNIQUE, V, kRaysDeferred, VKR_MODE><<<dim3(shade_grid_size(grid.x)), kShadeThreads, shade_lds_bytes(VKR_STRATEGY, TECHNIQUE, V, VKR_MODE), stream>>>(p);
