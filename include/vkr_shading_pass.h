@@ -455,6 +455,10 @@ VKR_API int compare_device_arithmetic(const device_t* device, uint32_t operation
 	ones if none).  A slice of the search over all 2^46 pairs of significands that admitted the chain
 	(profiles/tools/division_chains.hip), kept in the test suite.  No reference counterpart (the reference
 	leaves division to the driver's compiler). */
+/*! Diagnostics (profiles/tools/predict_scaling.py): copies `bytes` bytes (a multiple of 16) from one device buffer to another
+	with `workgroups` workgroups of 256 threads on hipStream_t `stream` - a copy that occupies a few compute units for a while, as
+	the kernels of a collective do, instead of the whole GPU for a moment, as hipMemcpyAsync does. */
+VKR_API int copy_with_workgroups(void* destination, const void* source, uint64_t bytes, uint32_t workgroups, void* stream);
 VKR_API int compare_device_division(const device_t* device, uint32_t first_significand, uint32_t divisor_count, uint32_t stride, uint32_t dividend_exponent, uint32_t divisor_exponent, uint64_t out_mismatches_and_first[2]);
 
 /*! Writes sizeof() of every ABI struct (device_t, polygonal_light_t,

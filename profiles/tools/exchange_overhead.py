@@ -56,7 +56,8 @@ def main():
             out.setdefault("c_noop", []).append(round(time_exchanged_frames(r, args.steps), 4))
             out.setdefault("c_noop_issue", []).append(round(time_exchanged_frames.issue_ms, 4))
             r.destroy_exchange()
-            for name, gather in (("machinery", lambda *a: 0), ("copies", stand_in_collective(hip, peers.ptr.value, args.rank, args.ranks))):
+            for name, gather in (("machinery", lambda *a: 0), ("copies", stand_in_collective(hip, peers.ptr.value, args.rank, args.ranks, 0)),
+                                 ("copies16", stand_in_collective(hip, peers.ptr.value, args.rank, args.ranks, 16)), ("copies32", stand_in_collective(hip, peers.ptr.value, args.rank, args.ranks, 32))):
                 for on_demand in (True, False):
                     r.create_exchange_with_gather(gather, "rgba32f")
                     r.assemble_on_demand(on_demand)

@@ -43,7 +43,8 @@ XGMI_LINK_GBPS = 153.0
 
 
 def time_frames(r, target, steps):
-    for _ in range(max(3, steps // 4)):
+    # (at least two rounds of the frame contexts: a context allocates its buffers when it first renders)
+    for _ in range(max(9, steps // 4)):
         r.render(target)
     r.finish_frames(); r.sync()
     t0 = time.perf_counter()
@@ -55,7 +56,7 @@ def time_frames(r, target, steps):
 
 
 def time_exchanged_frames(r, steps):
-    for _ in range(max(3, steps // 4)):
+    for _ in range(max(9, steps // 4)):
         r.render_and_exchange(None)
     r.finish_exchange(); r.sync()
     t0 = time.perf_counter()
@@ -67,16 +68,27 @@ def time_exchanged_frames(r, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def stand_in_collective(hip, peers, rank, ranks):
+def stand_in_collective(hip, peers, rank, ranks, workgroups=16):
     """slab_gather_function_t: the N - 1 slabs of the peers land in their slots of `gathered` (two device-to-device copies
-    around the rank's own slot, which the frame was shaded into)"""
+    around the rank's own slot, which the frame was shaded into).  workgroups > 0: copied by that many workgroups
+    (copy_with_workgroups of the C-ABI) - a few compute units busy for a while, like the channels of a collective; 0: by
+    hipMemcpyAsync, whose blit kernel takes the whole GPU for a moment (what round 6 first measured: 0.03 - 0.05 ms per frame of
+    a rank's shading side at N = 8, profiles/r10k)."""
+    from vulkan_renderer_amd import capi
+    lib = capi.load()
+
+    def copy(destination, source, nbytes, stream):
+        if workgroups:
+            return lib.copy_with_workgroups(destination, source, nbytes, workgroups, stream)
+        return hip.hipMemcpyAsync(C.c_void_p(destination), C.c_void_p(source), C.c_size_t(nbytes), 3, C.c_void_p(stream))
+
     def gather(my_rank, buffer_set, send, gathered, send_bytes, stream):
         failed = 0
         if rank > 0:
-            failed |= hip.hipMemcpyAsync(C.c_void_p(gathered), C.c_void_p(peers), C.c_size_t(rank * send_bytes), 3, C.c_void_p(stream))
+            failed |= copy(gathered, peers, rank * send_bytes, stream)
         if rank + 1 < ranks:
             offset = (rank + 1) * send_bytes
-            failed |= hip.hipMemcpyAsync(C.c_void_p(gathered + offset), C.c_void_p(peers + offset), C.c_size_t((ranks - 1 - rank) * send_bytes), 3, C.c_void_p(stream))
+            failed |= copy(gathered + offset, peers + offset, (ranks - 1 - rank) * send_bytes, stream)
         return int(failed != 0)
     return gather
 
@@ -108,14 +120,14 @@ def main():
             r.create_targets(); r.create_pass(); r.render_visibility()
             whole_ms = time_frames(r, None, steps if config == 4 else 400)
             lines += ["## BASELINE config %s (%dx%d): whole frame on one GPU %.3f ms" % (config, width, height, whole_ms), "",
-                      "| ranks | tile | slowest rank ms: alone / exchange / scatter | balance (exchange) | collective ms: direct / rings / one ring | speed-up, shading side only (alone) | **speed-up with the exchange: direct / rings / one ring** | ... with a scatter per frame (rings) |", "|---|---|---|---|---|---|---|---|"]
+                      "| ranks | tile | slowest rank ms: alone / exchange / scatter | balance (exchange) | collective ms: direct / rings / one ring | speed-up, shading side only (alone) | **speed-up with the exchange: direct / rings / one ring** | ... with a scatter per frame (rings) | exchanging the encoded output (rgb8): slowest rank ms, speed-up (one ring) |", "|---|---|---|---|---|---|---|---|---|"]
             for ranks in args.ranks:
                 depth = args.frames_in_flight or renderer.frames_in_flight_for(ranks)
                 if depth != r.frames_in_flight:
                     r.frames_in_flight = depth
                     r.create_pass()
                 for tile in args.tiles:
-                    alone, exchanged, scattered = [], [], []
+                    alone, exchanged, scattered, encoded = [], [], [], []
                     slab_pixels = 0
                     rank_steps = max(4, steps if config == 4 else steps * 4)
                     for rank in range(ranks):
@@ -126,8 +138,8 @@ def main():
                         r.sync()
                         slab.free()
                         peers = DeviceBuffer(slab_pixels * 16 * ranks)
-                        for on_demand, out in ((True, exchanged), (False, scattered)):
-                            r.create_exchange_with_gather(stand_in_collective(hip, peers.ptr.value, rank, ranks), "rgba32f")
+                        for on_demand, slab_format, out in ((True, "rgba32f", exchanged), (False, "rgba32f", scattered), (True, "rgb8", encoded)):
+                            r.create_exchange_with_gather(stand_in_collective(hip, peers.ptr.value, rank, ranks), slab_format)
                             r.assemble_on_demand(on_demand)
                             out.append(time_exchanged_frames(r, rank_steps))
                             r.destroy_exchange()
@@ -136,17 +148,19 @@ def main():
                     collective = {"direct": slab_mb / XGMI_LINK_GBPS, "rings": (ranks - 1) * slab_mb / (0.5 * 7 * XGMI_LINK_GBPS), "one_ring": (ranks - 1) * slab_mb / XGMI_LINK_GBPS}
                     with_exchange = {k: whole_ms / max(max(exchanged), v) for k, v in collective.items()}
                     with_scatter = {k: whole_ms / max(max(scattered), v) for k, v in collective.items()}
+                    # the encoded output (packed RGB8, 3 of 16 bytes per pixel) as the exchanged format: --exchange rgb8 of bench.py
+                    with_rgb8 = {k: whole_ms / max(max(encoded), v * 3.0 / 16.0) for k, v in collective.items()}
                     entry = {"config": config, "ranks": ranks, "tile": tile, "whole_frame_ms": round(whole_ms, 4), "per_rank_ms": [round(v, 4) for v in alone],
-                             "per_rank_ms_exchange": [round(v, 4) for v in exchanged], "per_rank_ms_scatter": [round(v, 4) for v in scattered],
+                             "per_rank_ms_exchange": [round(v, 4) for v in exchanged], "per_rank_ms_scatter": [round(v, 4) for v in scattered], "per_rank_ms_exchange_rgb8": [round(v, 4) for v in encoded],
                              "balance": round(sum(exchanged) / (ranks * max(exchanged)), 4), "predicted_speedup_shading_only": round(whole_ms / max(alone), 3),
-                             "predicted_speedup": {k: round(v, 3) for k, v in with_exchange.items()}, "predicted_speedup_scatter_every_frame": {k: round(v, 3) for k, v in with_scatter.items()},
+                             "predicted_speedup": {k: round(v, 3) for k, v in with_exchange.items()}, "predicted_speedup_scatter_every_frame": {k: round(v, 3) for k, v in with_scatter.items()}, "predicted_speedup_rgb8": {k: round(v, 3) for k, v in with_rgb8.items()},
                              "collective_ms": {k: round(v, 4) for k, v in collective.items()},
                              "frames_in_flight": depth, "slab_mb": round(slab_mb, 2), "bands_per_frame": int(r.app.shading_pass.last_band_count)}
                     results.append(entry)
                     print(json.dumps(entry), flush=True)
-                    lines.append("| %d | %d | %.3f / %.3f / %.3f | %.3f | %.3f / %.3f / %.3f | %.2f | **%.2f / %.2f / %.2f** | %.2f |" % (
+                    lines.append("| %d | %d | %.3f / %.3f / %.3f | %.3f | %.3f / %.3f / %.3f | %.2f | **%.2f / %.2f / %.2f** | %.2f | %.3f, %.2f |" % (
                         ranks, tile, max(alone), max(exchanged), max(scattered), entry["balance"], collective["direct"], collective["rings"], collective["one_ring"],
-                        entry["predicted_speedup_shading_only"], with_exchange["direct"], with_exchange["rings"], with_exchange["one_ring"], with_scatter["rings"]))
+                        entry["predicted_speedup_shading_only"], with_exchange["direct"], with_exchange["rings"], with_exchange["one_ring"], with_scatter["rings"], max(encoded), with_rgb8["one_ring"]))
             lines.append("")
             r.close()
     open(args.out + ".md", "w").write("\n".join(lines) + "\n")

@@ -190,7 +190,7 @@ def run_workload(job, config, role, scene=None):
             for slot in range(min(count, len(ring))):
                 r.end_read_back(slot)
         host_frames(2 * len(ring))  # (the first use of a slot allocates its pinned memory)
-        frames_to_host = max(32, min(steps, 200))
+        frames_to_host = max(120, min(steps, 200))
         fence()
         t = time.perf_counter()
         host_frames(frames_to_host)

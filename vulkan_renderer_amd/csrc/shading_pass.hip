@@ -180,6 +180,9 @@ struct frame_context {
 	hipEvent_t shaded;
 	hipEvent_t done;  // recorded behind the last kernel of the frame
 	bool recorded;    // `done` has been recorded: the next frame's resolve is ordered behind it
+	// what the context's most recent launch wrote its output to: a launch only has to be ordered behind the one before it
+	// when they write the same buffer (frames of a slab exchange take turns on several slabs, round 6)
+	const void* target;
 	bool pending;     // device->stream has not been made to wait for `done` yet
 	uint32_t readers_seen;  // frame_pipeline::readers_generation this context's stream has waited for
 };
@@ -1284,7 +1287,11 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				// (whether device->stream has already been made to wait for that launch - finish_frames() -
 				// says nothing about this stream)
 				frame_context* previous = &frames->contexts[(frames->last + frames->depth - 1u) % frames->depth];
-				if (previous != frame && previous->recorded) (void) hipStreamWaitEvent(stream, previous->done, 0);
+				// (bands of one frame, and frames that share a target; VKR_ORDER_ALL_RESOLVES=1: always, as until round 5)
+				static const bool order_all = getenv("VKR_ORDER_ALL_RESOLVES") != NULL;
+				if (previous != frame && previous->recorded && (order_all || previous->target == (const void*) p.out_radiance || band != 0))
+					(void) hipStreamWaitEvent(stream, previous->done, 0);
+				frame->target = p.out_radiance;
 				// ... and behind whatever still reads the target on device->stream (output encoding)
 				if (frame->readers_seen != frames->readers_generation) {
 					(void) hipStreamWaitEvent(stream, frames->readers_done, 0);
@@ -1615,6 +1622,20 @@ extern "C" int compare_device_division(const device_t* device, uint32_t first_si
 	}
 	(void) hipFree(counters);
 	return failed;
+}
+
+__global__ void __launch_bounds__(256) k_copy_with_workgroups(uint4* destination, const uint4* source, uint64_t count) {
+	for (uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t) gridDim.x * 256u) destination[i] = source[i];
+}
+
+extern "C" int copy_with_workgroups(void* destination, const void* source, uint64_t bytes, uint32_t workgroups, void* stream) {
+	if (!destination || !source || bytes % 16 != 0 || workgroups == 0) {
+		printf("copy_with_workgroups() needs two device buffers, a multiple of 16 bytes and at least one workgroup.\n");
+		return 1;
+	}
+	if (bytes == 0) return 0;
+	k_copy_with_workgroups<<<workgroups, 256, 0, (hipStream_t) stream>>>((uint4*) destination, (const uint4*) source, bytes / 16);
+	return hip_failed(hipGetLastError(), "launching the copy");
 }
 
 extern "C" int evaluate_device_arithmetic(const device_t* device, uint32_t operation, const float* a, const float* b, float* out, uint32_t count) {
