@@ -133,6 +133,12 @@ def main():
             result["timing_matrix_cells"] = timing_matrix_cells(job)
         except Exception as error:  # (diagnostics for the details file: never a reason to lose the line)
             result["timing_matrix_cells"] = {"error": repr(error)}
+    if (job.world > 1 or args.force_distributed) and args.exchange == "rgba32f" and not args.no_extra:
+        # The same tiled frame with the ENCODED output as the exchanged format (packed RGB8 - the format the reference's pass
+        # writes, shading_pass.frag.glsl:871-892 - 3 instead of 16 bytes per pixel over the links), on the same clock: if the
+        # float exchange is bound by the links at this N, this line shows what the shading side allows.
+        encoded = run_workload(job, args.config, "extra", exchange_format="rgb8")
+        result["exchange_rgb8"] = {k: encoded[k] for k in ("value", "unit", "steps", "ms_per_step", "median_frame_period_ms", "scaling_parity", "stages") if k in encoded}
     if not args.no_secondary and args.config != 4 and not customised:
         second = run_workload(job, 4, "secondary")
         keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "shadow_rays_per_frame", "Mrays_per_s", "light_shafts", "stages", "scaling_parity", "setup", "roofline", "traversal")

@@ -458,6 +458,12 @@ VKR_API int compare_device_arithmetic(const device_t* device, uint32_t operation
 /*! Diagnostics (profiles/tools/predict_scaling.py): copies `bytes` bytes (a multiple of 16) from one device buffer to another
 	with `workgroups` workgroups of 256 threads on hipStream_t `stream` - a copy that occupies a few compute units for a while, as
 	the kernels of a collective do, instead of the whole GPU for a moment, as hipMemcpyAsync does. */
+/*! Diagnostics: the kernels that keep a polygon table in device memory find their region by the hardware slot the wave runs in
+	(csrc/shading_kernel.h hardware_wave_slot); this launches `workgroups` single-wave workgroups on two streams at once, each of
+	which claims its slot, works for a while and releases it.  out[0]: waves that found their slot claimed by a wave that was
+	still running (must be 0), out[1]: distinct slots that were used.  extra_lds_bytes: dynamic LDS per workgroup (varies how many
+	waves fit a CU). */
+VKR_API int check_hardware_wave_slots(const device_t* device, uint32_t workgroups, uint32_t extra_lds_bytes, uint64_t out_shared_and_used[2]);
 VKR_API int copy_with_workgroups(void* destination, const void* source, uint64_t bytes, uint32_t workgroups, void* stream);
 VKR_API int compare_device_division(const device_t* device, uint32_t first_significand, uint32_t divisor_count, uint32_t stride, uint32_t dividend_exponent, uint32_t divisor_exponent, uint64_t out_mismatches_and_first[2]);
 

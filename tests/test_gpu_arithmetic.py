@@ -135,3 +135,20 @@ def test_square_root_and_inverse_square_root_are_the_ieee_results_for_every_floa
         for special in (0x00000000, 0x80000000, 0x7F800000, 0x7FC00000, 0xBF800000, 0xFF800000):
             assert device.lib.compare_device_arithmetic(C.byref(device.app.device), mine, theirs, special, 1, out) == 0
             assert out[0] == 0, (mine, theirs, hex(special))
+
+
+@pytest.mark.parametrize("extra_lds", [0, 20480, 65536])
+def test_hardware_wave_slots_are_unique_among_resident_waves(extra_lds):
+    """The two-technique kernels keep one polygon table in device memory, in the region of the hardware slot the wave runs in
+    (XCD, shader engine, shader array, CU, SIMD, wave slot: csrc/shading_kernel.h hardware_wave_slot).  Two waves that are resident
+    at the same time must never compute the same slot - within a kernel, and across two kernels that run at once."""
+    import ctypes as C
+    r = renderer.Renderer()
+    out = (C.c_uint64 * 2)()
+    assert r.lib.check_hardware_wave_slots(C.byref(r.app.device), 200000, extra_lds, out) == 0
+    shared, used = int(out[0]), int(out[1])
+    r.close()
+    print(extra_lds, shared, used)
+    assert shared == 0, (shared, used)
+    # every SIMD of the chip took part: at least one slot per SIMD of 256 CUs, at most kWaveSlots
+    assert 1024 <= used <= (1 << 17), used

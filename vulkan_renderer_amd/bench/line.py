@@ -87,6 +87,10 @@ def short_line(result, details_path=None):
         line["north_star_target"] = _pick(target, ("shape", "target_Msamples_per_s", "value", "met"))
         if target.get("parity"):
             line["north_star_target"]["pixels_differing"] = _short_parity(target["parity"])["pixels_differing"]
+    if result.get("exchange_rgb8"):
+        line["exchange_rgb8"] = _pick(result["exchange_rgb8"], ("value", "ms_per_step"))
+        if result["exchange_rgb8"].get("scaling_parity"):
+            line["exchange_rgb8"]["pixels_differing"] = result["exchange_rgb8"]["scaling_parity"].get("pixels_differing_from_single_gpu_frame")
     if result.get("secondary"):
         line["secondary"] = _short_workload(result["secondary"])
     extras = result.get("extra_workloads") or {}

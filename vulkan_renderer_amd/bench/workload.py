@@ -24,7 +24,7 @@ def protocol_window(frames_in_flight, least=8):
     return ((max(1, int(least)) + n - 1) // n) * n
 
 
-def run_workload(job, config, role, scene=None):
+def run_workload(job, config, role, scene=None, exchange_format=None):
     """Sets one BASELINE configuration up, times it and returns the dict that describes the run.
     role: "primary" (the headline: CPU baseline, parity, other arithmetic modes), "extra" (a short run of another
     1920x1080 configuration with parity bits and roofline, attached to the headline line) or "secondary" (config 4)."""
@@ -36,7 +36,8 @@ def run_workload(job, config, role, scene=None):
     rank, world = job.rank, job.world
     settings = dict(synthetic.CONFIG_SETTINGS[config])
     strong = args.scaling == "strong"
-    exchange = args.exchange if (world > 1 or args.force_distributed) else "none"
+    # (exchange_format: another format than --exchange, for the companion run of main())
+    exchange = (exchange_format or args.exchange) if (world > 1 or args.force_distributed) else "none"
     distributed = world > 1 or args.force_distributed
     width = args.width or settings["width"]
     height = (args.height or settings["height"]) * (1 if strong else world)

@@ -234,6 +234,7 @@ SIGNATURES = {
     "read_back_radiance": (C.c_int, [P(Application), C.c_void_p]),
     "read_back_encoded": (C.c_int, [P(Application), C.c_void_p]),
     "read_back_visibility": (C.c_int, [P(Application), C.c_void_p]),
+    "check_hardware_wave_slots": (C.c_int, [P(Device), C.c_uint32, C.c_uint32, P(C.c_uint64)]),
     "copy_with_workgroups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "begin_read_back": (C.c_int, [P(Application), C.c_uint32, C.c_void_p, C.c_uint64]),
     "end_read_back": (C.c_void_p, [P(Application), C.c_uint32]),

@@ -111,6 +111,9 @@ struct shade_params {
 	// the table of the second prepared polygon of every shading workgroup, for the kernel variants that keep only one in
 	// LDS (psa_table_in_memory(V)): [workgroup of the launch][slot][thread] float2; NULL for all other variants
 	float2* psa_table_memory;
+	// 1: a wave's region of psa_table_memory is that of the hardware slot it runs in (hardware_wave_slot(), kWaveSlots regions),
+	// 0: that of its workgroup
+	uint32_t psa_table_by_wave_slot;
 	// error display (ERROR_INDEX of the reference; the two constants of error_to_color
 	// that the GLSL compiler folds: 10^4.99 and 20 / (5 log2 10), computed on the host)
 	uint32_t error_index;
@@ -134,14 +137,38 @@ constexpr uint32_t kRayChunk = 256;       // most rays a wave claims per atomic 
 enum { kRaysNone = 0, kRaysInline = 1, kRaysDeferred = 2, kRaysDeferredBlocks = 3 };
 constexpr bool is_deferred(int rays) { return rays == kRaysDeferred || rays == kRaysDeferredBlocks; }
 
-// Round 6: from V = 6 on only ONE of the two tables is in LDS; the specular polygon's goes to device memory, [workgroup][slot]
-// [thread] like the LDS table (shade_params::psa_table_memory; a wave writes and reads its own 7.5 KB, which stay in its XCD's
-// L2).  Why: the V = 7 kernel of BASELINE config 4 runs 16.93 / 18.50 / 20.51 / 23.15 ms with 9 / 8 / 7 / 6 waves per CU
-// (profiles/r10f/waves_per_cu.jsonl: LDS that is asked for and not used) - every wave more is worth 7 - 9 % -, the two tables
-// of V = 7 (15 360 B + 1 312 B of other LDS = 14 granules of 1 280 B) hold it at nine where its registers allow twelve, and one
-// table (8 granules) does not hold it at all.  V <= 5 fits twelve waves with both tables and keeps them.
-constexpr bool psa_table_in_memory(int v) { return v >= 6; }
+// Round 6: from V = 6 on only ONE of the two polygon tables of the two-technique kernels is in LDS; the specular polygon's is
+// in device memory, [region][slot][thread] like the LDS table (shade_params::psa_table_memory).  Why: these kernels live on
+// resident waves.  The V = 7 kernel of BASELINE config 4 runs 16.93 / 18.50 / 20.51 / 23.15 ms with 9 / 8 / 7 / 6 waves per CU
+// (profiles/r10f/waves_per_cu.jsonl: LDS that is asked for and not used) - every wave more is worth 7 - 9 % -, and its two
+// tables (15 360 B + 1 312 B of other LDS = 14 granules of 1 280 B) held it at nine where its registers allow twelve:
+// 16.9 -> 14.4 ms with one table.  V <= 5 fits twelve waves with both tables in LDS and keeps them there.
+// Tried and not adopted (profiles/r10m, r10o): FOUR waves per SIMD for these kernels (128 VGPRs, 35 - 45 dwords per lane in
+// scratch memory, one table in memory for every V): config 3 1.153 -> 1.119 ms per frame, the target shape 0.431 -> 0.409,
+// config 4 16.45 -> 15.90 - but the spills go through the L2 to the fabric: FETCH_SIZE + WRITE_SIZE of a config-3 launch
+// 0.20 -> 1.33 GB, of a config-4 frame 2 -> 25 GB.  3 % of time for six to twelve times the memory traffic: no.  (Five waves
+// lose outright, 1.255 ms; the one-technique kernels lose at four, config 2 0.139 -> 0.155.)
+#ifndef VKR_PSA_MEMORY_FROM
+#define VKR_PSA_MEMORY_FROM 6
+#endif
+constexpr bool psa_table_in_memory(int v) { return v >= VKR_PSA_MEMORY_FROM; }
 constexpr uint32_t psa_table_memory_bytes_per_workgroup(int v) { return (2u * (uint32_t) v + 1u) * 64u * 8u; }
+// Where a wave's table lies in that memory: in the region of its workgroup (the default), or - shade_params::
+// psa_table_by_wave_slot, VKR_PSA_TABLE_INDEX=slot - in the region of the HARDWARE SLOT the wave occupies, (XCD, shader engine,
+// shader array, CU, SIMD, wave slot) from HW_REG_XCC_ID and HW_REG_HW_ID, unique among the waves that are resident at any time
+// whatever kernel, stream or frame they belong to (check_hardware_wave_slots() of the C-ABI tests that on the device): one
+// buffer of kWaveSlots regions for the whole pass, written again and again by the waves that follow each other in a slot.  The
+// idea was that such a region stays in its XCD's L2; the counters say the table stores reach the fabric either way (config 4:
+// WRITE_SIZE 5.2 GB per frame with both schemes, profiles/r10o), so it is an option, not the default.
+constexpr uint32_t kWaveSlots = 1u << 17;
+VKR_DEV uint32_t hardware_wave_slot() {
+	// s_getreg_b32 simm16 = (size - 1) << 11 | offset << 6 | register: HW_REG_HW_ID = 4 (wave_id [3:0], simd_id [5:4], pipe_id [7:6],
+	// cu_id [11:8], sh_id [12], se_id [15:13]), HW_REG_XCC_ID = 20 (xcc_id [3:0])
+	uint32_t hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+	uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+	// (the pipe that dispatched the wave is not part of where it runs)
+	return ((xcc & 7u) << 14) | (((hw >> 8) & 0xFFu) << 6) | (hw & 0x3Fu);
+}
 // codes of the per-thread term stream written in deferred mode
 // (kCodePendingHiddenNaN: the value of the blocked term is not stored because it can only be NaN - every
 // estimator but the plain optimal MIS heuristic computes it as 0 x something, i.e. +-0 or NaN, and a NaN
@@ -1614,9 +1641,13 @@ constexpr bool has_psa_tables(int strategy, int technique, int error) {
 	return strategy >= kStrategySeparately && (technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular;
 }
 // (Rays traced inside the kernel bring the traversal's registers with them: those variants would spill.)
+// (waves per SIMD asked of the register allocator; VKR_SHADE_TABLE_WAVES for the kernels with polygon tables: the experiment above)
+#ifndef VKR_SHADE_TABLE_WAVES
+#define VKR_SHADE_TABLE_WAVES 3
+#endif
 constexpr int shade_min_workgroups(int strategy, int technique, int v, int rays, int error) {
 	return ((technique == kTechniquePsa || technique == kTechniquePsaBiased) && error != kErrorDiffuse && error != kErrorSpecular
-		&& v <= (has_psa_tables(strategy, technique, error) ? 7 : 6) && rays != kRaysInline) ? 3 : 1;
+		&& v <= (has_psa_tables(strategy, technique, error) ? 7 : 6) && rays != kRaysInline) ? (has_psa_tables(strategy, technique, error) ? VKR_SHADE_TABLE_WAVES : 3) : 1;
 }
 // bytes of dynamic LDS of a shading workgroup: the polygon tables
 constexpr uint32_t shade_lds_bytes(int strategy, int technique, int v, int error) {
@@ -1648,7 +1679,7 @@ __global__ void __launch_bounds__(kShadeThreads, shade_min_workgroups(STRATEGY, 
 	extern __shared__ float2 psa_tables[];
 	// (the wavefront buffers are indexed by the thread's number within this launch)
 	pixel_context ctx = {p, 0, local_block * 256u + thread, 0, 0, false, false, 0u, 0u, nullptr, queue, mk3(0.0f, 0.0f, 0.0f), 2u, kTables ? psa_tables + threadIdx.x : nullptr,
-		(kTables && psa_table_in_memory(V) && p.psa_table_memory) ? p.psa_table_memory + (size_t) b * (kPsaTableSlots(V) * kPsaTableStride) + threadIdx.x : nullptr, nullptr};
+		(kTables && psa_table_in_memory(V) && p.psa_table_memory) ? p.psa_table_memory + (size_t) (p.psa_table_by_wave_slot ? hardware_wave_slot() : b) * (kPsaTableSlots(V) * kPsaTableStride) + threadIdx.x : nullptr, nullptr};
 	if constexpr (RAYS == kRaysDeferredBlocks) {
 		// (the waves of a workgroup never touch each other's entry: no barrier)
 		lds_state_word* state = ray_block_state();

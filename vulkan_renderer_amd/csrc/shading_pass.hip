@@ -198,8 +198,8 @@ struct frame_pipeline {
 	// bumped whenever an input that the frames read from device memory has been rewritten (visibility buffer, scene):
 	// part of the light shafts' tag
 	uint32_t inputs_generation;
-	// the polygon tables in device memory (wavefront_buffers::psa_table_memory) of frames WITHOUT wavefront rays, which
-	// run on device->stream one at a time and own no context
+	// the polygon tables in device memory (wavefront_buffers::psa_table_memory) of the frames without wavefront rays, which
+	// own no context (and, with VKR_PSA_TABLE_INDEX=slot, of all launches of the pass: regions by hardware wave slot)
 	wavefront_buffers device_stream_buffers;
 	uint32_t next;            // context of the next pipelined frame
 	uint32_t last;            // context of the most recent frame
@@ -1166,9 +1166,15 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			p.ray_queue_capacity = w->queue_capacity; p.ray_thread_bits = w->thread_bits;
 		}
 		if (table_in_memory) {
-			wavefront_buffers* owner = frame ? &frame->buffers : &frames->device_stream_buffers;
-			if (ensure_psa_table_memory(owner, (size_t) shade_grid_size(blocks_per_band) * table_bytes_per_workgroup)) return 1;
+			// a region per workgroup of the launch, in the launch's own buffers (VKR_PSA_TABLE_INDEX=slot: one buffer for the
+			// whole pass, indexed by the hardware slot a wave runs in - shading_kernel.h hardware_wave_slot.  Measured, config 4:
+			// the same time and the same traffic, 16.40 / 16.42 ms and 8.8 / 9.0 GB per frame, profiles/r10o - the table stores
+			// reach the fabric either way -, so the scheme that assumes nothing about the hardware is the default)
+			static const bool by_block = !(getenv("VKR_PSA_TABLE_INDEX") != NULL && strcmp(getenv("VKR_PSA_TABLE_INDEX"), "slot") == 0);
+			wavefront_buffers* owner = (frame && by_block) ? &frame->buffers : &frames->device_stream_buffers;
+			if (ensure_psa_table_memory(owner, (size_t) (by_block ? shade_grid_size(blocks_per_band) : kWaveSlots) * table_bytes_per_workgroup)) return 1;
 			p.psa_table_memory = owner->psa_table_memory;
+			p.psa_table_by_wave_slot = by_block ? 0u : 1u;
 		}
 		pass->last_frame_stream = stream;
 		// (a target that earlier work of the caller still reads: every stream that writes it waits)
@@ -1621,6 +1627,48 @@ extern "C" int compare_device_division(const device_t* device, uint32_t first_si
 		failed = vkr_copy_to_host(out_mismatches_and_first, counters, 2 * sizeof(unsigned long long), device);
 	}
 	(void) hipFree(counters);
+	return failed;
+}
+
+// Every wave claims the word of its hardware slot, stays for a while and leaves it again; a wave that finds the word taken
+// shares its slot with a wave that is still there.  out[0]: such waves, out[1]: slots that were used
+__global__ void __launch_bounds__(64) k_check_hardware_wave_slots(uint32_t* owners, unsigned long long* out, uint32_t spin) {
+	uint32_t slot = hardware_wave_slot();
+	uint32_t old = 0;
+	if (threadIdx.x == 0) old = atomicExch(owners + slot, blockIdx.x + 1u);
+	old = __builtin_amdgcn_readfirstlane(old);
+	if (threadIdx.x == 0 && old != 0u) atomicAdd(out, 1ull);
+	if (threadIdx.x == 0 && old == 0u && atomicOr(owners + kWaveSlots + slot, 1u) == 0u) atomicAdd(out + 1, 1ull);
+	// (work that the compiler cannot remove and whose length differs between waves)
+	float x = (float) threadIdx.x;
+	for (uint32_t i = 0; i != spin * (1u + (blockIdx.x & 7u)); ++i) x = fmaf(x, 1.0000001f, 1.0e-7f);
+	if (x == 12345.678f) out[2] = 1ull;
+	if (threadIdx.x == 0) atomicExch(owners + slot, 0u);
+}
+
+extern "C" int check_hardware_wave_slots(const device_t* device, uint32_t workgroups, uint32_t extra_lds_bytes, uint64_t out_shared_and_used[2]) {
+	uint32_t* owners = NULL;
+	unsigned long long* out = NULL;
+	hipStream_t stream = (hipStream_t) device->stream;
+	int failed = hip_failed(hipMalloc(&owners, sizeof(uint32_t) * 2 * kWaveSlots), "allocating the slot owners") || hip_failed(hipMalloc(&out, 3 * sizeof(unsigned long long)), "allocating counters")
+		|| hip_failed(hipMemsetAsync(owners, 0, sizeof(uint32_t) * 2 * kWaveSlots, stream), "clearing") || hip_failed(hipMemsetAsync(out, 0, 3 * sizeof(unsigned long long), stream), "clearing");
+	if (!failed) {
+		// (two launches on two streams at once: slots are unique across kernels, not only within one)
+		hipStream_t other = (hipStream_t) device->frame_streams[0];
+		if (other) {
+			hipEvent_t ready;
+			failed = hip_failed(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "creating an event") || hip_failed(hipEventRecord(ready, stream), "recording") || hip_failed(hipStreamWaitEvent(other, ready, 0), "waiting");
+			if (!failed) k_check_hardware_wave_slots<<<workgroups, 64, extra_lds_bytes, other>>>(owners, out, 2000u);
+			(void) hipEventDestroy(ready);
+		}
+		k_check_hardware_wave_slots<<<workgroups, 64, extra_lds_bytes, stream>>>(owners, out, 3000u);
+		failed = failed || hip_failed(hipGetLastError(), "launching the slot check");
+		if (other) failed = failed || hip_failed(hipStreamSynchronize(other), "waiting for the slot check");
+	}
+	unsigned long long host[3] = {0, 0, 0};
+	failed = failed || hip_failed(hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, stream), "reading the counters") || hip_failed(hipStreamSynchronize(stream), "waiting for the slot check");
+	out_shared_and_used[0] = host[0]; out_shared_and_used[1] = host[1];
+	(void) hipFree(owners); (void) hipFree(out);
 	return failed;
 }
 
