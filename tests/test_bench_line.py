@@ -138,3 +138,21 @@ def test_counters_are_attached_to_the_workload_they_were_measured_on():
     assert bench.pmc_entry_for(table, 3, "libm", "bench", 1920, 1080, 8, now) is None
     assert bench.pmc_entry_for(table, 2, "libm", "large", 1920, 1080, 1, now) is None
     assert bench.pmc_entry_for({"config3_libm": dict(bench_scene, scene="large")}, 3, "libm", "bench", 1920, 1080, 1, now) is None
+
+
+def test_timing_windows_are_multiples_of_the_frames_in_flight():
+    """Frames in flight finish in bursts of the pipeline depth: the windows whose median bench.py reports must be
+    whole numbers of bursts, or the median is biased (rounds 4 - 5: 9 % above the wall clock with windows of 8 and a depth of 3)."""
+    bench = _bench()
+    for depth in range(1, 9):
+        for least in (1, 8, 12):
+            window = bench.protocol_window(depth, least)
+            assert window % depth == 0 and window >= least and window - depth < max(least, depth)
+    assert bench.protocol_window(3) == 9 and bench.protocol_window(4) == 8 and bench.protocol_window(1) == 8 and bench.protocol_window(6) == 12
+    # the burst model: ends of frames at multiples of the depth; windows of 9 see the true period, windows of 8 do not
+    import numpy as np
+    depth, period = 3, 1.0
+    ends = np.array([period * depth * ((k // depth) + 1) for k in range(600)])
+    for window, biased in ((8, True), (9, False), (12, False)):
+        spans = (ends[window::window] - ends[:-window:window]) / window
+        assert (abs(float(np.median(spans)) - period) > 0.05) == biased, (window, float(np.median(spans)))

@@ -80,3 +80,22 @@ def test_primary_visibility_matches_oracle(dataset):
     r.close()
     assert (gpu != 0xFFFFFFFF).mean() > 0.3
     assert np.array_equal(gpu, cpu), "%d pixels differ" % int((gpu != cpu).sum())
+
+
+@pytest.mark.parametrize("rays", [True, False], ids=["rays", "no_rays"])
+def test_polygon_tables_in_device_memory_by_workgroup_and_by_hardware_wave_slot(dataset, monkeypatch, rays):
+    """From V = 6 on the two-technique kernels keep one of their two polygon tables in device memory: in the
+    region of the workgroup (default) or of the hardware slot the wave runs in (VKR_PSA_TABLE_INDEX=slot).  Config 4's lights
+    (3 ... 6 vertices: V = 7) with and without wavefront rays: both schemes give the oracle's frame."""
+    frames = {}
+    for index in ("block", "slot"):
+        monkeypatch.setenv("VKR_PSA_TABLE_INDEX", index)
+        r, image, visibility = gpu_render(dataset, 4, 320, 180, "libm", sample_count=2, trace_shadow_rays=rays)
+        assert r.app.shading_pass.max_polygon_vertex_count == 7
+        if index == "block":
+            cpu, _, _ = oracle_render(r, visibility=visibility, math_mode=0)
+        frames[index] = image
+        r.close()
+    monkeypatch.delenv("VKR_PSA_TABLE_INDEX")
+    assert compare(frames["block"], cpu)["bit_exact"]
+    assert np.array_equal(frames["block"].view(np.uint32), frames["slot"].view(np.uint32))

@@ -1170,7 +1170,7 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 			// whole pass, indexed by the hardware slot a wave runs in - shading_kernel.h hardware_wave_slot.  Measured, config 4:
 			// the same time and the same traffic, 16.40 / 16.42 ms and 8.8 / 9.0 GB per frame, profiles/r10o - the table stores
 			// reach the fabric either way -, so the scheme that assumes nothing about the hardware is the default)
-			static const bool by_block = !(getenv("VKR_PSA_TABLE_INDEX") != NULL && strcmp(getenv("VKR_PSA_TABLE_INDEX"), "slot") == 0);
+			const bool by_block = !(getenv("VKR_PSA_TABLE_INDEX") != NULL && strcmp(getenv("VKR_PSA_TABLE_INDEX"), "slot") == 0);
 			wavefront_buffers* owner = (frame && by_block) ? &frame->buffers : &frames->device_stream_buffers;
 			if (ensure_psa_table_memory(owner, (size_t) (by_block ? shade_grid_size(blocks_per_band) : kWaveSlots) * table_bytes_per_workgroup)) return 1;
 			p.psa_table_memory = owner->psa_table_memory;
