@@ -128,7 +128,10 @@ typedef struct screenshot_s {
 	tile t (row-major) belongs to rank t % rank_count, and a rank stores its tiles
 	densely one after the other ("slab").  rank_count == 1 renders in place unless
 	slab_layout is set (the dense layout with a single rank: how the exchange path of
-	include/vkr_slab_exchange.h is exercised on one GPU). */
+	include/vkr_slab_exchange.h is exercised on one GPU).  The blocks of a tile are consecutive in the
+	launch, so with one rank the tile size only decides which pixels are in flight together; tile_size 0
+	then picks the fastest order (64, or 128 above three megapixels: 2 % at BASELINE config 3).  Below
+	16, and 0 with a slab layout, means 16. */
 typedef struct tile_schedule_s {
 	uint32_t tile_size;
 	uint32_t rank, rank_count;

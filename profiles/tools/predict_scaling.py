@@ -116,7 +116,7 @@ def main():
             settings = renderer.setup_config(r, config, dataset)
             width, height = settings["width"], settings["height"]
             steps = 6 if config == 4 else 40
-            r.set_tiles(16, 0, 1, slab_layout=False)
+            r.set_tiles(0, 0, 1, slab_layout=False)
             r.create_targets(); r.create_pass(); r.render_visibility()
             whole_ms = time_frames(r, None, steps if config == 4 else 400)
             lines += ["## BASELINE config %s (%dx%d): whole frame on one GPU %.3f ms" % (config, width, height, whole_ms), "",

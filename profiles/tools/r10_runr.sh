@@ -1,0 +1,12 @@
+# tile size of the single-GPU block order (tile-major blocks, row-major frame): 16 (raster order of 16x16 blocks, the default so far), 32, 64, 128
+O=gpurun_out/r10r; mkdir -p $O
+Q="--no-extra --no-secondary --no-other-modes --no-host-frames --no-live-pmc"
+for round in 1 2; do for tile in 16 32 64 128; do for w in "3 bench" "3 large" "target bench" "2 bench" "4 bench"; do set -- $w
+S="--steps 200 --warmup 20"; [ $1 = 4 ] && S="--steps 20 --warmup 4"; [ $2 = large ] && S="--steps 60 --warmup 10"; [ $1 = 2 ] && S="--steps 1000 --warmup 100"
+VKR_BENCH_TILE=$tile python bench.py --config $1 --scene $2 $Q $S --details $O/t.json > $O/t.log 2>&1
+python - <<PY
+import json
+d=json.load(open("$O/t.json"))
+print(json.dumps({"tile": $tile, "config": "$1", "scene": "$2", "round": $round, "ms_per_step": d["ms_per_step"], "kernel_ms_alone": d["roofline"]["kernel_ms"], "pass_alone_ms": d["roofline"]["pass_alone_ms"], "pixels_differing": (d.get("parity") or {}).get("pixels_differing")}))
+PY
+done; done; done | tee $O/tile_order.jsonl

@@ -99,3 +99,24 @@ def test_polygon_tables_in_device_memory_by_workgroup_and_by_hardware_wave_slot(
     monkeypatch.delenv("VKR_PSA_TABLE_INDEX")
     assert compare(frames["block"], cpu)["bit_exact"]
     assert np.array_equal(frames["block"].view(np.uint32), frames["slot"].view(np.uint32))
+
+
+@pytest.mark.parametrize("config", [2, 3])
+def test_the_order_of_the_blocks_changes_no_pixel(dataset, config):
+    """With one rank that renders in place the tile size only decides which 16x16 blocks are consecutive in the launch (0 = the
+    automatic choice, 64 or 128 by frame size): same frame, same rays, for a frame whose size is no multiple of
+    any tile."""
+    frames = {}
+    for tile in (0, 16, 32, 64, 128):
+        r = renderer.Renderer(frames_in_flight=2)
+        renderer.setup_config(r, config, dataset, width=456, height=200, acceleration_structure=True)
+        r.set_tiles(tile, 0, 1)
+        r.create_targets()
+        r.create_pass()
+        r.render_visibility()
+        r.render()
+        r.render()
+        frames[tile] = (r.read_radiance(), r.last_ray_count())
+        r.close()
+    for tile, (image, rays) in frames.items():
+        assert np.array_equal(image.view(np.uint32), frames[16][0].view(np.uint32)) and rays == frames[16][1], tile

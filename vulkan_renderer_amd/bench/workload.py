@@ -67,7 +67,7 @@ def run_workload(job, config, role, scene=None, exchange_format=None):
     r.sync()
     load_ms = (time.perf_counter() - t) * 1e3
     structure = r.app.scene.acceleration_structure
-    r.set_tiles(args.tile_size if distributed else 16, rank, world if distributed else 1, slab_layout=distributed)
+    r.set_tiles(args.tile_size if distributed else int(os.environ.get("VKR_BENCH_TILE", "0")), rank, world if distributed else 1, slab_layout=distributed)
     r.create_targets()
     r.create_pass()
     t = time.perf_counter()
@@ -374,7 +374,7 @@ def mode_companion(job, config, mode, headline_image, width, height, sample_coun
     args, torch = job.args, job.torch
     r = renderer.Renderer(hip_device=job.local_rank, stream=job.stream.cuda_stream, arithmetic=mode, timing_stride=protocol_window(frames_in_flight, args.timing_stride), frames_in_flight=frames_in_flight)
     renderer.setup_config(r, config, job.dataset, width=width, height=height, sample_count=sample_count, acceleration_structure=args.bvh)
-    r.set_tiles(16, 0, 1, slab_layout=False)
+    r.set_tiles(0, 0, 1, slab_layout=False)
     r.create_targets()
     r.create_pass()
     r.render_visibility()
