@@ -47,7 +47,7 @@ def main():
             dataset = synthetic.write_dataset(tmp, grid=256, box_count=64, seed=1234, ltc_resolution=64, fresnel_count=51)
         r = renderer.Renderer(arithmetic=args.mode, frames_in_flight=3, timing_stride=64)
         renderer.setup_config(r, config, dataset)
-        r.set_tiles(args.tile if args.ranks > 1 else 16, args.rank, args.ranks, slab_layout=args.ranks > 1)
+        r.set_tiles(args.tile if args.ranks > 1 else 0, args.rank, args.ranks, slab_layout=args.ranks > 1)
         r.create_targets()
         target = None
         slab = None

@@ -68,7 +68,7 @@ def time_exchanged_frames(r, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def stand_in_collective(hip, peers, rank, ranks, workgroups=16):
+def stand_in_collective(hip, peers, rank, ranks, workgroups=0):
     """slab_gather_function_t: the N - 1 slabs of the peers land in their slots of `gathered` (two device-to-device copies
     around the rank's own slot, which the frame was shaded into).  workgroups > 0: copied by that many workgroups
     (copy_with_workgroups of the C-ABI) - a few compute units busy for a while, like the channels of a collective; 0: by
