@@ -1629,11 +1629,12 @@ VKR_DEV void store_final_color(const shade_params& p, size_t out_index, f3 color
 #define VKR_MODE_NAMESPACE exact_math
 #endif
 inline namespace VKR_MODE_NAMESPACE {
-// Occupancy.  With the polygon tables in LDS (two-technique strategies) the kernel needs 163 - 171
+// Occupancy.  With the polygon tables out of the registers (two-technique strategies) the kernel needs 163 - 171
 // VGPRs up to V = 7, the one-technique variants 160 - 175; asking for three waves per SIMD makes
-// the register allocator stop at 168 without scratch (checked for every variant by
-// profiles/tools/kernel_resources.sh).  Up to V = 6 the tables of twelve waves fit the 160 KB of
-// LDS of a CU, at V = 7 those of ten (three waves on two of the four SIMDs); V = 8 would spill.
+// the register allocator stop at 168 (no scratch at V = 5, 15 dwords per lane at V = 7; checked for every variant by
+// profiles/tools/kernel_resources.sh).  LDS comes in granules of 1 280 bytes: both tables of V <= 5 fit twelve times
+// into the 160 KB of a CU; from V = 6 on one table is in LDS and the other in device memory (psa_table_in_memory above),
+// and LDS limits no variant below the twelve waves that its registers allow; V = 8 would spill.
 constexpr uint32_t kShadeThreads = 64;
 // Workgroups to launch for `blocks` 16x16 pixel blocks (whole groups of 8 blocks x 4 patches)
 inline uint32_t shade_grid_size(uint32_t blocks) { return ((blocks + 7u) / 8u) * 32u; }

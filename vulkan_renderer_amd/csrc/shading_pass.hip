@@ -1651,7 +1651,11 @@ __global__ void __launch_bounds__(64) k_check_hardware_wave_slots(uint32_t* owne
 	float x = (float) threadIdx.x;
 	for (uint32_t i = 0; i != spin * (1u + (blockIdx.x & 7u)); ++i) x = fmaf(x, 1.0000001f, 1.0e-7f);
 	if (x == 12345.678f) out[2] = 1ull;
-	if (threadIdx.x == 0) atomicExch(owners + slot, 0u);
+	// (with the value it returns: the wave waits for the exchange before it ends.  Without, the wave may be gone - and the next
+	// one in its slot - while the exchange is still on its way, and the next wave finds the slot "taken": 149 of 400 000 waves in
+	// the first version of this check.  The same holds for any store: that a wave's last stores have landed when its successor in
+	// the slot starts is nothing the hardware promises, which is why regions by wave slot are an option of the pass, not its default)
+	if (threadIdx.x == 0 && atomicExch(owners + slot, 0u) == 0xFFFFFFFFu) out[2] = 2ull;
 }
 
 extern "C" int check_hardware_wave_slots(const device_t* device, uint32_t workgroups, uint32_t extra_lds_bytes, uint64_t out_shared_and_used[2]) {
