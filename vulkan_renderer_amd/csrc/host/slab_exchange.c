@@ -228,7 +228,13 @@ void destroy_slab_exchange(slab_exchange_t* exchange, application_t* app) {
 }
 
 /* Everything of an exchange but its collective: ranks, format, buffer sets, stream, events */
-static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app, slab_format_t format) {
+/* one_device: every rank of the exchange runs on this device (one rank, or the local transport).  Then the events that hand
+   a slab to the collective and the gathered slabs back to the pass release to DEVICE scope like every event of the pass (an
+   event without the flag releases to system scope: the L2s are written back and invalidated under the frames that are
+   running, every time it is recorded).  With peers on other devices they keep the default, system scope: a peer's kernel may
+   read this rank's slab over xGMI, and what the peers wrote into the gathered buffer has to be seen by the kernels that read
+   it here, past lines of the buffer's previous use that this device's L2 still holds. */
+static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app, slab_format_t format, int one_device) {
 	memset(exchange, 0, sizeof(*exchange));
 	const tile_schedule_t* schedule = &app->tile_schedule;
 	uint32_t rank_count = schedule->rank_count > 1 ? schedule->rank_count : 1;
@@ -248,12 +254,11 @@ static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app
 	exchange->set_count = sets;
 	if (hip_failed(hipSetDevice(app->device.hip_device), "selecting the device")) return 1;
 	int failed = hip_failed(hipStreamCreateWithFlags((hipStream_t*) &exchange->stream, hipStreamNonBlocking), "creating the exchange stream");
+	const unsigned event_flags = (one_device || rank_count == 1) ? (hipEventDisableTiming | hipEventReleaseToDevice) : hipEventDisableTiming;
 	for (uint32_t b = 0; b != sets && !failed; ++b) {
 		failed = hip_failed(hipMalloc(&exchange->gathered[b], exchange->send_bytes * rank_count), "allocating the gathered slabs")
-			/* (device-scope release like every event of the pass: an event without the flag releases to system scope, i.e. the
-			   L2s are written back under the frames that are running, every time it is recorded) */
-			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->rendered[b], hipEventDisableTiming | hipEventReleaseToDevice), "creating events")
-			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->assembled[b], hipEventDisableTiming | hipEventReleaseToDevice), "creating events");
+			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->rendered[b], event_flags), "creating events")
+			|| hip_failed(hipEventCreateWithFlags((hipEvent_t*) &exchange->assembled[b], event_flags), "creating events");
 		/* in place: what this rank sends is its own slot of the gathered slabs */
 		if (!failed) exchange->send[b] = (uint8_t*) exchange->gathered[b] + (size_t) exchange->rank * exchange->send_bytes;
 		if (!failed && format == slab_format_rgba32f) exchange->slab_radiance[b] = exchange->send[b];
@@ -275,7 +280,7 @@ static int create_exchange_buffers(slab_exchange_t* exchange, application_t* app
 }
 
 int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const slab_exchange_id_t* id, slab_format_t format) {
-	if (create_exchange_buffers(exchange, app, format)) return 1;
+	if (create_exchange_buffers(exchange, app, format, 0)) return 1;
 	rccl_binding_t* binding = (rccl_binding_t*) calloc(1, sizeof(rccl_binding_t));
 	exchange->binding = binding;
 	if (!binding || bind_rccl(binding)) {
@@ -294,16 +299,21 @@ int create_slab_exchange(slab_exchange_t* exchange, application_t* app, const sl
 	return 0;
 }
 
-int create_slab_exchange_with_gather(slab_exchange_t* exchange, application_t* app, slab_gather_function_t gather, void* gather_context, slab_format_t format) {
+static int create_exchange_with_gather(slab_exchange_t* exchange, application_t* app, slab_gather_function_t gather, void* gather_context, slab_format_t format, int one_device) {
 	if (!gather) {
 		printf("create_slab_exchange_with_gather() needs a gather function.\n");
 		memset(exchange, 0, sizeof(*exchange));
 		return 1;
 	}
-	if (create_exchange_buffers(exchange, app, format)) return 1;
+	if (create_exchange_buffers(exchange, app, format, one_device)) return 1;
 	exchange->gather = gather;
 	exchange->gather_context = gather_context;
 	return 0;
+}
+
+int create_slab_exchange_with_gather(slab_exchange_t* exchange, application_t* app, slab_gather_function_t gather, void* gather_context, slab_format_t format) {
+	/* (a transport of the caller may reach other devices) */
+	return create_exchange_with_gather(exchange, app, gather, gather_context, format, 0);
 }
 
 int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, local_slab_group_t* group, slab_format_t format) {
@@ -313,7 +323,7 @@ int create_local_slab_exchange(slab_exchange_t* exchange, application_t* app, lo
 		memset(exchange, 0, sizeof(*exchange));
 		return 1;
 	}
-	int failed = create_slab_exchange_with_gather(exchange, app, gather_with_copies, group, format);
+	int failed = create_exchange_with_gather(exchange, app, gather_with_copies, group, format, 1);
 	uint32_t rank = app->tile_schedule.rank;
 	if (!failed) {
 		pthread_mutex_lock(&group->mutex);
