@@ -180,9 +180,11 @@ struct frame_context {
 	hipEvent_t shaded;
 	hipEvent_t done;  // recorded behind the last kernel of the frame
 	bool recorded;    // `done` has been recorded: the next frame's resolve is ordered behind it
-	// what the context's most recent launch wrote its output to: a launch only has to be ordered behind the one before it
-	// when they write the same buffer (frames of a slab exchange take turns on several slabs, round 6)
-	const void* target;
+	// what the context's most recent launches wrote their output to (a ring of the last eight): a launch only has to be ordered
+	// behind another one when they write the same buffer (frames of a slab exchange take turns on several slabs, round 6); the
+	// context's `done` event lies behind all of them
+	const void* targets[8];
+	uint32_t target_cursor;
 	bool pending;     // device->stream has not been made to wait for `done` yet
 	uint32_t readers_seen;  // frame_pipeline::readers_generation this context's stream has waited for
 };
@@ -1303,9 +1305,16 @@ static int render_pass(application_t* app, void* out_radiance, void* out_rgb8) {
 				frame_context* previous = &frames->contexts[(frames->last + frames->depth - 1u) % frames->depth];
 				// (bands of one frame, and frames that share a target; VKR_ORDER_ALL_RESOLVES=1: always, as until round 5)
 				static const bool order_all = getenv("VKR_ORDER_ALL_RESOLVES") != NULL;
-				if (previous != frame && previous->recorded && (order_all || previous->target == (const void*) p.out_radiance || band != 0))
-					(void) hipStreamWaitEvent(stream, previous->done, 0);
-				frame->target = p.out_radiance;
+				// (a caller's ring of targets need not have the length of the pipeline: every other context one of whose recent
+				// launches wrote this target comes first)
+				for (uint32_t c = 0; c != frames->depth; ++c) {
+					frame_context* other = &frames->contexts[c];
+					if (other == frame || !other->recorded) continue;
+					bool same = order_all || (other == previous && band != 0);
+					for (const void* written : other->targets) same = same || written == (const void*) p.out_radiance;
+					if (same) (void) hipStreamWaitEvent(stream, other->done, 0);
+				}
+				frame->targets[frame->target_cursor++ % 8u] = p.out_radiance;
 				// ... and behind whatever still reads the target on device->stream (output encoding)
 				if (frame->readers_seen != frames->readers_generation) {
 					(void) hipStreamWaitEvent(stream, frames->readers_done, 0);
