@@ -27,6 +27,9 @@ constexpr uint32_t kWideRefillBelow = 166;
 // measurement): the first VKR_LDS_TOP_NODES nodes of the four-wide tree - its top levels, breadth
 // first: 1 + 4 + 16 = 21 nodes are three levels - are copied into LDS by every workgroup and fetched
 // from there (flat loads: the address decides between LDS and global memory).  0: off (the default).
+#ifndef VKR_TRACE_BLOCKER_CACHE
+#define VKR_TRACE_BLOCKER_CACHE 1
+#endif
 #ifndef VKR_LDS_TOP_NODES
 #define VKR_LDS_TOP_NODES 0
 #endif
@@ -232,6 +235,10 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 	float t_max = 0.0f;
 	// (byte index of the term's code: below 2^32, the host checks)
 	uint32_t item = kIdle, code_index = 0;
+#if VKR_TRACE_BLOCKER_CACHE
+	// the triangle that blocked this lane's most recent blocked ray, or kIdle (see try_last_blocker below)
+	uint32_t last_blocker = kIdle;
+#endif
 	// The stack pointer is the lane's LDS address itself (entries are THREADS x 4 bytes apart), so
 	// that a push is a store and a conditional add; entries beyond the LDS part only exist as a
 	// depth (`top` then points behind the LDS part and is never dereferenced)
@@ -304,6 +311,9 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 			float dist;
 			bool blocked = ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist);
 			// a blocked ray is done: its term keeps the code the shading kernel gave it
+#if VKR_TRACE_BLOCKER_CACHE
+			if (blocked) last_blocker = item & ~kLeafBit;
+#endif
 			if (blocked) { item = kIdle; top = my_stack; }
 			else pop = true;
 		}
@@ -317,6 +327,20 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 				item = top < lds_end ? VKR_STACK_AT(top) : my_spill[(size_t) ((top - lds_end) / kEntry) * spill_stride];
 			}
 		}
+	};
+	// Blocker cache (round 6).  A lane's consecutive rays mostly come from one pixel (or its neighbour) and go toward one
+	// light - the 64 rays of a batch are what the lanes of a shading wave queued for one sample of one light, and the next batch
+	// is the next sample - so the triangle that blocked the lane's last blocked ray is the most likely blocker of its next ray.
+	// A ray that has just been taken is tested against it before it walks: a hit ends the ray at once (any hit is a hit: the
+	// result of the query is the same boolean), a miss costs one triangle test next to the 6 - 22 node fetches of a walk.
+	auto try_last_blocker = [&]() {
+#if VKR_TRACE_BLOCKER_CACHE
+		if (item == 0u && last_blocker != kIdle) {
+			const float4* t = bvh.triangles + 3 * (size_t) last_blocker;
+			float dist;
+			if (ray_triangle<false>(t[0], t[1], t[2], o, d, 1.0e-3f, t_max, dist)) item = kIdle;
+		}
+#endif
 	};
 	bool batch_pending = fetch_batch();
 	// ---- a batch at a time, until the wave finds its lanes idle too often ------------------------------
@@ -345,6 +369,7 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 					item = kIdle;
 				}
 			}
+			try_last_blocker();
 		}
 		// walk until every lane has run dry
 		while (true) {
@@ -399,6 +424,7 @@ __global__ void __launch_bounds__(THREADS, kWideTraceWaves) trace_shadow_rays_wi
 					codes[code_index] = (uint8_t) kCodeVisible;
 					item = kIdle;
 				}
+				try_last_blocker();
 			}
 			if (pending_next >= pending_end) {
 				// the batch after it: requested now, looked at when lanes have run dry again
